@@ -1,0 +1,451 @@
+"""CPU oracle for the DELiVR tiled 3D-U-Net cFos inference path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in ``delivr_cfos_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and
+there only as the checker / the reported CPU baseline - never as the product path.
+
+It is a plain numpy / torch-CPU / scipy restatement of the reference's algorithm.  Every
+function cites the reference file:line it follows (paths relative to /root/reference).
+
+Pinning status (see DESIGN.md "Oracle"):
+  * tiler / skip / fp16 blend / count map / divide / threshold / eroded re-mask are PINNED:
+    ``oracle/make_goldens.py`` runs the reference's own ``sliding_window_inferer.py`` and
+    ``inference.py:create_nifti_seg`` (imported unchanged under stub modules, this container
+    only) and stores the results in ``tests/golden/``; ``tests/test_oracle_golden.py`` checks
+    this restatement against those vectors.
+  * spline-2 zoom and binary erosion are pinned by scipy itself (the reference's real dependency).
+  * PARITY UNPINNED (third-party, not vendored, not installable offline): the U-Net arithmetic
+    (MONAI 1.2.0 BasicUNet -> restated from torch.nn primitives, i.e. the same ATen kernels),
+    the 26-connected labelling + statistics (cc3d 3.12.3 -> restated with scipy.ndimage.label
+    and numpy), the block-mean down-sampler (scikit-image 0.19.3 downscale_local_mean).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# a2  tiler
+# ----------------------------------------------------------------------------------------------
+
+
+def scan_interval(image_size: Sequence[int], roi_size: Sequence[int], overlap: float) -> Tuple[int, ...]:
+    """inference/sliding_window_inferer.py:255-276 (_get_scan_interval)."""
+    out = []
+    for n, r in zip(image_size, roi_size):
+        if r == n:
+            out.append(int(r))
+        else:
+            iv = int(r * (1 - overlap))
+            out.append(iv if iv > 0 else 1)
+    return tuple(out)
+
+
+def dense_patch_starts(image_size: Sequence[int], roi_size: Sequence[int], interval: Sequence[int]) -> List[List[int]]:
+    """Per-dimension window starts.  MONAI 1.2.0 monai/data/utils.py:dense_patch_slices
+    [3P-recall]; call site inference/sliding_window_inferer.py:143."""
+    starts = []
+    for n, r, s in zip(image_size, roi_size, interval):
+        if s == 0:
+            num = 1
+        else:
+            num = int(math.ceil(float(n) / s))
+            scan_dim = next(d for d in range(num) if d * s + r >= n)
+            num = scan_dim + 1
+        dim_starts = []
+        for i in range(num):
+            st = i * s
+            st -= max(st + r - n, 0)
+            dim_starts.append(st)
+        starts.append(dim_starts)
+    return starts
+
+
+def window_list(image_size: Sequence[int], roi_size: Sequence[int], overlap: float) -> np.ndarray:
+    """All windows as an (n_win, 3) int array of (z0, y0, x0), enumerated first-dim slowest
+    (inference/sliding_window_inferer.py:140-145; itertools.product order in dense_patch_slices)."""
+    roi = tuple(min(r, n) for r, n in zip(roi_size, image_size))
+    iv = scan_interval(image_size, roi, overlap)
+    sz, sy, sx = dense_patch_starts(image_size, roi, iv)
+    return np.array([(z, y, x) for z in sz for y in sy for x in sx], dtype=np.int64).reshape(-1, 3)
+
+
+# ----------------------------------------------------------------------------------------------
+# a6  U-Net (MONAI 1.2.0 BasicUNet, restated from torch.nn primitives)
+# ----------------------------------------------------------------------------------------------
+
+FEATURES = (32, 32, 64, 128, 256, 32)
+N_PARAMS = 5_749_377
+
+
+def build_unet(seed: Optional[int] = 0, features: Sequence[int] = FEATURES):
+    """BasicUNet(spatial_dims=3, in=1, out=1, features, act="mish", norm=instance(affine),
+    dropout=0.1 -> identity in eval) - ctor at inference/inference.py:190-197.  Module names
+    and construction order follow MONAI 1.2.0 basic_unet.py [3P-recall] so that
+    ``state_dict()`` keys equal the checkpoint's (minus DataParallel's ``module.`` prefix)."""
+    import torch
+    from torch import nn
+
+    class ADN(nn.Sequential):
+        def __init__(self, c):
+            super().__init__()
+            self.add_module("N", nn.InstanceNorm3d(c, eps=1e-5, affine=True))
+            self.add_module("D", nn.Dropout(0.1))
+            self.add_module("A", nn.Mish())
+
+    class Convolution(nn.Sequential):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.add_module("conv", nn.Conv3d(cin, cout, 3, 1, 1, bias=True))
+            self.add_module("adn", ADN(cout))
+
+    class TwoConv(nn.Sequential):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.add_module("conv_0", Convolution(cin, cout))
+            self.add_module("conv_1", Convolution(cout, cout))
+
+    class Down(nn.Sequential):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.add_module("max_pooling", nn.MaxPool3d(2))
+            self.add_module("convs", TwoConv(cin, cout))
+
+    class UpSample(nn.Sequential):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.add_module("deconv", nn.ConvTranspose3d(cin, cout, 2, 2, bias=True))
+
+    class UpCat(nn.Module):
+        def __init__(self, cin, cat, cout, halves=True):
+            super().__init__()
+            up = cin // 2 if halves else cin
+            self.upsample = UpSample(cin, up)
+            self.convs = TwoConv(cat + up, cout)
+
+        def forward(self, x, x_e):
+            x0 = self.upsample(x)
+            return self.convs(torch.cat([x_e, x0], dim=1))
+
+    class BasicUNet(nn.Module):
+        def __init__(self, fea):
+            super().__init__()
+            self.conv_0 = TwoConv(1, fea[0])
+            self.down_1 = Down(fea[0], fea[1])
+            self.down_2 = Down(fea[1], fea[2])
+            self.down_3 = Down(fea[2], fea[3])
+            self.down_4 = Down(fea[3], fea[4])
+            self.upcat_4 = UpCat(fea[4], fea[3], fea[3])
+            self.upcat_3 = UpCat(fea[3], fea[2], fea[2])
+            self.upcat_2 = UpCat(fea[2], fea[1], fea[1])
+            self.upcat_1 = UpCat(fea[1], fea[0], fea[5], halves=False)
+            self.final_conv = nn.Conv3d(fea[5], 1, 1)
+
+        def forward(self, x):
+            x0 = self.conv_0(x)
+            x1 = self.down_1(x0)
+            x2 = self.down_2(x1)
+            x3 = self.down_3(x2)
+            x4 = self.down_4(x3)
+            u4 = self.upcat_4(x4, x3)
+            u3 = self.upcat_3(u4, x2)
+            u2 = self.upcat_2(u3, x1)
+            u1 = self.upcat_1(u2, x0)
+            return self.final_conv(u1)
+
+    if seed is not None:
+        torch.manual_seed(seed)
+    net = BasicUNet(tuple(features))
+    net.eval()
+    return net
+
+
+def randomize_affine(net, seed: int = 1) -> None:
+    """Give the InstanceNorm affine parameters and all biases non-trivial seeded values so that
+    parity tests exercise gamma/beta/bias paths (default init is gamma=1, beta=0)."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if ".adn.N.weight" in name:
+                p.copy_(1.0 + 0.25 * torch.randn(p.shape, generator=g))
+            elif ".adn.N.bias" in name:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+
+
+def unet_forward(net, x: np.ndarray) -> np.ndarray:
+    """fp32 forward of (B,1,d,h,w) -> logits (B,1,d,h,w) on the CPU
+    (call site inference/sliding_window_inferer.py:222)."""
+    import torch
+
+    with torch.no_grad():
+        return net(torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)).numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# a3-a5, a8  one sliding-window pass (gather, skip, flip, predict, blend)
+# ----------------------------------------------------------------------------------------------
+
+
+def sliding_window_pass(
+    volume: np.ndarray,  # (Zp,Yp,Xp) uint16
+    roi: Sequence[int],
+    predictor: Callable[[np.ndarray], np.ndarray],  # (B,1,d,h,w) f32 -> (B,1,d,h,w) f32
+    out_sum: np.ndarray,  # (Zp,Yp,Xp), mutated in place
+    count: Optional[np.ndarray],  # (Zp,Yp,Xp) uint8, mutated in place (may be None)
+    overlap: float = 0.5,
+    flip_dim: Optional[int] = None,  # 2 = Z, 3 = Y, 4 = X of (B,1,d,h,w)
+    sw_batch_size: int = 1,
+    threshold: int = 0,
+    fp16: bool = True,
+) -> dict:
+    """inference/sliding_window_inferer.py:161-251.  ``fp16=True`` reproduces the reference's
+    half-precision accumulate exactly (logits cast to fp16, fp16 += fp16); ``fp16=False`` is the
+    build's fp32 accumulate.  Returns {"n_windows", "n_skipped"}."""
+    wins = window_list(volume.shape, roi, overlap)
+    d, h, w = (min(r, n) for r, n in zip(roi, volume.shape))
+    n_skipped = 0
+    for g in range(0, len(wins), sw_batch_size):
+        batch = wins[g : g + sw_batch_size]
+        data = np.stack([volume[z : z + d, y : y + h, x : x + w] for z, y, x in batch]).astype(np.int32)
+        if data.max() <= threshold:  # :198-202 (per sw-batch!)
+            prob = np.full(data.shape, -1000.0, dtype=np.float32)
+            n_skipped += len(batch)
+        else:
+            xin = data.astype(np.float32)[:, None]
+            if flip_dim is not None:
+                xin = np.flip(xin, axis=flip_dim)
+            prob = predictor(np.ascontiguousarray(xin))
+            if flip_dim is not None:
+                prob = np.flip(prob, axis=flip_dim)
+            prob = prob[:, 0]
+        if fp16:
+            prob = prob.astype(np.float16)
+        for (z, y, x), p in zip(batch, prob):
+            out_sum[z : z + d, y : y + h, x : x + w] += p.astype(out_sum.dtype)
+            if count is not None:
+                count[z : z + d, y : y + h, x : x + w] += 1
+    return {"n_windows": len(wins), "n_skipped": n_skipped}
+
+
+def pass_schedule(tta: bool) -> List[Optional[int]]:
+    """flip_dim per pass: inference/inference.py:261-279.  Noise (std<=1e-3 on 1e2-1e4-scale
+    raw intensities) is treated as zero."""
+    sched: List[Optional[int]] = [None]
+    if tta:
+        for _ in range(4):
+            sched += [None, 2, 3]
+    return sched
+
+
+def padded_shape(stack_shape: Sequence[int], crop: Sequence[int]) -> Tuple[int, ...]:
+    """inference/inference.py:229-231."""
+    return tuple(int(np.ceil(n / c) * c) for n, c in zip(stack_shape, crop))
+
+
+# ----------------------------------------------------------------------------------------------
+# a9, a10  divide, threshold, eroded re-mask
+# ----------------------------------------------------------------------------------------------
+
+
+def zblock_planes(shape_zyx: Sequence[int], buf_size: int = 1000**3) -> Tuple[str, int]:
+    """Which axis np.lib.Arrayterator(buf_size) blocks along and how many indices per block, for a
+    3-D array: inference/inference.py:53,285 (numpy/lib/_arrayterator_impl.py:__iter__)."""
+    Z, Y, X = shape_zyx
+    count = buf_size
+    if count <= X:
+        return ("x", count)
+    count //= X
+    if count <= Y:
+        return ("y", count)
+    count //= Y
+    if count <= Z:
+        return ("z", max(count, 1))
+    return ("z", Z)
+
+
+def erode_l1(mask: np.ndarray, iterations: int = 30) -> np.ndarray:
+    """binary_erosion(mask, iterations, border_value=1) with the default 6-neighbourhood
+    (inference/inference.py:82) == (taxicab distance to nearest zero voxel > iterations-... ) -
+    evaluated here by scipy itself (the reference's real dependency)."""
+    from scipy.ndimage import binary_erosion
+
+    return binary_erosion(mask, iterations=iterations, border_value=1).astype(np.uint8)
+
+
+def finalize(
+    out_sum: np.ndarray,  # (Zp,Yp,Xp) Sigma logits (fp16 reference / fp32 build)
+    count: Optional[np.ndarray],  # (Zp,Yp,Xp) or None (sign-only rule)
+    raw: np.ndarray,  # (Zp,Yp,Xp) uint16 (the masked input)
+    stack_shape_zyx: Sequence[int],
+    threshold: float = 0.5,
+    erode_iters: int = 30,
+    buf_size: int = 1000**3,
+) -> np.ndarray:
+    """inference/inference.py:285-299 (divide) + :31-95 (create_nifti_seg): mean = sum/count,
+    sigmoid(float32(mean)) >= threshold, mask = erode(raw > 0) per z-block, product -> uint8."""
+    Z, Y, X = stack_shape_zyx
+    axis, nb = zblock_planes((Z, Y, X), buf_size)
+    if axis != "z":
+        raise NotImplementedError("Arrayterator blocks along y/x only for Y*X > buf_size")
+    s = out_sum[:Z, :Y, :X]
+    if count is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = (s / count[:Z, :Y, :X]).astype(s.dtype)
+    else:
+        mean = s
+    m32 = mean.astype(np.float32)
+    with np.errstate(over="ignore"):
+        sig = 1.0 / (1.0 + np.exp(-m32))
+    thr = sig >= np.float32(threshold)
+    out = np.zeros((Z, Y, X), dtype=np.uint8)
+    for z0 in range(0, Z, nb):
+        z1 = min(z0 + nb, Z)
+        keep = erode_l1((raw[z0:z1, :Y, :X] > 0).astype(np.uint8), erode_iters)
+        out[z0:z1] = thr[z0:z1].astype(np.uint8) * keep
+    return out
+
+
+def l1_distance_keep(mask: np.ndarray, radius: int) -> np.ndarray:
+    """Independent statement of the same erosion as a separable taxicab distance transform
+    (what the HIP kernel implements): keep voxel iff L1 distance to the nearest zero voxel inside
+    the block exceeds ``radius`` (outside the block counts as foreground)."""
+    INF = radius + 1
+    d = np.where(mask > 0, INF, 0).astype(np.int32)
+    for ax in range(3):
+        d = np.moveaxis(d, ax, 0)
+        for i in range(1, d.shape[0]):
+            d[i] = np.minimum(d[i], d[i - 1] + 1)
+        for i in range(d.shape[0] - 2, -1, -1):
+            d[i] = np.minimum(d[i], d[i + 1] + 1)
+        d = np.moveaxis(d, 0, ax)
+    return (d > radius).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------
+# a11-a13  connected components, statistics, CSV
+# ----------------------------------------------------------------------------------------------
+
+
+def ccl26(mask: np.ndarray) -> Tuple[np.ndarray, int]:
+    """cc3d.connected_components(bin_img, return_N=True) with the default connectivity 26
+    (count_blobs.py:61): labels 1..N numbered in C-raster order of each component's first
+    voxel [3P-recall], uint32."""
+    from scipy.ndimage import label
+
+    lab, n = label(mask > 0, structure=np.ones((3, 3, 3), dtype=bool))
+    return lab.astype(np.uint32), int(n)
+
+
+def cc_stats(labels: np.ndarray, n: int) -> dict:
+    """cc3d.statistics(labels, no_slice_conversion=True) (count_blobs.py:85) [3P-recall]:
+    voxel_counts (N+1,), bounding_boxes (N+1,6) = [z0,z1,y0,y1,x0,x1] inclusive, centroids
+    (N+1,3) float64 = coordinate sums / count in array-axis order.  Index 0 = background."""
+    flat = labels.ravel()
+    counts = np.bincount(flat, minlength=n + 1).astype(np.uint32)
+    zz, yy, xx = np.nonzero(labels)
+    lv = labels[zz, yy, xx]
+    sums = np.zeros((n + 1, 3), dtype=np.float64)
+    bbox = np.zeros((n + 1, 6), dtype=np.uint16)
+    for k, c in enumerate((zz, yy, xx)):
+        sums[:, k] = np.bincount(lv, weights=c.astype(np.float64), minlength=n + 1)
+        lo = np.full(n + 1, np.iinfo(np.int64).max, dtype=np.int64)
+        hi = np.full(n + 1, -1, dtype=np.int64)
+        np.minimum.at(lo, lv, c)
+        np.maximum.at(hi, lv, c)
+        bbox[1:, 2 * k] = lo[1:]
+        bbox[1:, 2 * k + 1] = hi[1:]
+    # background row: cc3d reports the background's own extent/centroid; restated the same way
+    bz, by, bx = np.nonzero(labels == 0)
+    if bz.size:
+        for k, c in enumerate((bz, by, bx)):
+            sums[0, k] = c.sum(dtype=np.float64)
+            bbox[0, 2 * k], bbox[0, 2 * k + 1] = c.min(), c.max()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        centroids = sums / counts[:, None].astype(np.float64)
+    return {"voxel_counts": counts, "bounding_boxes": bbox, "centroids": centroids}
+
+
+def cells_csv_text(stats: dict, n: int) -> str:
+    """count_blobs.py:98-114: rows for labels 1..N-1 (the last label is dropped), columns
+    [index(=0), Blob, Coords (python list repr of floats), Size]."""
+    import io
+
+    import pandas as pd
+
+    df = pd.DataFrame(columns=["Blob", "Coords", "Size"])
+    for i in range(1, n):
+        df_l = pd.DataFrame({"Blob": i, "Coords": [stats["centroids"][i].tolist()], "Size": stats["voxel_counts"][i]})
+        df = pd.concat([df, df_l])
+    buf = io.StringIO()
+    df.to_csv(buf)
+    return buf.getvalue()
+
+
+# ----------------------------------------------------------------------------------------------
+# a14, a15  resamplers
+# ----------------------------------------------------------------------------------------------
+
+
+def block_mean_u16(vol: np.ndarray, factors: Sequence[int]) -> np.ndarray:
+    """skimage.transform.downscale_local_mean(vol, factors).astype('uint16')
+    (downsample/downsample_and_mask.py:44) [3P-recall]: zero-pad to a multiple of the factors,
+    mean over each block in float64, truncating cast == floor(sum / prod(factors))."""
+    fz, fy, fx = factors
+    Z, Y, X = vol.shape
+    Zp, Yp, Xp = (-(-Z // fz) * fz, -(-Y // fy) * fy, -(-X // fx) * fx)
+    pad = np.zeros((Zp, Yp, Xp), dtype=np.float64)
+    pad[:Z, :Y, :X] = vol
+    m = pad.reshape(Zp // fz, fz, Yp // fy, fy, Xp // fx, fx).mean(axis=(1, 3, 5))
+    return m.astype(np.uint16)
+
+
+def zoom_spline2_f64(mask: np.ndarray, out_shape: Sequence[int]) -> np.ndarray:
+    """Own restatement of scipy.ndimage.zoom(mask, ratios, order=2, prefilter=False) before the
+    uint8 cast (downsample/downsample_and_mask.py:299): align-corners map, quadratic B-spline,
+    whole-sample mirror at the edges.  Returns float64."""
+    a = mask.astype(np.float64)
+    for ax, n_out in enumerate(out_shape):
+        n_in = a.shape[ax]
+        a = np.moveaxis(a, ax, 0)
+        res = np.zeros((n_out,) + a.shape[1:], dtype=np.float64)
+        scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+        for i in range(n_out):
+            x = i * scale
+            c = int(math.floor(x + 0.5))
+            t = x - c
+            ws = (0.5 * (0.5 - t) ** 2, 0.75 - t * t, 0.5 * (0.5 + t) ** 2)
+            for k, wt in zip((c - 1, c, c + 1), ws):
+                if n_in == 1:
+                    k = 0
+                else:
+                    p = 2 * (n_in - 1)
+                    k = k % p
+                    if k < 0:
+                        k += p
+                    if k >= n_in:
+                        k = p - k
+                res[i] += wt * a[k]
+        a = np.moveaxis(res, 0, ax)
+    return a
+
+
+def zoom_spline2_u8(mask: np.ndarray, out_shape: Sequence[int]) -> np.ndarray:
+    """The reference call itself (scipy is installed): zoom(..., output=uint8, order=2,
+    prefilter=False) with ratios out/in as at downsample/downsample_and_mask.py:285-299."""
+    from scipy.ndimage import zoom
+
+    ratios = tuple(o / i for o, i in zip(out_shape, mask.shape))
+    out = np.zeros(tuple(out_shape), dtype=np.uint8)
+    zoom(mask, ratios, output=out, order=2, prefilter=False)
+    return out
+
+
+def scale_coords(coords_zyx: np.ndarray, original_shape: Sequence[int], down_shape: Sequence[int]) -> np.ndarray:
+    """automate_mBrainaligner.py:261-284: factor = original/downsampled per axis; cells are
+    divided by the factor going down and multiplied going up."""
+    f = np.asarray(original_shape, dtype=np.float64) / np.asarray(down_shape, dtype=np.float64)
+    return np.asarray(coords_zyx, dtype=np.float64) / f

@@ -1,0 +1,287 @@
+"""Generate the committed fixtures under tests/golden/ (run ONLY in the build container).
+
+    python -m oracle.make_goldens
+
+TEST INFRASTRUCTURE.  Sources of truth:
+  * ref_*  : produced by the reference's own code (inference/sliding_window_inferer.py,
+             inference/inference.py:create_nifti_seg, count_blobs.py's CSV formatting) imported
+             unchanged under oracle/ref_harness.py's stubs.
+  * scipy_*: produced by scipy.ndimage (the reference's real dependency for zoom/erosion).
+  * orc_*  : produced by oracle/delivr_oracle.py for the third-party pieces that cannot run here
+             (MONAI U-Net -> torch.nn restatement, cc3d -> scipy.ndimage.label); these pin the
+             HIP path to the oracle on the GPU box, they do not pin the oracle to the reference.
+Fixtures are data only (inputs + expected outputs); no reference source text is stored.
+"""
+from __future__ import annotations
+
+import gzip
+import io
+import os
+import struct
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import delivr_oracle as orc  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def read_nifti_gz(path: str) -> np.ndarray:
+    """Minimal NIfTI-1 reader (nibabel is absent): returns the array in file (x-fastest) order
+    reshaped to (dim3, dim2, dim1)."""
+    raw = gzip.open(path, "rb").read()
+    dims = struct.unpack_from("<8h", raw, 40)
+    dtype_code = struct.unpack_from("<h", raw, 70)[0]
+    vox_offset = int(struct.unpack_from("<f", raw, 108)[0])
+    dt = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16,
+          768: np.uint32, 1024: np.int64, 1280: np.uint64}[dtype_code]
+    n = dims[1] * dims[2] * dims[3]
+    arr = np.frombuffer(raw, dtype=dt, count=n, offset=vox_offset)
+    return arr.reshape(dims[3], dims[2], dims[1])
+
+
+def det_predictor_torch(x):
+    """Deterministic stand-in network for the host-logic goldens: (x - 2000) / 1000."""
+    return (x - 2000.0) / 1000.0
+
+
+def make_blend_volume(seed=3):
+    rng = np.random.default_rng(seed)
+    vol = rng.integers(500, 5000, size=(64, 64, 32)).astype(np.uint16)
+    vol[:, :, 16:] = 0  # background half along X
+    vol[40:, 40:, :] = 0  # plus a background corner
+    return vol
+
+
+def golden_tiler(swi):
+    from monai.data.utils import dense_patch_slices  # the stub the reference itself calls
+
+    cases = [((64, 64, 32), (32, 32, 16)), ((96, 96, 64), (96, 96, 64)), ((100, 70, 50), (32, 32, 16)),
+             ((128, 128, 128), (64, 64, 64)), ((192, 96, 64), (96, 96, 64))]
+    out = {}
+    for i, (img, roi) in enumerate(cases):
+        iv = swi._get_scan_interval(img, roi, 3, 0.5)
+        sl = dense_patch_slices(img, roi, iv)
+        starts = np.array([[s.start for s in w] for w in sl], dtype=np.int64)
+        out[f"case{i}_image"] = np.array(img)
+        out[f"case{i}_roi"] = np.array(roi)
+        out[f"case{i}_interval"] = np.array(iv)
+        out[f"case{i}_starts"] = starts
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "ref_tiler.npz"), **out)
+    print("ref_tiler.npz", len(cases), "cases")
+
+
+def golden_blend(swi):
+    import torch
+
+    vol = make_blend_volume()
+    inp = vol[None, None]
+    out = {"volume": vol}
+    for tag, sched, bs in (("p1_b1", [None], 1), ("p1_b4", [None], 4), ("p13_b1", orc.pass_schedule(True), 1)):
+        acc = torch.zeros(inp.shape, dtype=torch.float16)
+        cnt = torch.zeros(inp.shape, dtype=torch.uint8)
+        inferer = swi.SlidingWindowInferer(roi_size=(32, 32, 16), sw_batch_size=bs, overlap=0.5, mode="gaussian",
+                                           padding_mode="replicate", sw_device=torch.device("cpu"),
+                                           device=torch.device("cpu"))
+        for k, flip in enumerate(sched):
+            kw = dict(output_image=acc, count_map=cnt)
+            if k > 0:
+                kw["tta"] = True
+            if flip is not None:
+                kw["flip_dim"] = flip
+            inferer(inp, det_predictor_torch, **kw)
+        out[f"{tag}_sum"] = acc.numpy()[0, 0]
+        out[f"{tag}_count"] = cnt.numpy()[0, 0]
+    np.savez_compressed(os.path.join(GOLD, "ref_blend.npz"), **out)
+    print("ref_blend.npz")
+
+
+def golden_finalize(inf):
+    """create_nifti_seg on random fp16 means + a raw volume with zero margins; second case forces
+    >= 2 Arrayterator z-blocks by handing the (unchanged) reference function a numpy proxy whose
+    Arrayterator ignores the hard-coded 1000**3 and uses a small buffer."""
+    rng = np.random.default_rng(5)
+    Z, Y, X = 40, 70, 66
+    Zp, Yp, Xp = 48, 80, 80
+    raw = np.zeros((1, 1, Zp, Yp, Xp), dtype=np.uint16)
+    raw[0, 0, :Z, :Y, :X] = rng.integers(1, 4000, size=(Z, Y, X))
+    raw[0, 0, :, :, :3] = 0  # 3 zero columns -> 33 zero columns after the L1-30 erosion
+    raw[0, 0, 20:23, 30:50, 40:60] = 0  # an interior hole
+    mean = (rng.standard_normal((1, 1, Zp, Yp, Xp)) * 2).astype(np.float16)
+    out = {"raw": raw[0, 0], "mean": mean[0, 0], "stack_shape": np.array([1, 1, Z, Y, X])}
+    real_np = inf.np
+    for tag, buf in (("oneblock", None), ("blocks", 12 * Y * X)):
+        if buf is not None:
+            proxy = types.SimpleNamespace(**{k: getattr(real_np, k) for k in dir(real_np) if not k.startswith("__")})
+            lib = types.SimpleNamespace(format=real_np.lib.format,
+                                        Arrayterator=lambda a, _b, buf=buf: real_np.lib.Arrayterator(a, buf))
+            proxy.lib = lib
+            inf.np = proxy
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "binaries.npy")
+            try:
+                inf.create_nifti_seg(threshold=0.5, model_output=mean, output_file=f, network_output_file=None,
+                                     dataset=raw, original_stack_shape=(1, 1, Z, Y, X))
+            finally:
+                inf.np = real_np
+            with open(f, "rb") as fh:
+                header = fh.read(128)
+            out[f"{tag}_binaries"] = np.load(f)
+            out[f"{tag}_header"] = np.frombuffer(header, dtype=np.uint8)
+        out[f"{tag}_buf"] = np.array(buf if buf is not None else 1000**3)
+    np.savez_compressed(os.path.join(GOLD, "ref_finalize.npz"), **out)
+    print("ref_finalize.npz", {k: int(out[k].sum()) for k in ("oneblock_binaries", "blocks_binaries")})
+
+
+def golden_ccl_and_csv():
+    """CCL labels/stats from the oracle (scipy) on two of the reference's gt patches + adversarial
+    shapes; CSV text produced by the reference's own count_blobs() with cc3d stubbed by the oracle
+    (count_blobs.py:98-114 is the formatting code that is being pinned)."""
+    import pickle
+
+    td_root = os.path.join(ref_harness.REFERENCE_ROOT, "training_data", "cFos", "gt")
+    out = {}
+    names = ["patchvolume_1008_0.nii.gz", "patchvolume_1008_3.nii.gz"]
+    for i, nm in enumerate(names):
+        gt = (read_nifti_gz(os.path.join(td_root, nm)) > 0).astype(np.uint8)
+        lab, n = orc.ccl26(gt)
+        st = orc.cc_stats(lab, n)
+        out[f"gt{i}_maskbits"] = np.packbits(gt.ravel())
+        out[f"gt{i}_shape"] = np.array(gt.shape)
+        out[f"gt{i}_n"] = np.array(n)
+        out[f"gt{i}_labels"] = lab.astype(np.uint16)
+        out[f"gt{i}_counts"] = st["voxel_counts"]
+        out[f"gt{i}_bbox"] = st["bounding_boxes"]
+        out[f"gt{i}_centroids"] = st["centroids"]
+        print(nm, "components:", n)
+    # adversarial: diagonal-only 26-links, single voxels, border-touching, a U shape that merges late
+    adv = np.zeros((12, 16, 20), dtype=np.uint8)
+    for k in range(8):
+        adv[k, k, k] = 1  # pure 3-D diagonal chain
+    adv[0, 15, 19] = 1
+    adv[11, 0, 0] = 1
+    adv[5, 2:14, 10] = 1
+    adv[5, 2, 10:18] = 1
+    adv[5, 13, 10:18] = 1
+    adv[5, 3:13, 17] = 1  # ring
+    adv[7, 6, 12] = 1
+    adv[8, 7, 13] = 1  # 2-voxel diagonal
+    adv[10:12, 10:12, 3:5] = 1
+    lab, n = orc.ccl26(adv)
+    st = orc.cc_stats(lab, n)
+    out.update(adv_mask=adv, adv_n=np.array(n), adv_labels=lab.astype(np.uint16), adv_counts=st["voxel_counts"],
+               adv_bbox=st["bounding_boxes"], adv_centroids=st["centroids"])
+    np.savez_compressed(os.path.join(GOLD, "orc_ccl.npz"), **out)
+
+    # ---- CSV through the reference's count_blobs() ----
+    gt = np.unpackbits(out["gt0_maskbits"])[: 100**3].reshape(100, 100, 100)
+    cc3d = types.ModuleType("cc3d")
+
+    def connected_components(img, return_N=False, out_file=None):
+        lab, n = orc.ccl26(np.asarray(img))
+        return (lab, n) if return_N else lab
+
+    cc3d.connected_components = connected_components
+    cc3d.statistics = lambda labels, no_slice_conversion=False: orc.cc_stats(labels, int(labels.max()))
+    sys.modules["cc3d"] = cc3d
+    fh_stub = types.ModuleType("filehandling")
+    fh_stub.read_nifti = fh_stub.write_nifti = None
+    sys.modules["filehandling"] = fh_stub
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("delivr_ref_count_blobs",
+                                                  os.path.join(ref_harness.REFERENCE_ROOT, "count_blobs.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    with tempfile.TemporaryDirectory() as td:
+        p_in = os.path.join(td, "in")
+        p_out = os.path.join(td, "out") + "/"
+        os.makedirs(os.path.join(p_in, "brainA", "binary_segmentations"))
+        np.save(os.path.join(p_in, "brainA", "binary_segmentations", "binaries.npy"), gt.astype(np.uint8))
+        settings = {"postprocessing": {"output_location": p_out}, "FLAGS": {"LOAD_ALL_RAM": True}}
+        cb.count_blobs(settings, p_in, 0, "brainA", (1, 1, 100, 100, 100))
+        files = sorted(os.listdir(p_out))
+        csv_name = [f for f in files if f.endswith(".csv")][0]
+        csv_text = open(os.path.join(p_out, csv_name)).read()
+        with open(os.path.join(p_out, "brainA-stats.pickle"), "rb") as f:
+            stats = pickle.load(f)
+    np.savez_compressed(os.path.join(GOLD, "ref_csv.npz"), csv_name=np.array(csv_name),
+                        csv_text=np.array(csv_text), files=np.array(files),
+                        n=np.array(int(out["gt0_n"])), stat_keys=np.array(sorted(stats.keys())))
+    print("ref_csv.npz", csv_name, len(csv_text), "bytes", files)
+
+
+def golden_unet():
+    """Seeded random-weight U-Net logits (fp32, torch CPU) for a 32^3 and a 48x32x16 patch,
+    per-parameter checksums so the GPU box can verify that the seed reproduces the weights, and
+    per-stage activations checksums."""
+    import torch
+
+    from delivr_cfos_amd.synth import synth_volume_np
+
+    net = orc.build_unet(seed=0)
+    orc.randomize_affine(net, seed=1)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == orc.N_PARAMS, n_params
+    vol = synth_volume_np((64, 64, 64), seed=7, dense=True)
+    x32 = vol[16:48, 16:48, 16:48].astype(np.float32)[None, None]
+    x_odd = vol[8:56, 16:48, 24:40].astype(np.float32)[None, None]  # 48x32x16
+    out = {"x32": vol[16:48, 16:48, 16:48], "x_odd": vol[8:56, 16:48, 24:40],
+           "logits32": orc.unet_forward(net, x32)[0, 0], "logits_odd": orc.unet_forward(net, x_odd)[0, 0]}
+    names, sums, abss = [], [], []
+    for k, v in net.state_dict().items():
+        names.append(k)
+        sums.append(float(v.double().sum()))
+        abss.append(float(v.double().abs().sum()))
+    out.update(param_names=np.array(names), param_sum=np.array(sums), param_abs=np.array(abss))
+    # stage activations (mean, std) to localise a mismatch
+    acts = {}
+    hooks = []
+    for nm, m in net.named_modules():
+        if nm and nm.count(".") == 0:
+            hooks.append(m.register_forward_hook(lambda mod, i, o, nm=nm: acts.__setitem__(nm, o)))
+    with torch.no_grad():
+        net(torch.as_tensor(x32))
+    for h in hooks:
+        h.remove()
+    out["stage_names"] = np.array(list(acts.keys()))
+    out["stage_mean"] = np.array([float(a.double().mean()) for a in acts.values()])
+    out["stage_std"] = np.array([float(a.double().std()) for a in acts.values()])
+    np.savez_compressed(os.path.join(GOLD, "orc_unet.npz"), **out)
+    print("orc_unet.npz logits32 mean/std", out["logits32"].mean(), out["logits32"].std(),
+          "frac>=0", (out["logits32"] >= 0).mean())
+
+
+def golden_resample():
+    rng = np.random.default_rng(11)
+    vol = rng.integers(0, 65535, size=(9, 31, 47)).astype(np.uint16)
+    bm = orc.block_mean_u16(vol, (4, 15, 15))
+    mask = (rng.random((7, 9, 11)) < 0.5).astype(np.uint8)
+    zo = orc.zoom_spline2_u8(mask, (26, 40, 37))
+    np.savez_compressed(os.path.join(GOLD, "scipy_resample.npz"), bm_in=vol, bm_factors=np.array([4, 15, 15]),
+                        bm_out=bm, zoom_in=mask, zoom_out=zo)
+    print("scipy_resample.npz")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    swi, inf = ref_harness.load_reference_inference()
+    golden_tiler(swi)
+    golden_blend(swi)
+    golden_finalize(inf)
+    golden_ccl_and_csv()
+    golden_unet()
+    golden_resample()
+
+
+if __name__ == "__main__":
+    main()

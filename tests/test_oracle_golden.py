@@ -1,0 +1,136 @@
+"""The CPU oracle against the committed golden vectors (tests/golden/, made by
+oracle/make_goldens.py from the reference's own code / scipy).  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import delivr_oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_tiler_matches_reference(golden_dir):
+    g = _load(golden_dir, "ref_tiler.npz")
+    for i in range(int(g["n_cases"])):
+        img, roi = tuple(g[f"case{i}_image"]), tuple(g[f"case{i}_roi"])
+        assert orc.scan_interval(img, roi, 0.5) == tuple(g[f"case{i}_interval"])
+        np.testing.assert_array_equal(orc.window_list(img, roi, 0.5), g[f"case{i}_starts"])
+
+
+def _det(x):
+    return (x - 2000.0) / 1000.0
+
+
+@pytest.mark.parametrize("tag,bs,tta", [("p1_b1", 1, False), ("p1_b4", 4, False), ("p13_b1", 1, True)])
+def test_blend_matches_reference(golden_dir, tag, bs, tta):
+    g = _load(golden_dir, "ref_blend.npz")
+    vol = g["volume"]
+    acc = np.zeros(vol.shape, dtype=np.float16)
+    cnt = np.zeros(vol.shape, dtype=np.uint8)
+    for flip in orc.pass_schedule(tta):
+        orc.sliding_window_pass(vol, (32, 32, 16), _det, acc, cnt, 0.5, flip, sw_batch_size=bs, fp16=True)
+    np.testing.assert_array_equal(cnt, g[f"{tag}_count"])
+    np.testing.assert_array_equal(acc.view(np.uint16), g[f"{tag}_sum"].view(np.uint16))  # bit-exact fp16
+
+
+def test_per_batch_skip_differs_from_per_tile(golden_dir):
+    """D7: the reference decides the background skip per sw-batch; the build adopts per tile."""
+    g = _load(golden_dir, "ref_blend.npz")
+    assert not np.array_equal(g["p1_b1_sum"], g["p1_b4_sum"])
+
+
+@pytest.mark.parametrize("tag", ["oneblock", "blocks"])
+def test_finalize_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, "ref_finalize.npz")
+    Z, Y, X = (int(v) for v in g["stack_shape"][2:])
+    out = orc.finalize(g["mean"], None, g["raw"], (Z, Y, X), 0.5, 30, buf_size=int(g[f"{tag}_buf"]))
+    np.testing.assert_array_equal(out, g[f"{tag}_binaries"])
+    # 3 zero columns -> 33 zero columns (L1-radius-30 erosion)
+    assert out[:, :, :33].sum() == 0
+    hdr = bytes(g[f"{tag}_header"])
+    assert len(hdr) == 128 and hdr[:6] == b"\x93NUMPY" and hdr.endswith(b"\n")
+
+
+def test_l1_distance_form_equals_scipy_erosion():
+    rng = np.random.default_rng(0)
+    m = (rng.random((20, 40, 50)) > 0.002).astype(np.uint8)
+    for r in (1, 5, 30):
+        np.testing.assert_array_equal(orc.l1_distance_keep(m, r), orc.erode_l1(m, r))
+
+
+def test_ccl_goldens_and_invariants(golden_dir):
+    g = _load(golden_dir, "orc_ccl.npz")
+    for key in ("gt0", "gt1"):
+        shape = tuple(g[f"{key}_shape"])
+        mask = np.unpackbits(g[f"{key}_maskbits"])[: int(np.prod(shape))].reshape(shape)
+        lab, n = orc.ccl26(mask)
+        assert n == int(g[f"{key}_n"])
+        np.testing.assert_array_equal(lab, g[f"{key}_labels"])
+        # numbering rule: label k's first voxel (raster order) precedes label k+1's
+        first = np.full(n + 1, lab.size, dtype=np.int64)
+        idx = np.nonzero(lab.ravel())[0]
+        np.minimum.at(first, lab.ravel()[idx], idx)
+        assert np.all(np.diff(first[1:]) > 0)
+        st = orc.cc_stats(lab, n)
+        np.testing.assert_array_equal(st["voxel_counts"], g[f"{key}_counts"])
+        np.testing.assert_array_equal(st["bounding_boxes"], g[f"{key}_bbox"])
+        np.testing.assert_allclose(st["centroids"][1:], g[f"{key}_centroids"][1:], rtol=0, atol=0)
+    lab, n = orc.ccl26(g["adv_mask"])
+    assert n == int(g["adv_n"])
+    np.testing.assert_array_equal(lab, g["adv_labels"])
+    # diagonal chain is ONE component under 26-connectivity
+    assert len(set(lab[k, k, k] for k in range(8))) == 1
+
+
+def test_csv_format_matches_reference(golden_dir):
+    g = _load(golden_dir, "ref_csv.npz")
+    c = _load(golden_dir, "orc_ccl.npz")
+    shape = tuple(c["gt0_shape"])
+    mask = np.unpackbits(c["gt0_maskbits"])[: int(np.prod(shape))].reshape(shape)
+    lab, n = orc.ccl26(mask)
+    txt = orc.cells_csv_text(orc.cc_stats(lab, n), n)
+    assert txt == str(g["csv_text"])
+    assert str(g["csv_name"]) == "(100, 100, 100)_brainA.csv"
+    assert txt.count("\n") == n  # header + rows 1..N-1 (last label dropped, count_blobs.py:104)
+
+
+def test_unet_seed_reproduces_and_logits(golden_dir):
+    g = _load(golden_dir, "orc_unet.npz")
+    net = orc.build_unet(seed=0)
+    orc.randomize_affine(net, seed=1)
+    assert sum(p.numel() for p in net.parameters()) == orc.N_PARAMS
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["param_names"]]
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["param_sum"], rtol=1e-12, atol=1e-12)
+    out = orc.unet_forward(net, g["x32"].astype(np.float32)[None, None])[0, 0]
+    np.testing.assert_allclose(out, g["logits32"], rtol=1e-4, atol=1e-4)
+
+
+def test_resamplers(golden_dir):
+    g = _load(golden_dir, "scipy_resample.npz")
+    np.testing.assert_array_equal(orc.block_mean_u16(g["bm_in"], tuple(g["bm_factors"])), g["bm_out"])
+    # integer form == float mean then truncate
+    v = g["bm_in"].astype(np.int64)
+    f = tuple(int(x) for x in g["bm_factors"])
+    Zp, Yp, Xp = (-(-n // k) * k for n, k in zip(v.shape, f))
+    pad = np.zeros((Zp, Yp, Xp), dtype=np.int64)
+    pad[: v.shape[0], : v.shape[1], : v.shape[2]] = v
+    s = pad.reshape(Zp // f[0], f[0], Yp // f[1], f[1], Xp // f[2], f[2]).sum(axis=(1, 3, 5))
+    np.testing.assert_array_equal((s // (f[0] * f[1] * f[2])).astype(np.uint16), g["bm_out"])
+    z = orc.zoom_spline2_f64(g["zoom_in"], g["zoom_out"].shape)
+    mine = np.floor(z + 0.5).astype(np.uint8)
+    ties = np.abs(z - 0.5) < 1e-9
+    assert np.array_equal(mine[~ties], g["zoom_out"][~ties])
+    np.testing.assert_array_equal(orc.zoom_spline2_u8(g["zoom_in"], g["zoom_out"].shape), g["zoom_out"])
+
+
+def test_arrayterator_block_rule():
+    for shape, buf in (((40, 70, 66), 12 * 70 * 66), ((10, 7, 5), 1000**3), ((9, 4, 5), 41), ((9, 4, 5), 20)):
+        a = np.zeros(shape, dtype=np.uint8)
+        blocks = [b.shape for b in np.lib.Arrayterator(a, buf)]
+        axis, nb = orc.zblock_planes(shape, buf)
+        if axis == "z":
+            assert blocks[0] == (min(nb, shape[0]),) + shape[1:]
