@@ -1,0 +1,120 @@
+"""ctypes binding of libdelivr_hip.so (C ABI: include/delivr_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing this module raises at
+import of the symbol table, and every op fails loudly when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdelivr_hip.so")
+
+DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
+PREC_F32, PREC_BF16 = 0, 1
+N_CONV, N_DECONV = 18, 4
+PROF_MAX = 32
+
+
+class DelivrHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdelivr_hip error {code}: {msg}")
+        self.code = code
+
+
+class UnetWeights(C.Structure):
+    _fields_ = [
+        ("features", C.c_int * 6),
+        ("conv_w", C.c_void_p * N_CONV),
+        ("conv_b", C.c_void_p * N_CONV),
+        ("norm_g", C.c_void_p * N_CONV),
+        ("norm_b", C.c_void_p * N_CONV),
+        ("deconv_w", C.c_void_p * N_DECONV),
+        ("deconv_b", C.c_void_p * N_DECONV),
+        ("final_w", C.c_void_p),
+        ("final_b", C.c_void_p),
+    ]
+
+
+class SwParams(C.Structure):
+    _fields_ = [
+        ("Zp", C.c_int), ("Yp", C.c_int), ("Xp", C.c_int),
+        ("roi", C.c_int * 3),
+        ("overlap", C.c_float),
+        ("flip_dim", C.c_int),
+        ("skip_threshold", C.c_int),
+        ("precision", C.c_int),
+        ("sw_batch", C.c_int),
+        ("win_begin", C.c_int64),
+        ("win_end", C.c_int64),
+        ("z0", C.c_int), ("nz", C.c_int),
+        ("repeat", C.c_int),
+    ]
+
+
+class SwStats(C.Structure):
+    _fields_ = [("n_windows", C.c_int64), ("n_skipped", C.c_int64), ("n_forward_launches", C.c_int64)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/delivr_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "dlv_abi_version": (C.c_int, []),
+    "dlv_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "dlv_ctx_destroy": (C.c_int, [_P]),
+    "dlv_last_error": (C.c_char_p, [_P]),
+    "dlv_sync": (C.c_int, [_P]),
+    "dlv_stream": (_P, [_P]),
+    "dlv_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "dlv_free": (C.c_int, [_P, _P]),
+    "dlv_memset_dev": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "dlv_copy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "dlv_copy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "dlv_unet_load": (C.c_int, [_P, C.POINTER(UnetWeights)]),
+    "dlv_unet_blob_size": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "dlv_unet_blob_dev": (C.c_int, [_P, C.POINTER(_P)]),
+    "dlv_unet_alloc_blob": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "dlv_unet_forward_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dlv_sw_num_windows": (C.c_int, [C.POINTER(SwParams), C.POINTER(C.c_int64)]),
+    "dlv_sw_window_starts": (C.c_int, [C.POINTER(SwParams), C.POINTER(C.c_int64), C.c_int64]),
+    "dlv_sw_infer_dev": (C.c_int, [_P, C.POINTER(SwParams), _P, _P, _P, C.POINTER(SwStats)]),
+    "dlv_finalize_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                   C.c_int, _P, _P]),
+    "dlv_ccl26_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]),
+    "dlv_cc_stats_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint64, _P, _P, _P]),
+    "dlv_block_mean_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "dlv_zoom_spline2_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "dlv_mask_pad_u16_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "dlv_trilinear_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
+    "dlv_prof_reset": (C.c_int, [_P]),
+    "dlv_prof_report": (C.c_int, [_P, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the shared library and binds every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C delivr_cfos_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dlv_abi_version() != 1:
+        raise ImportError("libdelivr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

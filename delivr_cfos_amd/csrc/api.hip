@@ -1,0 +1,370 @@
+// api.hip - context, memory helpers, weight loading and the in-library kernel timer of
+// libdelivr_hip.so (C ABI declared in include/delivr_hip.h).
+#include "common.h"
+
+int dlv_fail(dlv_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (slot < 0 || slot >= WS_N_SLOTS) return dlv_fail(ctx, DLV_EINVAL, "bad scratch slot %d", slot);
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DLV_HIP(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + (bytes >> 3);  // 12.5 % headroom against regrowth
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&ctx->ws[slot], want);
+        }
+        if (e != hipSuccess)
+            return dlv_fail(ctx, DLV_ENOMEM, "scratch slot %d: hipMalloc(%zu) failed: %s", slot, bytes,
+                            hipGetErrorString(e));
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return DLV_OK;
+}
+
+// ---- kernel timer ------------------------------------------------------------------------------
+DlvProf::DlvProf(dlv_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+    if (!c->prof_on) return;
+    int slot = -1;
+    for (size_t i = 0; i < c->prof_slots.size(); ++i)
+        if (strncmp(c->prof_slots[i].name, name, sizeof(c->prof_slots[i].name)) == 0) slot = (int)i;
+    if (slot < 0) {
+        if (c->prof_slots.size() >= DLV_PROF_MAX_KERNELS) return;
+        DlvProfSlot s;
+        memset(s.name, 0, sizeof(s.name));
+        strncpy(s.name, name, sizeof(s.name) - 1);
+        c->prof_slots.push_back(s);
+        slot = (int)c->prof_slots.size() - 1;
+    }
+    c->prof_slots[slot].flops += flops;
+    c->prof_slots[slot].bytes += bytes;
+    DlvProfPending p;
+    p.slot = slot;
+    for (hipEvent_t* e : {&p.a, &p.b}) {
+        if (!c->prof_free.empty()) {
+            *e = c->prof_free.back();
+            c->prof_free.pop_back();
+        } else if (hipEventCreate(e) != hipSuccess) {
+            return;
+        }
+    }
+    (void)hipEventRecord(p.a, c->stream);
+    c->prof_pending.push_back(p);
+    idx = (int)c->prof_pending.size() - 1;
+}
+void DlvProf::end() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_pending[idx].b, ctx->stream);
+}
+
+static int prof_drain(dlv_ctx* ctx) {
+    if (ctx->prof_pending.empty()) return DLV_OK;
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof_slots[p.slot].total_ms += ms;
+            ctx->prof_slots[p.slot].launches += 1;
+        }
+        ctx->prof_free.push_back(p.a);
+        ctx->prof_free.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
+    return DLV_OK;
+}
+
+// ---- weight blob layout --------------------------------------------------------------------------
+static const int kConvLevel[DLV_N_CONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
+
+static void conv_channels(const int f[6], int cin[DLV_N_CONV], int cout[DLV_N_CONV], int dcin[DLV_N_DECONV],
+                          int dcout[DLV_N_DECONV]) {
+    // MONAI BasicUNet topology (features f[0..5]); upcat_1 keeps its channels (halves=False)
+    int ci[DLV_N_CONV] = {1, f[0], f[0], f[1], f[1], f[2], f[2], f[3], f[3], f[4],
+                          f[3] + f[4] / 2, f[3], f[2] + f[3] / 2, f[2], f[1] + f[2] / 2, f[1], f[0] + f[1], f[5]};
+    int co[DLV_N_CONV] = {f[0], f[0], f[1], f[1], f[2], f[2], f[3], f[3], f[4], f[4],
+                          f[3], f[3], f[2], f[2], f[1], f[1], f[5], f[5]};
+    for (int i = 0; i < DLV_N_CONV; ++i) {
+        cin[i] = ci[i];
+        cout[i] = co[i];
+    }
+    int di[DLV_N_DECONV] = {f[4], f[3], f[2], f[1]};
+    int dco[DLV_N_DECONV] = {f[4] / 2, f[3] / 2, f[2] / 2, f[1]};
+    for (int j = 0; j < DLV_N_DECONV; ++j) {
+        dcin[j] = di[j];
+        dcout[j] = dco[j];
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// walks the blob layout; if base != nullptr assigns the pointers into ctx
+static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
+    int cin[DLV_N_CONV], cout[DLV_N_CONV], dcin[DLV_N_DECONV], dcout[DLV_N_DECONV];
+    conv_channels(f, cin, cout, dcin, dcout);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off = align256(off + bytes);
+        return p;
+    };
+    for (int i = 0; i < DLV_N_CONV; ++i) {
+        size_t nw = (size_t)cout[i] * cin[i] * 27;
+        float* w = (float*)take(nw * 4);
+        float* b = (float*)take((size_t)cout[i] * 4);
+        float* g = (float*)take((size_t)cout[i] * 4);
+        float* be = (float*)take((size_t)cout[i] * 4);
+        uint16_t* wb = (uint16_t*)take(nw * 2);
+        if (base) {
+            ctx->conv[i].cin = cin[i];
+            ctx->conv[i].cout = cout[i];
+            ctx->conv[i].w_f32 = w;
+            ctx->conv[i].bias = b;
+            ctx->conv[i].gamma = g;
+            ctx->conv[i].beta = be;
+            ctx->conv[i].w_bf16 = wb;
+        }
+    }
+    for (int j = 0; j < DLV_N_DECONV; ++j) {
+        size_t nw = (size_t)dcin[j] * dcout[j] * 8;
+        float* w = (float*)take(nw * 4);
+        float* b = (float*)take((size_t)dcout[j] * 4);
+        uint16_t* wb = (uint16_t*)take(nw * 2);
+        if (base) {
+            ctx->deconv[j].cin = dcin[j];
+            ctx->deconv[j].cout = dcout[j];
+            ctx->deconv[j].w_f32 = w;
+            ctx->deconv[j].bias = b;
+            ctx->deconv[j].w_bf16 = wb;
+        }
+    }
+    float* fw = (float*)take((size_t)f[5] * 4);
+    float* fb = (float*)take(4);
+    if (base) {
+        ctx->final_w = fw;
+        ctx->final_b = fb;
+    }
+    return off;
+}
+
+static int check_features(dlv_ctx* ctx, const int f[6]) {
+    for (int i = 0; i < 6; ++i)
+        if (f[i] <= 0 || f[i] % 32 != 0 || f[i] > 256)
+            return dlv_fail(ctx, DLV_EUNSUP, "features[%d]=%d: channel counts must be multiples of 32, <= 256", i,
+                            f[i]);
+    if (f[2] % 2 || f[3] % 2 || f[4] % 2) return dlv_fail(ctx, DLV_EUNSUP, "features 2..4 must be even");
+    if ((f[2] / 2) % 32 || (f[3] / 2) % 32 || (f[4] / 2) % 32)
+        return dlv_fail(ctx, DLV_EUNSUP, "halved up-sampling channels must be multiples of 32");
+    return DLV_OK;
+}
+
+static int alloc_blob(dlv_ctx* ctx, const int f[6]) {
+    DLV_TRY(check_features(ctx, f));
+    size_t bytes = layout_blob(ctx, f, nullptr);
+    if (ctx->blob) {
+        DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DLV_HIP(ctx, hipFree(ctx->blob));
+        ctx->blob = nullptr;
+    }
+    DLV_HIP(ctx, hipMalloc(&ctx->blob, bytes));
+    DLV_HIP(ctx, hipMemsetAsync(ctx->blob, 0, bytes, ctx->stream));
+    ctx->blob_bytes = bytes;
+    memcpy(ctx->features, f, sizeof(int) * 6);
+    layout_blob(ctx, f, (char*)ctx->blob);
+    return DLV_OK;
+}
+
+extern "C" {
+
+int dlv_abi_version(void) { return DLV_ABI_VERSION; }
+
+int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
+    if (!out) return DLV_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return DLV_EHIP;
+    dlv_ctx* ctx = new (std::nothrow) dlv_ctx();
+    if (!ctx) return DLV_ENOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete ctx;
+        return DLV_EHIP;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return DLV_EHIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return DLV_OK;
+}
+
+int dlv_ctx_destroy(dlv_ctx* ctx) {
+    if (!ctx) return DLV_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->prof_pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : ctx->prof_free) (void)hipEventDestroy(e);
+    for (int i = 0; i < WS_N_SLOTS; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->blob) (void)hipFree(ctx->blob);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DLV_OK;
+}
+
+const char* dlv_last_error(dlv_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int dlv_sync(dlv_ctx* ctx) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+
+void* dlv_stream(dlv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int dlv_malloc(dlv_ctx* ctx, size_t bytes, void** out_dev) {
+    if (!ctx || !out_dev) return DLV_EINVAL;
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    DLV_HIP(ctx, hipMalloc(out_dev, bytes));
+    return DLV_OK;
+}
+int dlv_free(dlv_ctx* ctx, void* p_dev) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DLV_HIP(ctx, hipFree(p_dev));
+    return DLV_OK;
+}
+int dlv_memset_dev(dlv_ctx* ctx, void* p_dev, int value, size_t bytes) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_HIP(ctx, hipMemsetAsync(p_dev, value, bytes, ctx->stream));
+    return DLV_OK;
+}
+int dlv_copy_h2d(dlv_ctx* ctx, void* dst_dev, const void* src, size_t bytes) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_HIP(ctx, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+int dlv_copy_d2h(dlv_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_HIP(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+
+int dlv_unet_alloc_blob(dlv_ctx* ctx, const int features[6]) {
+    if (!ctx || !features) return DLV_EINVAL;
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    DLV_TRY(alloc_blob(ctx, features));
+    ctx->weights_loaded = true;  // content arrives by broadcast into dlv_unet_blob_dev()
+    return DLV_OK;
+}
+
+int dlv_unet_load(dlv_ctx* ctx, const dlv_unet_weights* w) {
+    if (!ctx || !w) return DLV_EINVAL;
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < DLV_N_CONV; ++i)
+        if (!w->conv_w[i] || !w->conv_b[i] || !w->norm_g[i] || !w->norm_b[i])
+            return dlv_fail(ctx, DLV_EINVAL, "conv layer %d has a null parameter pointer", i);
+    for (int j = 0; j < DLV_N_DECONV; ++j)
+        if (!w->deconv_w[j] || !w->deconv_b[j]) return dlv_fail(ctx, DLV_EINVAL, "deconv %d has a null pointer", j);
+    if (!w->final_w || !w->final_b) return dlv_fail(ctx, DLV_EINVAL, "final conv has a null pointer");
+    DLV_TRY(alloc_blob(ctx, w->features));
+    auto up = [&](void* dst, const void* src, size_t bytes) -> int {
+        DLV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return DLV_OK;
+    };
+    for (int i = 0; i < DLV_N_CONV; ++i) {
+        DlvConvLayer& L = ctx->conv[i];
+        DLV_TRY(up(L.w_f32, w->conv_w[i], (size_t)L.cout * L.cin * 27 * 4));
+        DLV_TRY(up(L.bias, w->conv_b[i], (size_t)L.cout * 4));
+        DLV_TRY(up(L.gamma, w->norm_g[i], (size_t)L.cout * 4));
+        DLV_TRY(up(L.beta, w->norm_b[i], (size_t)L.cout * 4));
+    }
+    for (int j = 0; j < DLV_N_DECONV; ++j) {
+        DlvDeconvLayer& L = ctx->deconv[j];
+        DLV_TRY(up(L.w_f32, w->deconv_w[j], (size_t)L.cin * L.cout * 8 * 4));
+        DLV_TRY(up(L.bias, w->deconv_b[j], (size_t)L.cout * 4));
+    }
+    DLV_TRY(up(ctx->final_w, w->final_w, (size_t)ctx->features[5] * 4));
+    DLV_TRY(up(ctx->final_b, w->final_b, 4));
+    DLV_TRY(dlv_pack_weights_bf16(ctx));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->weights_loaded = true;
+    return DLV_OK;
+}
+
+int dlv_unet_blob_size(dlv_ctx* ctx, size_t* bytes) {
+    if (!ctx || !bytes) return DLV_EINVAL;
+    if (!ctx->blob) return dlv_fail(ctx, DLV_ESTATE, "no weights loaded/allocated");
+    *bytes = ctx->blob_bytes;
+    return DLV_OK;
+}
+int dlv_unet_blob_dev(dlv_ctx* ctx, void** blob_dev) {
+    if (!ctx || !blob_dev) return DLV_EINVAL;
+    if (!ctx->blob) return dlv_fail(ctx, DLV_ESTATE, "no weights loaded/allocated");
+    *blob_dev = ctx->blob;
+    return DLV_OK;
+}
+
+int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, int B, int d, int h, int w,
+                         int precision) {
+    if (!ctx || !x_dev || !logits_dev) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_unet_forward_dev before dlv_unet_load");
+    if (B <= 0 || d <= 0 || h <= 0 || w <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty batch/patch");
+    if (d % 16 || h % 16 || w % 16)
+        return dlv_fail(ctx, DLV_EUNSUP, "patch %dx%dx%d: every dimension must be a multiple of 16", d, h, w);
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    if (precision == DLV_PREC_F32) return dlv_unet_forward_f32(ctx, x_dev, logits_dev, B, d, h, w);
+    if (precision == DLV_PREC_BF16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w);
+    return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
+}
+
+int dlv_prof_enable(dlv_ctx* ctx, int on) {
+    if (!ctx) return DLV_EINVAL;
+    if (!on) DLV_TRY(prof_drain(ctx));
+    ctx->prof_on = on != 0;
+    return DLV_OK;
+}
+int dlv_prof_reset(dlv_ctx* ctx) {
+    if (!ctx) return DLV_EINVAL;
+    DLV_TRY(prof_drain(ctx));
+    ctx->prof_slots.clear();
+    return DLV_OK;
+}
+int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out) {
+    if (!ctx || !n_out) return DLV_EINVAL;
+    DLV_TRY(prof_drain(ctx));
+    int n = (int)ctx->prof_slots.size();
+    *n_out = n;
+    for (int i = 0; i < n && i < capacity && entries; ++i) {
+        memcpy(entries[i].name, ctx->prof_slots[i].name, sizeof(entries[i].name));
+        entries[i].launches = ctx->prof_slots[i].launches;
+        entries[i].total_ms = ctx->prof_slots[i].total_ms;
+        entries[i].flops = ctx->prof_slots[i].flops;
+        entries[i].bytes = ctx->prof_slots[i].bytes;
+    }
+    return DLV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+// ccl.hip - 26-connected component labelling + per-label statistics on the device.
+//
+// Replaces cc3d.connected_components(bin_img, return_N=True) (count_blobs.py:61; cc3d 3.12.3 is a
+// third-party C++ two-pass union-find, not vendored) and cc3d.statistics(..., no_slice_conversion=
+// True) (count_blobs.py:85).  Output contract: label(component) = 1 + rank of its
+// minimum linear index z*Y*X + y*X + x among all components; 0 = background.
+//
+// Algorithm: union-find over the voxel index space with atomicMin links (the root of a tree is
+// the minimum linear index of its component), 13 backward neighbours per foreground voxel, path
+// compression, then a raster-order renumbering of the roots by a two-level prefix sum.  Integer
+// work only: results are bit-exact and independent of scheduling.
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u32 uf_find(const u32* __restrict__ L, u32 i) {
+    u32 p;
+    while ((p = __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != i) i = p;
+    return i;
+}
+
+__device__ __forceinline__ void uf_union(u32* L, u32 a, u32 b) {
+    bool done = false;
+    while (!done) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a < b) {
+            const u32 old = atomicMin(L + b, a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const u32 old = atomicMin(L + a, b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_init_kernel(u32* __restrict__ L, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) L[i] = (u32)i;
+}
+
+// one thread per 4 consecutive x voxels of a row (rows are padded virtually: x+3 may exceed X)
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, int Z,
+                                                        int Y, int X) {
+    const int xq = (X + 3) / 4;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)Z * Y * xq) return;
+    const int x0 = (int)(t % xq) * 4;
+    const int y = (int)((t / xq) % Y);
+    const int z = (int)(t / ((u64)xq * Y));
+    const u64 row = ((u64)z * Y + y) * X;
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (x0 + k < X && mask[row + x0 + k]) bits |= 1u << k;
+    if (!bits) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!(bits & (1u << k))) continue;
+        const int x = x0 + k;
+        const u64 i = row + x;
+        // 13 neighbours that precede voxel i in raster order
+        for (int dz = -1; dz <= 0; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0) continue;
+            const int dy_hi = dz < 0 ? 1 : 0;
+            for (int dy = -1; dy <= dy_hi; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= Y) continue;
+                const int dx_hi = (dz < 0 || dy < 0) ? 1 : -1;
+                for (int dx = -1; dx <= dx_hi; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= X) continue;
+                    const u64 j = ((u64)zz * Y + yy) * X + xx;
+                    if (mask[j]) uf_union(L, (u32)i, (u32)j);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_compress_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (mask[i]) {
+            u32 r = (u32)i, p;
+            while ((p = L[r]) != r) r = p;
+            L[i] = r;  // racing writers store the same root; readers that see an older parent still reach it
+        }
+}
+
+constexpr int RPT = 16;                 // voxels per thread in the renumbering kernels
+constexpr int RCHUNK = 256 * RPT;       // voxels per block
+
+__device__ __forceinline__ int block_excl_scan(int v, int* total) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += wsum[k];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(256) ccl_count_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
+                                                              u64 n, u32* __restrict__ counts) {
+    const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
+    int c = 0;
+    for (int k = 0; k < RPT; ++k) {
+        const u64 i = base + k;
+        if (i < n && mask[i] && L[i] == (u32)i) ++c;
+    }
+    int total;
+    block_excl_scan(c, &total);
+    if (threadIdx.x == 0) counts[blockIdx.x] = (u32)total;
+}
+
+// single-block exclusive scan of the per-chunk root counts; counts[nb] receives the total
+__global__ void __launch_bounds__(1024) ccl_scan_counts_kernel(u32* __restrict__ counts, u64 nb) {
+    __shared__ u64 part[1024];
+    const u64 per = (nb + 1023) / 1024;
+    const u64 b0 = min((u64)threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+    u64 s = 0;
+    for (u64 i = b0; i < b1; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const u64 v = part[k];
+            part[k] = run;
+            run += v;
+        }
+        counts[nb] = (u32)run;  // N <= 2^32-1 by construction (labels are uint32)
+    }
+    __syncthreads();
+    u64 run = part[threadIdx.x];
+    for (u64 i = b0; i < b1; ++i) {
+        const u32 v = counts[i];
+        counts[i] = (u32)run;
+        run += v;
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
+                                                               u64 n, const u32* __restrict__ offsets,
+                                                               u32* __restrict__ labels) {
+    const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
+    int c = 0;
+    for (int k = 0; k < RPT; ++k) {
+        const u64 i = base + k;
+        if (i < n && mask[i] && L[i] == (u32)i) ++c;
+    }
+    int total;
+    u32 rank = offsets[blockIdx.x] + (u32)block_excl_scan(c, &total);
+    for (int k = 0; k < RPT; ++k) {
+        const u64 i = base + k;
+        if (i < n && mask[i] && L[i] == (u32)i) labels[i] = ++rank;
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
+                                                          u64 n, u32* __restrict__ labels) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        if (!mask[i]) labels[i] = 0;
+        else if (L[i] != (u32)i) labels[i] = labels[L[i]];
+    }
+}
+
+// ---- statistics -------------------------------------------------------------------------------------
+// per label: count, sum z/y/x (u64), bbox min/max (u32).  Background (label 0) is reduced per wave.
+__global__ void __launch_bounds__(256) cc_stats_kernel(const u32* __restrict__ labels, int Z, int Y, int X,
+                                                       u32* __restrict__ counts, u64* __restrict__ sums,
+                                                       u32* __restrict__ bbmin, u32* __restrict__ bbmax) {
+    const u64 n = (u64)Z * Y * X;
+    u32 bmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, bmax[3] = {0, 0, 0};
+    bool any_bg = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 l = labels[i];
+        const u32 x = (u32)(i % X), y = (u32)((i / X) % Y), z = (u32)(i / ((u64)X * Y));
+        if (l) {
+            atomicAdd(counts + l, 1u);
+            atomicAdd(sums + 3 * (u64)l, (u64)z);
+            atomicAdd(sums + 3 * (u64)l + 1, (u64)y);
+            atomicAdd(sums + 3 * (u64)l + 2, (u64)x);
+            atomicMin(bbmin + 3 * (u64)l, z);
+            atomicMin(bbmin + 3 * (u64)l + 1, y);
+            atomicMin(bbmin + 3 * (u64)l + 2, x);
+            atomicMax(bbmax + 3 * (u64)l, z);
+            atomicMax(bbmax + 3 * (u64)l + 1, y);
+            atomicMax(bbmax + 3 * (u64)l + 2, x);
+        } else {
+            any_bg = true;
+            bmin[0] = min(bmin[0], z); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], x);
+            bmax[0] = max(bmax[0], z); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], x);
+        }
+    }
+    if (__any(any_bg)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32 lo = bmin[k], hi = bmax[k];
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, __shfl_down(lo, o, 64));
+                hi = max(hi, __shfl_down(hi, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMin(bbmin + k, lo);
+                atomicMax(bbmax + k, hi);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, uint32_t* labels_dev, uint64_t* n_out) {
+    if (!ctx || !mask_dev || !labels_dev || !n_out) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty volume");
+    const u64 n = (u64)Z * Y * X;
+    if (n > ((u64)1 << 32)) return dlv_fail(ctx, DLV_EUNSUP, "volumes above 2^32 voxels need 64-bit labels");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 nb = (n + RCHUNK - 1) / RCHUNK;
+    char* ws;
+    const size_t parent_bytes = (size_t)n * 4;
+    DLV_TRY(dlv_ws_get(ctx, WS_CCL, parent_bytes + (size_t)(nb + 1) * 4 + 256, (void**)&ws));
+    u32* L = (u32*)ws;
+    u32* counts = (u32*)(ws + ((parent_bytes + 255) & ~(size_t)255));
+    const int gs = (int)std::min<u64>((n + 255) / 256, (u64)256 * 64);
+    DlvProf pr(ctx, "ccl26", 0.0, (double)n * (1 + 4 + 4 + 4));
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, L, n);
+    DLV_LAUNCH_CHECK(ctx, "ccl_init_kernel");
+    const u64 nt = (u64)Z * Y * ((X + 3) / 4);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, mask_dev, L, Z, Y, X);
+    DLV_LAUNCH_CHECK(ctx, "ccl_merge_kernel");
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n);
+    DLV_LAUNCH_CHECK(ctx, "ccl_compress_kernel");
+    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts);
+    DLV_LAUNCH_CHECK(ctx, "ccl_count_roots_kernel");
+    hipLaunchKernelGGL(ccl_scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, nb);
+    DLV_LAUNCH_CHECK(ctx, "ccl_scan_counts_kernel");
+    hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts,
+                       labels_dev);
+    DLV_LAUNCH_CHECK(ctx, "ccl_assign_roots_kernel");
+    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, labels_dev);
+    DLV_LAUNCH_CHECK(ctx, "ccl_relabel_kernel");
+    pr.end();
+    u32 total = 0;
+    DLV_HIP(ctx, hipMemcpyAsync(&total, counts + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    return DLV_OK;
+}
+
+int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* voxel_counts,
+                     uint16_t* bounding_boxes, double* centroids) {
+    if (!ctx || !labels_dev || !voxel_counts || !bounding_boxes || !centroids) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty volume");
+    if (Z > 65536 || Y > 65536 || X > 65536) return dlv_fail(ctx, DLV_EUNSUP, "bounding boxes are uint16");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 nvox = (u64)Z * Y * X;
+    const size_t rows = (size_t)n + 1;
+    // [counts u32 rows | bbmin u32 3*rows | bbmax u32 3*rows | pad | sums u64 3*rows]
+    const size_t off_min = rows * 4, off_max = off_min + rows * 12;
+    const size_t off_sum = (off_max + rows * 12 + 7) & ~(size_t)7;
+    const size_t bytes = off_sum + rows * 24;
+    char* ws;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, bytes, (void**)&ws));
+    DLV_HIP(ctx, hipMemsetAsync(ws, 0, bytes, ctx->stream));
+    DLV_HIP(ctx, hipMemsetAsync(ws + off_min, 0xff, rows * 12, ctx->stream));
+    u32* counts = (u32*)ws;
+    u32* bbmin = (u32*)(ws + off_min);
+    u32* bbmax = (u32*)(ws + off_max);
+    u64* sums = (u64*)(ws + off_sum);
+    const int gs = (int)std::min<u64>((nvox + 255) / 256, (u64)256 * 32);
+    DlvProf pr(ctx, "cc_stats", 0.0, (double)nvox * 4);
+    hipLaunchKernelGGL(cc_stats_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_dev, Z, Y, X, counts, sums, bbmin, bbmax);
+    pr.end();
+    DLV_LAUNCH_CHECK(ctx, "cc_stats_kernel");
+    std::vector<char> host(bytes);
+    DLV_HIP(ctx, hipMemcpyAsync(host.data(), ws, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const u32* hc = (const u32*)host.data();
+    const u32* hmin = (const u32*)(host.data() + off_min);
+    const u32* hmax = (const u32*)(host.data() + off_max);
+    const u64* hs = (const u64*)(host.data() + off_sum);
+    u64 fg = 0, fs[3] = {0, 0, 0};
+    for (size_t l = 1; l < rows; ++l) {
+        voxel_counts[l] = hc[l];
+        fg += hc[l];
+        for (int k = 0; k < 3; ++k) {
+            fs[k] += hs[3 * l + k];
+            bounding_boxes[6 * l + 2 * k] = (uint16_t)hmin[3 * l + k];
+            bounding_boxes[6 * l + 2 * k + 1] = (uint16_t)hmax[3 * l + k];
+            centroids[3 * l + k] = hc[l] ? (double)hs[3 * l + k] / (double)hc[l] : NAN;
+        }
+    }
+    // background row: totals minus the foreground
+    const u64 dims[3] = {(u64)Z, (u64)Y, (u64)X};
+    const u64 bgc = nvox - fg;
+    voxel_counts[0] = (uint32_t)bgc;
+    for (int k = 0; k < 3; ++k) {
+        const u64 all = (nvox / dims[k]) * (dims[k] * (dims[k] - 1) / 2);
+        centroids[k] = bgc ? (double)(all - fs[k]) / (double)bgc : NAN;
+        bounding_boxes[2 * k] = bgc ? (uint16_t)hmin[k] : 0;
+        bounding_boxes[2 * k + 1] = bgc ? (uint16_t)hmax[k] : 0;
+    }
+    return DLV_OK;
+}
+
+}  // extern "C"

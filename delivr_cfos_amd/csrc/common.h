@@ -1,0 +1,124 @@
+// common.h - context, error plumbing, scratch arena and the in-library kernel timer shared by
+// every translation unit of libdelivr_hip.so.  gfx950 only; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/delivr_hip.h"
+
+#define DLV_WAVE 64
+
+struct DlvProfSlot {
+    char name[48];
+    int64_t launches = 0;
+    double total_ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+struct DlvProfPending {
+    int slot;
+    hipEvent_t a, b;
+};
+
+// one packed layer of the U-Net in HBM
+struct DlvConvLayer {
+    int cin = 0, cout = 0;
+    float* w_f32 = nullptr;     // (Cout,Cin,27) fp32, as in the checkpoint
+    float* bias = nullptr;      // (Cout)
+    float* gamma = nullptr;     // (Cout)
+    float* beta = nullptr;      // (Cout)
+    uint16_t* w_bf16 = nullptr; // MFMA A-operand fragment order (see unet_bf16.hip)
+};
+struct DlvDeconvLayer {
+    int cin = 0, cout = 0;
+    float* w_f32 = nullptr;     // (Cin,Cout,8)
+    float* bias = nullptr;      // (Cout)
+    uint16_t* w_bf16 = nullptr; // fragment order, per output parity
+};
+
+enum DlvWsSlot {
+    WS_F32_ACT = 0,   // fp32 path activations
+    WS_BF16_ACT,      // bf16 path activations
+    WS_STATS,         // per-(n,c) sums / scale-shift
+    WS_TILE_IN,       // gathered fp32 tiles
+    WS_TILE_OUT,      // logits of a batch
+    WS_TILE_META,     // window starts / maxima
+    WS_ERODE,         // distance maps
+    WS_CCL,           // CCL scratch
+    WS_MISC,
+    WS_N_SLOTS
+};
+
+struct dlv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // weights
+    bool weights_loaded = false;
+    int features[6] = {0, 0, 0, 0, 0, 0};
+    void* blob = nullptr;  // one allocation holding every packed parameter
+    size_t blob_bytes = 0;
+    DlvConvLayer conv[DLV_N_CONV];
+    DlvDeconvLayer deconv[DLV_N_DECONV];
+    float* final_w = nullptr;
+    float* final_b = nullptr;
+    // scratch
+    void* ws[WS_N_SLOTS] = {nullptr};
+    size_t ws_bytes[WS_N_SLOTS] = {0};
+    // timing
+    bool prof_on = false;
+    std::vector<DlvProfSlot> prof_slots;
+    std::vector<DlvProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+};
+
+int dlv_fail(dlv_ctx* ctx, int code, const char* fmt, ...);
+
+#define DLV_HIP(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return dlv_fail((ctx), _e == hipErrorOutOfMemory ? DLV_ENOMEM : DLV_EHIP, "%s failed: %s (%s:%d)", \
+                            #expr, hipGetErrorString(_e), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define DLV_LAUNCH_CHECK(ctx, what)                                                                 \
+    do {                                                                                            \
+        hipError_t _e = hipGetLastError();                                                          \
+        if (_e != hipSuccess)                                                                       \
+            return dlv_fail((ctx), DLV_EHIP, "launch of %s failed: %s", (what), hipGetErrorString(_e)); \
+    } while (0)
+
+#define DLV_TRY(expr)                \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != DLV_OK) return _rc; \
+    } while (0)
+
+// grow-only scratch slot
+int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out);
+
+// kernel timer: DlvProf p(ctx, "name", flops, bytes); <launch>; p.end();
+struct DlvProf {
+    dlv_ctx* ctx;
+    int idx = -1;
+    DlvProf(dlv_ctx* c, const char* name, double flops, double bytes);
+    void end();
+};
+
+static inline int dlv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- internal engine entry points (defined in the .hip files) ---------------------------------
+int dlv_unet_forward_f32(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
+// bf16 path fused with the tiler: reads the uint16 volume at the given window starts, adds the
+// logits into acc (see sw_infer.hip)
+int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
+                        int h, int w, int flip_dim, float scale, float* acc);
+int dlv_pack_weights_bf16(dlv_ctx* ctx);
+size_t dlv_bf16_pack_bytes(const int features[6]);

@@ -1,0 +1,179 @@
+// finalize.hip - divide by the count map, threshold, eroded re-mask.
+//
+// Restates inference/inference.py:285-299 (block-wise divide) and :31-95 (create_nifti_seg):
+//   mean = acc / cnt;  fg = sigmoid(float32(mean)) >= threshold
+//   keep = binary_erosion(raw > 0, iterations=30, border_value=1)   [default 6-neighbourhood]
+//   out  = uint8(fg) * keep, cropped to the unpadded (Z,Y,X) stack
+// The erosion equals "taxicab distance to the nearest zero voxel INSIDE the block > iterations"
+// (outside the block counts as foreground), so it is evaluated as a separable capped L1 distance
+// transform: X by log-step min-plus doubling in LDS, Y and Z by forward/backward scans.  The
+// reference erodes per Arrayterator z-block (inference.py:53); `zblock` carries that block size.
+#include "common.h"
+
+namespace {
+
+// distance along X.  One block per (z,y) row; the row lives in LDS as uint8.
+__global__ void __launch_bounds__(256) erode_x_kernel(const uint16_t* __restrict__ raw, int Yp, int Xp, int Y, int X,
+                                                      int cap, uint8_t* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* a = smem;
+    unsigned char* b = smem + X;
+    const int y = blockIdx.x % Y, z = blockIdx.x / Y;
+    const uint16_t* row = raw + ((long long)z * Yp + y) * Xp;
+    for (int x = threadIdx.x; x < X; x += blockDim.x) a[x] = row[x] > 0 ? (unsigned char)cap : 0;
+    __syncthreads();
+    for (int k = 1; k < cap; k <<= 1) {
+        for (int x = threadIdx.x; x < X; x += blockDim.x) {
+            int v = a[x];
+            if (x - k >= 0) v = min(v, (int)a[x - k] + k);
+            if (x + k < X) v = min(v, (int)a[x + k] + k);
+            b[x] = (unsigned char)v;
+        }
+        __syncthreads();
+        unsigned char* t = a;
+        a = b;
+        b = t;
+    }
+    uint8_t* o = dist + ((long long)z * Y + y) * X;
+    for (int x = threadIdx.x; x < X; x += blockDim.x) o[x] = a[x];
+}
+
+template <int V>
+struct U8V;
+template <>
+struct U8V<1> {
+    using T = unsigned char;
+    static __device__ __forceinline__ unsigned ld(const uint8_t* p) { return *p; }
+    static __device__ __forceinline__ void st(uint8_t* p, unsigned v) { *p = (unsigned char)v; }
+};
+template <>
+struct U8V<4> {
+    static __device__ __forceinline__ unsigned ld(const uint8_t* p) { return *reinterpret_cast<const unsigned*>(p); }
+    static __device__ __forceinline__ void st(uint8_t* p, unsigned v) { *reinterpret_cast<unsigned*>(p) = v; }
+};
+
+// per-byte min(a, b+1) for V packed bytes (values <= 254)
+template <int V>
+__device__ __forceinline__ unsigned minplus1(unsigned cur, unsigned prev) {
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const unsigned c = (cur >> (8 * k)) & 0xffu, p = ((prev >> (8 * k)) & 0xffu) + 1u;
+        r |= min(c, p) << (8 * k);
+    }
+    return r;
+}
+
+// distance along Y, in place: forward then backward scan.  One thread per (z, V consecutive x).
+template <int V>
+__global__ void __launch_bounds__(256) erode_y_kernel(uint8_t* __restrict__ dist, int Z, int Y, int X) {
+    const int xv = X / V;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)Z * xv) return;
+    const int x = (int)(t % xv) * V, z = (int)(t / xv);
+    uint8_t* col = dist + (long long)z * Y * X + x;
+    unsigned prev = U8V<V>::ld(col);
+    for (int y = 1; y < Y; ++y) {
+        const unsigned cur = minplus1<V>(U8V<V>::ld(col + (long long)y * X), prev);
+        U8V<V>::st(col + (long long)y * X, cur);
+        prev = cur;
+    }
+    for (int y = Y - 2; y >= 0; --y) {
+        const unsigned cur = minplus1<V>(U8V<V>::ld(col + (long long)y * X), prev);
+        U8V<V>::st(col + (long long)y * X, cur);
+        prev = cur;
+    }
+}
+
+// distance along Z inside z-blocks + the final decision.  One thread per (block, y, V x).
+template <int V>
+__global__ void __launch_bounds__(256) erode_z_final_kernel(uint8_t* __restrict__ dist, const float* __restrict__ acc,
+                                                            const uint8_t* __restrict__ cnt, int Yp, int Xp, int Z,
+                                                            int Y, int X, int zblock, int radius, float threshold,
+                                                            uint8_t* __restrict__ out, float* __restrict__ prob) {
+    const int xv = X / V;
+    const long long per_block = (long long)Y * xv;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = (Z + zblock - 1) / zblock;
+    if (t >= per_block * nblk) return;
+    const int blk = (int)(t / per_block);
+    const long long r = t % per_block;
+    const int x = (int)(r % xv) * V, y = (int)(r / xv);
+    const int zb0 = blk * zblock, zb1 = min(zb0 + zblock, Z);
+    const long long plane = (long long)Y * X;
+    uint8_t* col = dist + (long long)y * X + x;
+    unsigned prev = U8V<V>::ld(col + zb0 * plane);
+    for (int z = zb0 + 1; z < zb1; ++z) {
+        const unsigned cur = minplus1<V>(U8V<V>::ld(col + z * plane), prev);
+        U8V<V>::st(col + z * plane, cur);
+        prev = cur;
+    }
+    for (int z = zb1 - 1; z >= zb0; --z) {
+        unsigned cur = U8V<V>::ld(col + z * plane);
+        if (z < zb1 - 1) cur = minplus1<V>(cur, prev);
+        prev = cur;
+        unsigned res = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const long long po = ((long long)z * Yp + y) * Xp + x + k;
+            float m = acc[po];
+            if (cnt) m = m / (float)cnt[po];  // 0/0 -> NaN -> background, as in the reference
+            const float pr = 1.0f / (1.0f + expf(-m));
+            const bool keep = ((cur >> (8 * k)) & 0xffu) > (unsigned)radius;
+            if (prob) prob[(long long)z * plane + (long long)y * X + x + k] = pr;
+            res |= ((pr >= threshold && keep) ? 1u : 0u) << (8 * k);
+        }
+        U8V<V>::st(out + (long long)z * plane + (long long)y * X + x, res);
+    }
+}
+
+}  // namespace
+
+extern "C" int dlv_finalize_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev,
+                                int Yp, int Xp, int Z, int Y, int X, float threshold, int erode_iters, int zblock,
+                                uint8_t* out_dev, float* prob_dev) {
+    if (!ctx || !acc_dev || !raw_dev || !out_dev) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0 || Y > Yp || X > Xp) return dlv_fail(ctx, DLV_EINVAL, "bad shapes");
+    if (erode_iters < 0 || erode_iters > 253) return dlv_fail(ctx, DLV_EUNSUP, "erode_iters must be in [0,253]");
+    if (2 * (size_t)X > 160 * 1024) return dlv_fail(ctx, DLV_EUNSUP, "X=%d exceeds the LDS row buffer", X);
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    if (zblock <= 0 || zblock > Z) zblock = Z;
+    const int cap = erode_iters + 1;
+    uint8_t* dist;
+    const long long nvox = (long long)Z * Y * X;
+    DLV_TRY(dlv_ws_get(ctx, WS_ERODE, (size_t)nvox, (void**)&dist));
+    {
+        DlvProf p(ctx, "erode_x_u8", 0.0, 3.0 * nvox);
+        hipLaunchKernelGGL(erode_x_kernel, dim3((unsigned)((long long)Z * Y)), dim3(256), 2 * (size_t)X, ctx->stream,
+                           raw_dev, Yp, Xp, Y, X, cap, dist);
+        p.end();
+        DLV_LAUNCH_CHECK(ctx, "erode_x_kernel");
+    }
+    const bool v4 = (X % 4 == 0);
+    {
+        DlvProf p(ctx, "erode_y_u8", 0.0, 4.0 * nvox);
+        if (v4)
+            hipLaunchKernelGGL(erode_y_kernel<4>, dim3(dlv_cdiv((long long)Z * (X / 4), 256)), dim3(256), 0, ctx->stream,
+                               dist, Z, Y, X);
+        else
+            hipLaunchKernelGGL(erode_y_kernel<1>, dim3(dlv_cdiv((long long)Z * X, 256)), dim3(256), 0, ctx->stream, dist,
+                               Z, Y, X);
+        p.end();
+        DLV_LAUNCH_CHECK(ctx, "erode_y_kernel");
+    }
+    {
+        const int nblk = (Z + zblock - 1) / zblock;
+        DlvProf p(ctx, "erode_z_final", 0.0, (4.0 + 4.0 + 1.0) * nvox);
+        if (v4)
+            hipLaunchKernelGGL(erode_z_final_kernel<4>, dim3(dlv_cdiv((long long)nblk * Y * (X / 4), 256)), dim3(256), 0,
+                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, erode_iters, threshold,
+                               out_dev, prob_dev);
+        else
+            hipLaunchKernelGGL(erode_z_final_kernel<1>, dim3(dlv_cdiv((long long)nblk * Y * X, 256)), dim3(256), 0,
+                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, erode_iters, threshold,
+                               out_dev, prob_dev);
+        p.end();
+        DLV_LAUNCH_CHECK(ctx, "erode_z_final_kernel");
+    }
+    return DLV_OK;
+}

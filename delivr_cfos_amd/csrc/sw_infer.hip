@@ -1,0 +1,327 @@
+// sw_infer.hip - the sliding-window pass with the volume resident in HBM.
+//
+// Restates inference/sliding_window_inferer.py:102-251 (sliding_window_inference):
+//   tiler      :140-145 (+ _get_scan_interval :255-276, MONAI dense_patch_slices)
+//   gather/cast:181-195    uint16 -> int32 -> fp32, (B,1,d,h,w)
+//   skip       :198-202    max(window) <= threshold -> logits := -1000 (decided per window here,
+//                          i.e. the reference at sw_batch_size = 1)
+//   flip TTA   :218-226
+//   blend      :232-251    acc += 1 * logit, cnt += 1   (fp32 here, fp16 in the reference)
+//
+// Windows are processed colour class by colour class: within a class no two windows overlap, so
+// the read-modify-write of the accumulator needs no atomics and every voxel receives its
+// contributions in a fixed order (bitwise reproducible, independent of batch size).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+struct Tiler {
+    int n[3], roi[3], iv[3];
+    std::vector<int> st[3];
+    int ncol[3];
+    std::vector<int> col[3];
+    int64_t count() const { return (int64_t)st[0].size() * st[1].size() * st[2].size(); }
+};
+
+int build_tiler(dlv_ctx* ctx, const dlv_sw_params* p, Tiler& t) {
+    t.n[0] = p->Zp;
+    t.n[1] = p->Yp;
+    t.n[2] = p->Xp;
+    if (!(p->overlap >= 0.f && p->overlap < 1.f)) return dlv_fail(ctx, DLV_EINVAL, "overlap must be >= 0 and < 1");
+    for (int k = 0; k < 3; ++k) {
+        if (t.n[k] <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty volume");
+        int r = p->roi[k] > 0 ? p->roi[k] : t.n[k];  // fall_back_tuple
+        if (r > t.n[k])
+            return dlv_fail(ctx, DLV_EUNSUP, "roi[%d]=%d exceeds the padded volume (%d): pad the volume first "
+                            "(downsample_and_mask.py:390-396 does)", k, r, t.n[k]);
+        t.roi[k] = r;
+        // _get_scan_interval: python int(r * (1 - overlap)) evaluated in double
+        int iv = r == t.n[k] ? r : (int)((double)r * (1.0 - (double)p->overlap));
+        if (iv <= 0) iv = 1;
+        t.iv[k] = iv;
+        // dense_patch_slices
+        const int num = (t.n[k] + iv - 1) / iv;
+        int scan = num - 1;
+        for (int dd = 0; dd < num; ++dd)
+            if ((long long)dd * iv + r >= t.n[k]) {
+                scan = dd;
+                break;
+            }
+        t.st[k].clear();
+        for (int i = 0; i <= scan; ++i) {
+            int s = i * iv;
+            s -= std::max(s + r - t.n[k], 0);
+            t.st[k].push_back(s);
+        }
+        // colours: windows i and i + c are disjoint when c*iv >= roi; a clamped last window gets its own
+        const int c = (r + iv - 1) / iv;
+        const int kk = (int)t.st[k].size();
+        t.col[k].assign(kk, 0);
+        int ncol = std::min(c, kk);
+        for (int i = 0; i < kk; ++i) t.col[k][i] = i % c;
+        if (kk > 1 && t.st[k][kk - 1] != (kk - 1) * iv && kk > c) {
+            t.col[k][kk - 1] = c;
+            ncol = c + 1;
+        }
+        t.ncol[k] = ncol;
+    }
+    return DLV_OK;
+}
+
+// ---- kernels --------------------------------------------------------------------------------------
+
+// per-window maximum of the uint16 volume.  grid (chunks, windows); one atomicMax per block.
+__global__ void __launch_bounds__(256) window_max_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
+                                                         const int* __restrict__ starts, int d, int h, int w,
+                                                         int* __restrict__ wmax) {
+    const int win = blockIdx.y;
+    const int z0 = starts[3 * win], y0 = starts[3 * win + 1], x0 = starts[3 * win + 2];
+    const uint16_t* base = vol + ((long long)z0 * Yp + y0) * Xp + x0;
+    unsigned m = 0;
+    const bool vec = (w % 8 == 0) && (Xp % 8 == 0) && (x0 % 8 == 0);
+    if (vec) {
+        const int w8 = w / 8;
+        const long long n8 = (long long)d * h * w8;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+            const int xx = (int)(i % w8), yy = (int)((i / w8) % h), zz = (int)(i / ((long long)w8 * h));
+            const uint4 v = *reinterpret_cast<const uint4*>(base + ((long long)zz * Yp + yy) * Xp + xx * 8);
+            const unsigned a = max(max(v.x & 0xffffu, v.x >> 16), max(v.y & 0xffffu, v.y >> 16));
+            const unsigned b = max(max(v.z & 0xffffu, v.z >> 16), max(v.w & 0xffffu, v.w >> 16));
+            m = max(m, max(a, b));
+        }
+    } else {
+        const long long n = (long long)d * h * w;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
+            m = max(m, (unsigned)base[((long long)zz * Yp + yy) * Xp + xx]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(wmax + win, (int)m);
+}
+
+// (B,1,d,h,w) fp32 <- uint16 volume windows, flipped along flip_dim (2 = Z, 3 = Y, 4 = X) if >= 0
+__global__ void __launch_bounds__(256) gather_f32_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
+                                                         const int* __restrict__ starts, int d, int h, int w,
+                                                         int flip_dim, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
+    const long long n = (long long)d * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
+        if (flip_dim == 2) zz = d - 1 - zz;
+        if (flip_dim == 3) yy = h - 1 - yy;
+        if (flip_dim == 4) xx = w - 1 - xx;
+        out[(long long)b * n + i] = (float)vol[((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx)];
+    }
+}
+
+// acc[window] += logits (un-flipped); cnt[window] += 1.  Windows of one launch never overlap.
+__global__ void __launch_bounds__(256) blend_add_kernel(const float* __restrict__ logits, const int* __restrict__ starts,
+                                                        int d, int h, int w, int flip_dim, int Yp, int Xp,
+                                                        float scale, int rep, float* __restrict__ acc,
+                                                        uint8_t* __restrict__ cnt) {
+    const int b = blockIdx.y;
+    const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
+    const long long n = (long long)d * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
+        int fz = zz, fy = yy, fx = xx;
+        if (flip_dim == 2) fz = d - 1 - zz;
+        if (flip_dim == 3) fy = h - 1 - yy;
+        if (flip_dim == 4) fx = w - 1 - xx;
+        const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
+        acc[o] += scale * logits[(long long)b * n + ((long long)fz * h + fy) * w + fx];
+        if (cnt) cnt[o] += (uint8_t)rep;
+    }
+}
+
+// background-skipped windows: acc += value (-1000), cnt += 1
+__global__ void __launch_bounds__(256) fill_add_kernel(const int* __restrict__ starts, int d, int h, int w, int Yp,
+                                                       int Xp, float value, int rep, float* __restrict__ acc,
+                                                       uint8_t* __restrict__ cnt) {
+    const int b = blockIdx.y;
+    const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
+    const long long n = (long long)d * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
+        const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
+        if (value != 0.f) acc[o] += value;
+        if (cnt) cnt[o] += (uint8_t)rep;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlv_sw_num_windows(const dlv_sw_params* p, int64_t* n_windows) {
+    if (!p || !n_windows) return DLV_EINVAL;
+    Tiler t;
+    DLV_TRY(build_tiler(nullptr, p, t));
+    *n_windows = t.count();
+    return DLV_OK;
+}
+
+int dlv_sw_window_starts(const dlv_sw_params* p, int64_t* starts, int64_t capacity) {
+    if (!p || !starts) return DLV_EINVAL;
+    Tiler t;
+    DLV_TRY(build_tiler(nullptr, p, t));
+    if (capacity < t.count()) return DLV_EINVAL;
+    int64_t i = 0;
+    for (int z : t.st[0])
+        for (int y : t.st[1])
+            for (int x : t.st[2]) {
+                starts[3 * i] = z;
+                starts[3 * i + 1] = y;
+                starts[3 * i + 2] = x;
+                ++i;
+            }
+    return DLV_OK;
+}
+
+int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev, uint8_t* cnt_dev,
+                     dlv_sw_stats* stats) {
+    if (!ctx || !p || !vol_dev || !acc_dev) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_sw_infer_dev before dlv_unet_load");
+    if (p->precision != DLV_PREC_F32 && p->precision != DLV_PREC_BF16)
+        return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", p->precision);
+    if (!(p->flip_dim == -1 || (p->flip_dim >= 2 && p->flip_dim <= 4)))
+        return dlv_fail(ctx, DLV_EINVAL, "flip_dim must be -1, 2, 3 or 4");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    Tiler t;
+    DLV_TRY(build_tiler(ctx, p, t));
+    const int d = t.roi[0], h = t.roi[1], w = t.roi[2];
+    if (d % 16 || h % 16 || w % 16)
+        return dlv_fail(ctx, DLV_EUNSUP, "window %dx%dx%d: every dimension must be a multiple of 16", d, h, w);
+    const int64_t total = t.count();
+    const int64_t wb = std::max<int64_t>(p->win_begin, 0);
+    const int64_t we = p->win_end > 0 ? std::min<int64_t>(p->win_end, total) : total;
+    const int z0 = p->nz > 0 ? p->z0 : 0;
+    const int nz = p->nz > 0 ? p->nz : p->Zp;
+    const int Yp = p->Yp, Xp = p->Xp;
+    const int rep = p->repeat > 0 ? p->repeat : 1;
+    if (stats) {
+        stats->n_windows = std::max<int64_t>(we - wb, 0);
+        stats->n_skipped = 0;
+        stats->n_forward_launches = 0;
+    }
+    if (we <= wb) return DLV_OK;
+    const int64_t nwin = we - wb;
+    if (nwin > (int64_t)1 << 30) return dlv_fail(ctx, DLV_EUNSUP, "too many windows in one shard");
+
+    // windows of the shard, grouped by colour class (stable within a class = reference order)
+    const int ny = (int)t.st[1].size(), nx = (int)t.st[2].size();
+    const int ncolors = t.ncol[0] * t.ncol[1] * t.ncol[2];
+    std::vector<std::vector<int>> by_color(ncolors);
+    std::vector<int> starts((size_t)nwin * 3);
+    for (int64_t g = wb; g < we; ++g) {
+        const int iz = (int)(g / ((int64_t)ny * nx)), iy = (int)((g / nx) % ny), ix = (int)(g % nx);
+        const int i = (int)(g - wb);
+        const int sz = t.st[0][iz], sy = t.st[1][iy], sx = t.st[2][ix];
+        if (sz < z0 || sz + d > z0 + nz)
+            return dlv_fail(ctx, DLV_EINVAL, "window %lld (z %d..%d) lies outside the slab [%d,%d)", (long long)g, sz,
+                            sz + d, z0, z0 + nz);
+        starts[3 * i] = sz - z0;
+        starts[3 * i + 1] = sy;
+        starts[3 * i + 2] = sx;
+        const int c = (t.col[0][iz] * t.ncol[1] + t.col[1][iy]) * t.ncol[2] + t.col[2][ix];
+        by_color[c].push_back(i);
+    }
+
+    // device metadata: [starts of all windows | window maxima | per-launch start lists]
+    int* meta;
+    const size_t meta_ints = (size_t)nwin * 3 + (size_t)nwin + (size_t)nwin * 3;
+    DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, meta_ints * sizeof(int), (void**)&meta));
+    int* starts_dev = meta;
+    int* wmax_dev = meta + nwin * 3;
+    int* list_dev = wmax_dev + nwin;
+    DLV_HIP(ctx, hipMemcpyAsync(starts_dev, starts.data(), (size_t)nwin * 3 * sizeof(int), hipMemcpyHostToDevice,
+                                ctx->stream));
+    DLV_HIP(ctx, hipMemsetAsync(wmax_dev, 0, (size_t)nwin * sizeof(int), ctx->stream));
+    const long long tile_vox = (long long)d * h * w;
+    {
+        const int chunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 8 * 4), 1), 64);
+        DlvProf pr(ctx, "window_max_u16", 0.0, 2.0 * tile_vox * nwin);
+        hipLaunchKernelGGL(window_max_kernel, dim3(chunks, (unsigned)nwin), dim3(256), 0, ctx->stream, vol_dev, Yp, Xp,
+                           starts_dev, d, h, w, wmax_dev);
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "window_max_kernel");
+    }
+    std::vector<int> wmax((size_t)nwin);
+    DLV_HIP(ctx, hipMemcpyAsync(wmax.data(), wmax_dev, (size_t)nwin * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // ordered launch lists: per colour [active..., skipped...]
+    std::vector<int> list;
+    list.reserve((size_t)nwin * 3);
+    struct Seg { size_t off; int n_active, n_skipped; };
+    std::vector<Seg> segs;
+    int64_t n_skipped = 0;
+    for (int c = 0; c < ncolors; ++c) {
+        Seg s{list.size() / 3, 0, 0};
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i : by_color[c]) {
+                const bool skip = wmax[i] <= p->skip_threshold;
+                if ((pass == 0) == skip) continue;
+                list.push_back(starts[3 * i]);
+                list.push_back(starts[3 * i + 1]);
+                list.push_back(starts[3 * i + 2]);
+                if (skip) ++s.n_skipped; else ++s.n_active;
+            }
+        n_skipped += s.n_skipped;
+        segs.push_back(s);
+    }
+    DLV_HIP(ctx, hipMemcpyAsync(list_dev, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+
+    int sw_batch = p->sw_batch;
+    if (sw_batch <= 0) {
+        // default: ~2^24 patch voxels per forward (8 windows of 128^3, 64 of 64^3, ...), capped
+        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 24) / tile_vox, 1), 64);
+    }
+    int64_t launches = 0;
+    const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);
+    for (const Seg& s : segs) {
+        for (int b0 = 0; b0 < s.n_active; b0 += sw_batch) {
+            const int B = std::min(sw_batch, s.n_active - b0);
+            const int* st_dev = list_dev + (s.off + b0) * 3;
+            if (p->precision == DLV_PREC_BF16) {
+                DLV_TRY(dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev));
+                if (cnt_dev) {
+                    hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
+                                       Xp, 0.0f, rep, acc_dev, cnt_dev);
+                    DLV_LAUNCH_CHECK(ctx, "fill_add_kernel(count)");
+                }
+            } else {
+                float *tin, *tout;
+                DLV_TRY(dlv_ws_get(ctx, WS_TILE_IN, (size_t)sw_batch * tile_vox * 4, (void**)&tin));
+                DLV_TRY(dlv_ws_get(ctx, WS_TILE_OUT, (size_t)sw_batch * tile_vox * 4, (void**)&tout));
+                hipLaunchKernelGGL(gather_f32_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, vol_dev, Yp, Xp,
+                                   st_dev, d, h, w, p->flip_dim, tin);
+                DLV_LAUNCH_CHECK(ctx, "gather_f32_kernel");
+                DLV_TRY(dlv_unet_forward_f32(ctx, tin, tout, B, d, h, w));
+                hipLaunchKernelGGL(blend_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, tout, st_dev, d, h, w,
+                                   p->flip_dim, Yp, Xp, (float)rep, rep, acc_dev, cnt_dev);
+                DLV_LAUNCH_CHECK(ctx, "blend_add_kernel");
+            }
+            ++launches;
+        }
+        if (s.n_skipped > 0) {
+            const int* st_dev = list_dev + (s.off + s.n_active) * 3;
+            DlvProf pr(ctx, "skip_fill_f32", 0.0, 8.0 * tile_vox * s.n_skipped);
+            hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, s.n_skipped), dim3(256), 0, ctx->stream, st_dev, d, h, w,
+                               Yp, Xp, -1000.0f * rep, rep, acc_dev, cnt_dev);
+            pr.end();
+            DLV_LAUNCH_CHECK(ctx, "fill_add_kernel");
+        }
+    }
+    if (stats) {
+        stats->n_skipped = n_skipped;
+        stats->n_forward_launches = launches;
+    }
+    return DLV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+"""HipEngine - one libdelivr_hip context bound to one MI355X, driven with torch tensors.
+
+torch is only the device-memory container here (and, across ranks, the RCCL front end): every
+computation below is a call through the C ABI (include/delivr_hip.h).  There is no CPU
+fallback; constructing an engine without a visible GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PREC_BF16, PREC_F32, DelivrHipError
+
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+
+# checkpoint keys of the 18 conv blocks in forward order (include/delivr_hip.h)
+CONV_BLOCKS = (
+    ["conv_0.conv_0", "conv_0.conv_1"]
+    + [f"down_{k}.convs.conv_{j}" for k in (1, 2, 3, 4) for j in (0, 1)]
+    + [f"upcat_{k}.convs.conv_{j}" for k in (4, 3, 2, 1) for j in (0, 1)]
+)
+DECONV_BLOCKS = [f"upcat_{k}.upsample.deconv" for k in (4, 3, 2, 1)]
+
+
+def strip_state_dict(checkpoint) -> Dict[str, "np.ndarray"]:
+    """Accepts what torch.load(model_weights) returns in the reference: a dict holding
+    "state_dict" (inference/inference.py:222) or "model_state" (inference_nifti_load.py:215), keys
+    prefixed "module." by DataParallel; or a bare state_dict."""
+    sd = checkpoint
+    if isinstance(sd, dict):
+        for key in ("state_dict", "model_state"):
+            if key in sd and isinstance(sd[key], dict):
+                sd = sd[key]
+                break
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("module."):
+            k = k[len("module."):]
+        out[k] = v
+    return out
+
+
+class HipEngine:
+    def __init__(self, device: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("delivr_cfos_amd needs an MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for the HIP path")
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.tstream = torch.cuda.Stream(device=self.device)
+        ctx = C.c_void_p()
+        rc = self.lib.dlv_ctx_create(self.device_index, C.c_void_p(self.tstream.cuda_stream), C.byref(ctx))
+        if rc != 0:
+            raise DelivrHipError(rc, "dlv_ctx_create failed")
+        self.ctx = ctx
+        self.features: Optional[Tuple[int, ...]] = None
+        self._keep = []
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.dlv_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DelivrHipError(rc, self.lib.dlv_last_error(self.ctx).decode(errors="replace"))
+
+    def _enter(self):
+        """kernels run on the engine stream: order them after whatever torch queued so far"""
+        self.tstream.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self.tstream)
+
+    def sync(self):
+        self._check(self.lib.dlv_sync(self.ctx))
+
+    def _dev(self, t, dtype, name):
+        torch = self.torch
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise TypeError(f"{name}: expected a torch tensor on {self.device}, got {type(t)} on "
+                            f"{getattr(t, 'device', None)}")
+        if t.dtype != dtype:
+            raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        return C.c_void_p(t.data_ptr())
+
+    def to_device(self, arr, dtype=None):
+        """numpy / torch-cpu -> tensor in HBM (uint16 volumes go through torch.uint16)."""
+        torch = self.torch
+        if isinstance(arr, torch.Tensor):
+            t = arr
+        else:
+            a = np.ascontiguousarray(arr)
+            t = torch.from_numpy(a)
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.to(self.device).contiguous()
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def load_state_dict(self, checkpoint) -> None:
+        """dlv_unet_load from a MONAI BasicUNet checkpoint (inference/inference.py:190-200,222)."""
+        torch = self.torch
+        sd = strip_state_dict(checkpoint)
+        w = _lib.UnetWeights()
+        keep = []
+
+        def ptr(key):
+            if key not in sd:
+                raise KeyError(f"checkpoint has no '{key}' (expected MONAI BasicUNet names)")
+            v = sd[key]
+            a = v.detach().cpu().float().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v, np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p).value, a.shape
+
+        feats = []
+        for i, blk in enumerate(CONV_BLOCKS):
+            w.conv_w[i], shp = ptr(f"{blk}.conv.weight")
+            w.conv_b[i], _ = ptr(f"{blk}.conv.bias")
+            w.norm_g[i], _ = ptr(f"{blk}.adn.N.weight")
+            w.norm_b[i], _ = ptr(f"{blk}.adn.N.bias")
+            if tuple(shp[2:]) != (3, 3, 3):
+                raise ValueError(f"{blk}.conv.weight has shape {shp}")
+            feats.append(shp)
+        for j, blk in enumerate(DECONV_BLOCKS):
+            w.deconv_w[j], shp = ptr(f"{blk}.weight")
+            w.deconv_b[j], _ = ptr(f"{blk}.bias")
+            if tuple(shp[2:]) != (2, 2, 2):
+                raise ValueError(f"{blk}.weight has shape {shp}")
+        w.final_w, fshape = ptr("final_conv.weight")
+        w.final_b, _ = ptr("final_conv.bias")
+        features = (feats[0][0], feats[2][0], feats[4][0], feats[6][0], feats[8][0], feats[16][0])
+        if feats[0][1] != 1 or fshape[0] != 1 or fshape[1] != features[5]:
+            raise ValueError("only in_channels=1 / out_channels=1 networks are supported (inference.py:190-197)")
+        for k in range(6):
+            w.features[k] = int(features[k])
+        self._enter()
+        self._check(self.lib.dlv_unet_load(self.ctx, C.byref(w)))
+        self._leave()
+        self.features = tuple(int(f) for f in features)
+
+    def weight_blob(self):
+        """The packed parameters in HBM as a uint8 torch tensor view (for an RCCL broadcast)."""
+        n = C.c_size_t()
+        p = C.c_void_p()
+        self._check(self.lib.dlv_unet_blob_size(self.ctx, C.byref(n)))
+        self._check(self.lib.dlv_unet_blob_dev(self.ctx, C.byref(p)))
+        return _tensor_view(self.torch, p.value, n.value, self.device)
+
+    def alloc_weight_blob(self, features: Sequence[int]):
+        arr = (C.c_int * 6)(*[int(f) for f in features])
+        self._check(self.lib.dlv_unet_alloc_blob(self.ctx, arr))
+        self.features = tuple(int(f) for f in features)
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def unet_forward(self, x, precision: str = "fp32"):
+        """(B,1,d,h,w) fp32 tensor in HBM -> logits (B,1,d,h,w) fp32."""
+        torch = self.torch
+        if x.dim() != 5 or x.shape[1] != 1:
+            raise ValueError("x must be (B,1,d,h,w)")
+        out = torch.empty_like(x)
+        B, _, d, h, w = x.shape
+        self._enter()
+        self._check(self.lib.dlv_unet_forward_dev(self.ctx, self._dev(x, torch.float32, "x"),
+                                                  self._dev(out, torch.float32, "out"), B, d, h, w,
+                                                  PRECISIONS[precision]))
+        self._leave()
+        return out
+
+    # ---- sliding window ----------------------------------------------------------------------------
+    def make_sw_params(self, padded_shape, roi, overlap=0.5, flip_dim=None, skip_threshold=0, precision="bf16",
+                       sw_batch=0, win_range=None, slab=None, repeat=1) -> _lib.SwParams:
+        p = _lib.SwParams()
+        p.Zp, p.Yp, p.Xp = (int(v) for v in padded_shape)
+        for k in range(3):
+            p.roi[k] = int(roi[k])
+        p.overlap = float(overlap)
+        p.flip_dim = -1 if flip_dim is None else int(flip_dim)
+        p.skip_threshold = int(skip_threshold)
+        p.precision = PRECISIONS[precision]
+        p.sw_batch = int(sw_batch)
+        p.win_begin, p.win_end = (0, 0) if win_range is None else (int(win_range[0]), int(win_range[1]))
+        p.z0, p.nz = (0, 0) if slab is None else (int(slab[0]), int(slab[1]))
+        p.repeat = int(repeat)
+        return p
+
+    def num_windows(self, params) -> int:
+        n = C.c_int64()
+        rc = self.lib.dlv_sw_num_windows(C.byref(params), C.byref(n))
+        if rc != 0:
+            raise DelivrHipError(rc, "dlv_sw_num_windows: bad geometry")
+        return n.value
+
+    def window_starts(self, params) -> np.ndarray:
+        n = self.num_windows(params)
+        buf = np.zeros((n, 3), dtype=np.int64)
+        rc = self.lib.dlv_sw_window_starts(C.byref(params), buf.ctypes.data_as(C.POINTER(C.c_int64)), n)
+        if rc != 0:
+            raise DelivrHipError(rc, "dlv_sw_window_starts failed")
+        return buf
+
+    def sw_infer(self, params, vol, acc, cnt=None) -> dict:
+        """One sliding-window pass; vol uint16 (nz,Yp,Xp), acc fp32 and cnt uint8 (optional) are
+        mutated in place (inference/sliding_window_inferer.py:232-251)."""
+        torch = self.torch
+        st = _lib.SwStats()
+        self._enter()
+        self._check(self.lib.dlv_sw_infer_dev(
+            self.ctx, C.byref(params), self._dev(vol, torch.uint16, "vol"), self._dev(acc, torch.float32, "acc"),
+            self._dev(cnt, torch.uint8, "cnt") if cnt is not None else None, C.byref(st)))
+        self._leave()
+        return {"n_windows": st.n_windows, "n_skipped": st.n_skipped, "n_forward_launches": st.n_forward_launches}
+
+    # ---- finalize ----------------------------------------------------------------------------------
+    def finalize(self, acc, cnt, raw, stack_shape, threshold=0.5, erode_iters=30, zblock=0, want_prob=False):
+        """-> uint8 (Z,Y,X) binaries [, fp32 sigmoid] (inference/inference.py:285-299, :31-95)."""
+        torch = self.torch
+        Z, Y, X = (int(v) for v in stack_shape)
+        Yp, Xp = int(acc.shape[-2]), int(acc.shape[-1])
+        out = torch.empty((Z, Y, X), dtype=torch.uint8, device=self.device)
+        prob = torch.empty((Z, Y, X), dtype=torch.float32, device=self.device) if want_prob else None
+        self._enter()
+        self._check(self.lib.dlv_finalize_dev(
+            self.ctx, self._dev(acc, torch.float32, "acc"),
+            self._dev(cnt, torch.uint8, "cnt") if cnt is not None else None, self._dev(raw, torch.uint16, "raw"),
+            Yp, Xp, Z, Y, X, float(threshold), int(erode_iters), int(zblock),
+            self._dev(out, torch.uint8, "out"), self._dev(prob, torch.float32, "prob") if want_prob else None))
+        self._leave()
+        return (out, prob) if want_prob else out
+
+    # ---- connected components ----------------------------------------------------------------------
+    def ccl26(self, mask):
+        """uint8 (Z,Y,X) in HBM -> (labels uint32 tensor in HBM (stored in an int32 tensor), N)."""
+        torch = self.torch
+        Z, Y, X = (int(v) for v in mask.shape)
+        labels = torch.empty((Z, Y, X), dtype=torch.int32, device=self.device)  # uint32 payload
+        n = C.c_uint64()
+        self._enter()
+        self._check(self.lib.dlv_ccl26_dev(self.ctx, self._dev(mask, torch.uint8, "mask"), Z, Y, X,
+                                           C.c_void_p(labels.data_ptr()), C.byref(n)))
+        self._leave()
+        return labels, int(n.value)
+
+    def cc_stats(self, labels, n: int) -> dict:
+        """cc3d.statistics(no_slice_conversion=True) layout (count_blobs.py:85)."""
+        Z, Y, X = (int(v) for v in labels.shape)
+        counts = np.zeros(n + 1, dtype=np.uint32)
+        bbox = np.zeros((n + 1, 6), dtype=np.uint16)
+        cent = np.zeros((n + 1, 3), dtype=np.float64)
+        self._enter()
+        self._check(self.lib.dlv_cc_stats_dev(self.ctx, C.c_void_p(labels.data_ptr()), Z, Y, X, n,
+                                              counts.ctypes.data_as(C.c_void_p), bbox.ctypes.data_as(C.c_void_p),
+                                              cent.ctypes.data_as(C.c_void_p)))
+        self._leave()
+        return {"voxel_counts": counts, "bounding_boxes": bbox, "centroids": cent}
+
+    # ---- resamplers --------------------------------------------------------------------------------
+    def block_mean_u16(self, vol, factors):
+        torch = self.torch
+        Z, Y, X = (int(v) for v in vol.shape)
+        fz, fy, fx = (int(f) for f in factors)
+        out = torch.empty((-(-Z // fz), -(-Y // fy), -(-X // fx)), dtype=torch.uint16, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_block_mean_u16_dev(self.ctx, self._dev(vol, torch.uint16, "vol"), Z, Y, X, fz, fy, fx,
+                                                    self._dev(out, torch.uint16, "out")))
+        self._leave()
+        return out
+
+    def zoom_spline2_u8(self, mask, out_shape):
+        torch = self.torch
+        iz, iy, ix = (int(v) for v in mask.shape)
+        oz, oy, ox = (int(v) for v in out_shape)
+        out = torch.empty((oz, oy, ox), dtype=torch.uint8, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_zoom_spline2_u8_dev(self.ctx, self._dev(mask, torch.uint8, "mask"), iz, iy, ix,
+                                                     self._dev(out, torch.uint8, "out"), oz, oy, ox))
+        self._leave()
+        return out
+
+    def mask_pad_u16(self, raw, mask, padded_shape, threshold=0):
+        torch = self.torch
+        Z, Y, X = (int(v) for v in raw.shape)
+        Zp, Yp, Xp = (int(v) for v in padded_shape)
+        out = torch.empty((Zp, Yp, Xp), dtype=torch.uint16, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_mask_pad_u16_dev(
+            self.ctx, self._dev(raw, torch.uint16, "raw"),
+            self._dev(mask, torch.uint8, "mask") if mask is not None else None, int(threshold), Z, Y, X,
+            self._dev(out, torch.uint16, "out"), Zp, Yp, Xp))
+        self._leave()
+        return out
+
+    def trilinear_u16(self, vol, out_shape):
+        torch = self.torch
+        iz, iy, ix = (int(v) for v in vol.shape)
+        oz, oy, ox = (int(v) for v in out_shape)
+        out = torch.empty((oz, oy, ox), dtype=torch.uint16, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_trilinear_u16_dev(self.ctx, self._dev(vol, torch.uint16, "vol"), iz, iy, ix,
+                                                   self._dev(out, torch.uint16, "out"), oz, oy, ox))
+        self._leave()
+        return out
+
+    # ---- kernel timer ------------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        self._check(self.lib.dlv_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_reset(self):
+        self._check(self.lib.dlv_prof_reset(self.ctx))
+
+    def prof_report(self) -> Dict[str, dict]:
+        ent = (_lib.ProfEntry * _lib.PROF_MAX)()
+        n = C.c_int()
+        self._check(self.lib.dlv_prof_report(self.ctx, ent, _lib.PROF_MAX, C.byref(n)))
+        out = {}
+        for i in range(min(n.value, _lib.PROF_MAX)):
+            e = ent[i]
+            out[e.name.decode()] = {"launches": e.launches, "total_ms": e.total_ms, "flops": e.flops, "bytes": e.bytes}
+        return out
+
+
+def _tensor_view(torch, ptr: int, nbytes: int, device):
+    """uint8 torch view of library-owned HBM (no copy) via __cuda_array_interface__."""
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device)

@@ -1,0 +1,202 @@
+/* delivr_hip.h - C ABI of libdelivr_hip.so: the MI355X (gfx950) implementation of DELiVR's tiled
+ * 3D-U-Net cFos inference path.
+ *
+ * The reference (erturklab/delivr_cfos) has no FFI layer: its boundary for this path is Python
+ * calls + .npy files.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference root).  The Python host package (delivr_cfos_amd/) binds
+ * these with ctypes and mirrors the reference's step API on top; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = DLV_OK, negative = DLV_E*; dlv_last_error(ctx) returns a
+ *     message owned by the ctx (valid until the next call on that ctx).
+ *   - no C++ exception and no HIP error code crosses the ABI.
+ *   - pointers are caller-owned.  "_dev" parameters are device (HBM) pointers on the ctx's
+ *     device; all others are host pointers.  Sizes are explicit; nothing allocated by the
+ *     library is handed to the caller (scratch lives in the ctx and is freed by dlv_ctx_destroy).
+ *   - volumes are C-order (Z,Y,X), X contiguous ("z-major slabs"), exactly the payload of the
+ *     reference's .npy files (inference/inference.py:234, count_blobs.py:46).
+ *   - a ctx is bound to one device and one HIP stream and is NOT thread-safe; distinct ctxs are
+ *     independent.  Calls are asynchronous on the ctx stream unless documented "synchronous";
+ *     dlv_sync() waits for the stream.
+ */
+#ifndef DELIVR_HIP_H
+#define DELIVR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLV_OK 0
+#define DLV_EINVAL (-1)   /* bad argument */
+#define DLV_EHIP (-2)     /* a HIP runtime call failed (message has the HIP error string) */
+#define DLV_ENOMEM (-3)   /* device allocation failed */
+#define DLV_ESTATE (-4)   /* call order violated (e.g. forward before dlv_unet_load) */
+#define DLV_EUNSUP (-5)   /* shape not supported by the kernels */
+
+#define DLV_ABI_VERSION 1
+
+/* compute precision of the U-Net forward */
+#define DLV_PREC_F32 0  /* fp32 VALU kernels, NCDHW: parity mode (matches torch fp32 to ~1e-5) */
+#define DLV_PREC_BF16 1 /* bf16 MFMA implicit-GEMM kernels, fp32 accumulate + fp32 norm stats */
+
+#define DLV_N_CONV 18
+#define DLV_N_DECONV 4
+
+typedef struct dlv_ctx dlv_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int dlv_abi_version(void);
+/* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream; otherwise it adopts the
+ * caller's hipStream_t.  Replaces the device set-up at inference/inference.py:153-160. */
+int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out);
+int dlv_ctx_destroy(dlv_ctx* ctx);
+const char* dlv_last_error(dlv_ctx* ctx);
+int dlv_sync(dlv_ctx* ctx);
+void* dlv_stream(dlv_ctx* ctx); /* the hipStream_t kernels are launched on */
+
+/* plain device-memory helpers so that a host without torch can drive the library */
+int dlv_malloc(dlv_ctx* ctx, size_t bytes, void** out_dev);
+int dlv_free(dlv_ctx* ctx, void* p_dev);
+int dlv_memset_dev(dlv_ctx* ctx, void* p_dev, int value, size_t bytes);
+int dlv_copy_h2d(dlv_ctx* ctx, void* dst_dev, const void* src, size_t bytes); /* synchronous */
+int dlv_copy_d2h(dlv_ctx* ctx, void* dst, const void* src_dev, size_t bytes); /* synchronous */
+
+/* ---- U-Net weights ------------------------------------------------------------------------ */
+/* MONAI BasicUNet(3,1,1,features,act=mish,norm=instance-affine) parameters as fp32 host arrays
+ * taken from the checkpoint's state_dict (inference/inference.py:190-200,222).  Conv layers are
+ * listed in forward order:
+ *   0 conv_0.conv_0   1 conv_0.conv_1   2,3 down_1.convs.conv_{0,1}   4,5 down_2   6,7 down_3
+ *   8,9 down_4   10,11 upcat_4.convs   12,13 upcat_3.convs   14,15 upcat_2.convs   16,17 upcat_1.convs
+ * conv_w[i]: (Cout,Cin,3,3,3); norm_g/norm_b: InstanceNorm3d affine weight/bias (Cout).
+ * deconv_w[j] (j=0..3 = upcat_4..upcat_1): ConvTranspose3d weight (Cin,Cout,2,2,2).
+ * final_w: (1,features[5],1,1,1). */
+typedef struct dlv_unet_weights {
+    int features[6];
+    const float* conv_w[DLV_N_CONV];
+    const float* conv_b[DLV_N_CONV];
+    const float* norm_g[DLV_N_CONV];
+    const float* norm_b[DLV_N_CONV];
+    const float* deconv_w[DLV_N_DECONV];
+    const float* deconv_b[DLV_N_DECONV];
+    const float* final_w;
+    const float* final_b;
+} dlv_unet_weights;
+
+/* copies (and re-packs for the MFMA kernels) the weights into HBM.  Synchronous. */
+int dlv_unet_load(dlv_ctx* ctx, const dlv_unet_weights* w);
+/* multi-GPU: after dlv_unet_load on the root rank the packed weight blob can be broadcast
+ * (RCCL, by the host) instead of re-reading the checkpoint on every rank
+ * (replaces DataParallel's per-forward broadcast_coalesced, inference/inference.py:217-219). */
+int dlv_unet_blob_size(dlv_ctx* ctx, size_t* bytes);
+int dlv_unet_blob_dev(dlv_ctx* ctx, void** blob_dev); /* device pointer owned by ctx */
+int dlv_unet_alloc_blob(dlv_ctx* ctx, const int features[6]); /* non-root ranks: allocate only */
+
+/* ---- U-Net forward (one batch of patches) -------------------------------------------------- */
+/* logits = BasicUNet(x): x_dev (B,1,d,h,w) fp32 -> logits_dev (B,1,d,h,w) fp32; d,h,w multiples
+ * of 16.  Replaces predictor(window_data) at inference/sliding_window_inferer.py:222. */
+int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, int B, int d, int h, int w,
+                         int precision);
+
+/* ---- sliding-window pass ------------------------------------------------------------------- */
+typedef struct dlv_sw_params {
+    int Zp, Yp, Xp;      /* padded volume shape (inference/inference.py:229-231) */
+    int roi[3];          /* window size (Z,Y,X) = config window_dim_0/1/2 (inference.py:162-168) */
+    float overlap;       /* 0.5 in the reference (inference.py:127,211) */
+    int flip_dim;        /* -1 none, 2 = Z, 3 = Y, 4 = X (sliding_window_inferer.py:218-226) */
+    int skip_threshold;  /* window_data_threshold (sliding_window_inferer.py:52,198): a window whose
+                            max <= threshold is not inferred and contributes -1000; decided PER
+                            WINDOW (= the reference at sw_batch_size 1) */
+    int precision;       /* DLV_PREC_* */
+    int sw_batch;        /* windows per forward launch (0 = library default) */
+    int64_t win_begin;   /* shard: windows [win_begin, win_end) of the reference's enumeration */
+    int64_t win_end;     /* (Z slowest, X fastest); win_end <= 0 means "to the end" */
+    int z0, nz;          /* the buffers below hold planes [z0, z0+nz) of the padded volume; every
+                            window of the shard must lie inside (nz <= 0: whole volume) */
+    int repeat;          /* this call stands for `repeat` identical passes (>= 1): acc += repeat*logit,
+                            cnt += repeat.  The reference's 13-pass TTA schedule (inference.py:265-279)
+                            has only 3 distinct passes once its <=1e-3 noise is dropped (5:4:4) */
+} dlv_sw_params;
+
+typedef struct dlv_sw_stats {
+    int64_t n_windows;   /* windows in the shard */
+    int64_t n_skipped;   /* of which background-skipped */
+    int64_t n_forward_launches;
+} dlv_sw_stats;
+
+/* number of windows the reference enumerates for this geometry (sliding_window_inferer.py:140-145) */
+int dlv_sw_num_windows(const dlv_sw_params* p, int64_t* n_windows);
+/* writes the (z0,y0,x0) start of every window in the reference's order: starts[3*n] */
+int dlv_sw_window_starts(const dlv_sw_params* p, int64_t* starts, int64_t capacity);
+
+/* One pass of sliding_window_inference (inference/sliding_window_inferer.py:161-251) with the
+ * volume resident in HBM: gather + cast, per-window background skip, optional flip, U-Net forward,
+ * un-flip, acc += logit (fp32; the reference accumulates fp16), cnt += 1.
+ * vol_dev: uint16 (nz,Yp,Xp); acc_dev: fp32 (nz,Yp,Xp) in/out; cnt_dev: uint8 (nz,Yp,Xp) in/out or
+ * NULL.  Synchronous with respect to the host only for the small skip-list read-back. */
+int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev,
+                     uint8_t* cnt_dev, dlv_sw_stats* stats);
+
+/* ---- finalize: divide, threshold, eroded re-mask ------------------------------------------- */
+/* inference/inference.py:285-299 + create_nifti_seg (:31-95).  mean = acc/cnt (cnt may be NULL:
+ * the division never changes the decision), fg = sigmoid(mean) >= threshold, keep = raw>0 eroded
+ * by an L1 ball of radius erode_iters evaluated inside z-blocks of zblock planes (0 = whole
+ * volume; the reference's Arrayterator rule gives floor(floor(1e9/X)/Y)), out = fg & keep.
+ * acc/cnt/raw are (.,Yp,Xp)-strided padded buffers, out_dev is the unpadded (Z,Y,X) uint8
+ * binaries.npy payload; prob_dev (nullable) receives sigmoid(mean) as fp32 (Z,Y,X)
+ * (network_output.npy, inference.py:312-318). */
+int dlv_finalize_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev,
+                     int Yp, int Xp, int Z, int Y, int X, float threshold, int erode_iters, int zblock,
+                     uint8_t* out_dev, float* prob_dev);
+
+/* ---- connected components + statistics ------------------------------------------------------ */
+/* cc3d.connected_components(bin_img, return_N=True), connectivity 26 (count_blobs.py:61): labels
+ * 1..N in C-raster order of each component's first voxel, 0 = background.  labels_dev: uint32
+ * (Z,Y,X).  Synchronous (returns N). */
+int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, uint32_t* labels_dev,
+                  uint64_t* n_out);
+/* cc3d.statistics(labels, no_slice_conversion=True) (count_blobs.py:85): host outputs sized n+1:
+ * voxel_counts uint32; bounding_boxes uint16 (n+1,6) = z0,z1,y0,y1,x0,x1 inclusive; centroids
+ * float64 (n+1,3) = coordinate sums / count (row 0 = background).  Synchronous. */
+int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n,
+                     uint32_t* voxel_counts, uint16_t* bounding_boxes, double* centroids);
+
+/* ---- resamplers (the steps either side of the path) ----------------------------------------- */
+/* transform.downscale_local_mean(chunk,(fz,fy,fx)).astype(uint16) (downsample_and_mask.py:44):
+ * out (ceil(Z/fz),ceil(Y/fy),ceil(X/fx)) = floor(sum over zero-padded block / (fz*fy*fx)). */
+int dlv_block_mean_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int Y, int X, int fz, int fy, int fx,
+                           uint16_t* out_dev);
+/* scipy.ndimage.zoom(mask, out/in, output=uint8, order=2, prefilter=False)
+ * (downsample_and_mask.py:299). */
+int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy, int ix, uint8_t* out_dev,
+                            int oz, int oy, int ox);
+/* img *= mask_us[i]; masked_nii[0,0,i,:Y,:X] = img (downsample_and_mask.py:396-417): writes the
+ * zero-padded (Zp,Yp,Xp) uint16 volume from raw (Z,Y,X) uint16 and mask (Z,Y,X) uint8 (nullable:
+ * threshold mode, values < threshold -> 0). */
+int dlv_mask_pad_u16_dev(dlv_ctx* ctx, const uint16_t* raw_dev, const uint8_t* mask_dev, int threshold, int Z,
+                         int Y, int X, uint16_t* out_dev, int Zp, int Yp, int Xp);
+/* north-star extension (no reference counterpart): trilinear resample, align_corners=False,
+ * clamp-to-edge, uint16 -> uint16 (round half up). */
+int dlv_trilinear_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy, int ix, uint16_t* out_dev,
+                          int oz, int oy, int ox);
+
+/* ---- in-library kernel timing (bench.py's roofline leg) ------------------------------------- */
+#define DLV_PROF_MAX_KERNELS 32
+typedef struct dlv_prof_entry {
+    char name[48];
+    int64_t launches;
+    double total_ms;     /* sum of HIP-event durations on the ctx stream */
+    double flops;        /* algorithmic FLOPs summed over those launches */
+    double bytes;        /* algorithmic HBM bytes summed over those launches */
+} dlv_prof_entry;
+int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
+int dlv_prof_reset(dlv_ctx* ctx);
+int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELIVR_HIP_H */

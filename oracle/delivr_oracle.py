@@ -405,32 +405,41 @@ def block_mean_u16(vol: np.ndarray, factors: Sequence[int]) -> np.ndarray:
 
 def zoom_spline2_f64(mask: np.ndarray, out_shape: Sequence[int]) -> np.ndarray:
     """Own restatement of scipy.ndimage.zoom(mask, ratios, order=2, prefilter=False) before the
-    uint8 cast (downsample/downsample_and_mask.py:299): align-corners map, quadratic B-spline,
-    whole-sample mirror at the edges.  Returns float64."""
+    uint8 cast (downsample/downsample_and_mask.py:299).  Arithmetic found bit-identical to scipy
+    1.15.3 in float64 (probe recorded in DESIGN.md): coordinate x = i * ((n_in-1)/(n_out-1));
+    c = floor(x+0.5), t = x-c; w0 = 0.5*(0.5-t)^2, w1 = 0.75-t*t, w2 = 1-w0-w1; taps c-1,c,c+1 with
+    whole-sample mirror at the edges; value = sum over the 27 taps (z slowest, x fastest) of
+    ((v*wz)*wy)*wx.  Returns float64."""
     a = mask.astype(np.float64)
-    for ax, n_out in enumerate(out_shape):
-        n_in = a.shape[ax]
-        a = np.moveaxis(a, ax, 0)
-        res = np.zeros((n_out,) + a.shape[1:], dtype=np.float64)
+    idx, wts = [], []
+    for n_out, n_in in zip(out_shape, a.shape):
         scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
-        for i in range(n_out):
-            x = i * scale
-            c = int(math.floor(x + 0.5))
-            t = x - c
-            ws = (0.5 * (0.5 - t) ** 2, 0.75 - t * t, 0.5 * (0.5 + t) ** 2)
-            for k, wt in zip((c - 1, c, c + 1), ws):
-                if n_in == 1:
-                    k = 0
-                else:
-                    p = 2 * (n_in - 1)
-                    k = k % p
-                    if k < 0:
-                        k += p
-                    if k >= n_in:
-                        k = p - k
-                res[i] += wt * a[k]
-        a = np.moveaxis(res, 0, ax)
-    return a
+        x = np.arange(n_out, dtype=np.float64) * scale
+        c = np.floor(x + 0.5)
+        t = x - c
+        w1 = 0.75 - t * t
+        y = 0.5 - t
+        w0 = 0.5 * y * y
+        w2 = 1.0 - w0 - w1
+        ks = []
+        for dk in (-1, 0, 1):
+            k = c.astype(np.int64) + dk
+            if n_in == 1:
+                k = np.zeros_like(k)
+            else:
+                p = 2 * (n_in - 1)
+                k = np.mod(k, p)
+                k = np.where(k >= n_in, p - k, k)
+            ks.append(k)
+        idx.append(ks)
+        wts.append((w0, w1, w2))
+    res = np.zeros(tuple(out_shape), dtype=np.float64)
+    for pz in range(3):
+        for py in range(3):
+            for px in range(3):
+                v = a[idx[0][pz][:, None, None], idx[1][py][None, :, None], idx[2][px][None, None, :]]
+                res += ((v * wts[0][pz][:, None, None]) * wts[1][py][None, :, None]) * wts[2][px][None, None, :]
+    return res
 
 
 def zoom_spline2_u8(mask: np.ndarray, out_shape: Sequence[int]) -> np.ndarray:

@@ -1,0 +1,216 @@
+"""HIP path vs the CPU oracle / committed golden vectors, through the C ABI.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def net():
+    from oracle import delivr_oracle as orc
+
+    n = orc.build_unet(seed=0)
+    orc.randomize_affine(n, seed=1)
+    return n
+
+
+@pytest.fixture(scope="module")
+def eng_w(eng, net):
+    eng.load_state_dict({"state_dict": {"module." + k: v for k, v in net.state_dict().items()}})
+    return eng
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_unet_fp32_matches_oracle_golden(eng_w, golden_dir):
+    """fp32 VALU path vs torch-fp32 logits; tolerance: 2e-4 absolute on logits of std ~0.36."""
+    import torch
+
+    g = _g(golden_dir, "orc_unet.npz")
+    for xk, lk in (("x32", "logits32"), ("x_odd", "logits_odd")):
+        x = torch.from_numpy(g[xk].astype(np.float32))[None, None].cuda()
+        out = eng_w.unet_forward(x, "fp32").cpu().numpy()[0, 0]
+        ref = g[lk]
+        err = np.abs(out - ref).max()
+        assert err < 2e-4, (xk, err)
+        assert ((out >= 0) == (ref >= 0)).mean() > 0.9995
+
+
+def test_unet_fp32_batch_is_per_sample(eng_w, golden_dir):
+    """InstanceNorm statistics are per (sample, channel): batching must not change a sample."""
+    import torch
+
+    g = _g(golden_dir, "orc_unet.npz")
+    x = torch.from_numpy(g["x32"].astype(np.float32))[None, None].cuda()
+    xb = torch.cat([x, x.flip(2), x * 0.5], dim=0).contiguous()
+    out = eng_w.unet_forward(xb, "fp32")
+    single = eng_w.unet_forward(x, "fp32")
+    assert torch.equal(out[0], single[0])
+
+
+@pytest.mark.parametrize("flip", [None, 2, 3, 4])
+def test_sw_pass_fp32_matches_oracle(eng_w, net, golden_dir, flip):
+    """tiler + per-window skip + flip + forward + fp32 blend vs the oracle's pass (fp32 accumulate).
+    Tolerance 1e-3 absolute on sums of up to 8 logits; count map bit-exact vs the REFERENCE golden."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    g = _g(golden_dir, "ref_blend.npz")
+    vol = g["volume"]
+    roi = (32, 32, 16)
+    acc_ref = np.zeros(vol.shape, dtype=np.float32)
+    cnt_ref = np.zeros(vol.shape, dtype=np.uint8)
+    info = orc.sliding_window_pass(vol, roi, lambda x: orc.unet_forward(net, x), acc_ref, cnt_ref, 0.5, flip,
+                                   sw_batch_size=1, fp16=False)
+    v = eng_w.to_device(vol)
+    acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(vol.shape, dtype=torch.uint8, device="cuda")
+    p = eng_w.make_sw_params(vol.shape, roi, 0.5, flip, 0, "fp32", sw_batch=3)
+    st = eng_w.sw_infer(p, v, acc, cnt)
+    eng_w.sync()
+    assert st["n_windows"] == info["n_windows"] and st["n_skipped"] == info["n_skipped"] > 0
+    np.testing.assert_array_equal(cnt.cpu().numpy(), g["p1_b1_count"])
+    np.testing.assert_array_equal(cnt.cpu().numpy(), cnt_ref)
+    a = acc.cpu().numpy()
+    assert np.abs(a - acc_ref).max() < 1e-3
+    # skipped windows contribute exactly -1000 each
+    assert (a <= -999).any()
+
+
+def test_window_enumeration_matches_reference(eng, golden_dir):
+    g = _g(golden_dir, "ref_tiler.npz")
+    for i in range(int(g["n_cases"])):
+        img, roi = tuple(int(v) for v in g[f"case{i}_image"]), tuple(int(v) for v in g[f"case{i}_roi"])
+        p = eng.make_sw_params(img, roi, 0.5)
+        np.testing.assert_array_equal(eng.window_starts(p), g[f"case{i}_starts"])
+
+
+def test_sw_shards_compose(eng_w, golden_dir):
+    """windows [0,k) + [k,n) in two calls == one call (the multi-GPU partition is a pure split)."""
+    import torch
+
+    vol = _g(golden_dir, "ref_blend.npz")["volume"]
+    v = eng_w.to_device(vol)
+    roi = (32, 32, 16)
+    full = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    eng_w.sw_infer(eng_w.make_sw_params(vol.shape, roi, 0.5, None, 0, "fp32"), v, full)
+    n = eng_w.num_windows(eng_w.make_sw_params(vol.shape, roi, 0.5))
+    parts = torch.zeros_like(full)
+    for rng in ((0, n // 3), (n // 3, n)):
+        eng_w.sw_infer(eng_w.make_sw_params(vol.shape, roi, 0.5, None, 0, "fp32", win_range=rng), v, parts)
+    eng_w.sync()
+    assert torch.allclose(full, parts, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["oneblock", "blocks"])
+def test_finalize_matches_reference_golden(eng, golden_dir, tag):
+    """threshold + L1-30 eroded re-mask, bit-exact vs the reference's create_nifti_seg output."""
+    import torch
+
+    g = _g(golden_dir, "ref_finalize.npz")
+    Z, Y, X = (int(v) for v in g["stack_shape"][2:])
+    buf = int(g[f"{tag}_buf"])
+    zblock = max((buf // X) // Y, 1)
+    acc = torch.from_numpy(g["mean"].astype(np.float32)).cuda()
+    raw = eng.to_device(g["raw"])
+    out = eng.finalize(acc, None, raw, (Z, Y, X), 0.5, 30, zblock if zblock < Z else 0)
+    np.testing.assert_array_equal(out.cpu().numpy(), g[f"{tag}_binaries"])
+    # with an explicit count map (mean = acc*cnt / cnt)
+    cnt = torch.full(acc.shape, 4, dtype=torch.uint8, device="cuda")
+    out2 = eng.finalize(acc * 4, cnt, raw, (Z, Y, X), 0.5, 30, zblock if zblock < Z else 0)
+    np.testing.assert_array_equal(out2.cpu().numpy(), g[f"{tag}_binaries"])
+
+
+def test_erosion_random_vs_scipy(eng):
+    import torch
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(4)
+    for shape, r in (((33, 47, 52), 3), ((20, 64, 75), 30), ((5, 9, 13), 1)):
+        raw = (rng.random(shape) > 0.003).astype(np.uint16) * 77
+        acc = torch.ones(shape, dtype=torch.float32, device="cuda")
+        out = eng.finalize(acc, None, eng.to_device(raw), shape, 0.5, r, 0).cpu().numpy()
+        np.testing.assert_array_equal(out, orc.erode_l1((raw > 0).astype(np.uint8), r))
+
+
+def test_ccl_goldens_bit_exact(eng, golden_dir):
+    import torch
+
+    g = _g(golden_dir, "orc_ccl.npz")
+    cases = []
+    for key in ("gt0", "gt1"):
+        shape = tuple(int(v) for v in g[f"{key}_shape"])
+        cases.append((np.unpackbits(g[f"{key}_maskbits"])[: int(np.prod(shape))].reshape(shape), key))
+    cases.append((g["adv_mask"], "adv"))
+    for mask, key in cases:
+        lab, n = eng.ccl26(eng.to_device(mask.astype(np.uint8)))
+        assert n == int(g[f"{key}_n"])
+        np.testing.assert_array_equal(lab.cpu().numpy().view(np.uint32), g[f"{key}_labels"].astype(np.uint32))
+        st = eng.cc_stats(lab, n)
+        np.testing.assert_array_equal(st["voxel_counts"], g[f"{key}_counts"])
+        np.testing.assert_array_equal(st["bounding_boxes"], g[f"{key}_bbox"])
+        np.testing.assert_array_equal(st["centroids"][1:], g[f"{key}_centroids"][1:])
+        np.testing.assert_allclose(st["centroids"][0], g[f"{key}_centroids"][0], rtol=1e-12)
+
+
+def test_ccl_random_and_edge_cases(eng):
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(9)
+    for shape, dens in (((40, 50, 61), 0.05), ((17, 33, 130), 0.3), ((8, 8, 8), 0.0), ((6, 7, 9), 1.0), ((1, 1, 5), 0.5)):
+        mask = (rng.random(shape) < dens).astype(np.uint8)
+        lab, n = eng.ccl26(eng.to_device(mask))
+        ref, nref = orc.ccl26(mask)
+        assert n == nref
+        np.testing.assert_array_equal(lab.cpu().numpy().view(np.uint32), ref)
+        if n:
+            st, sr = eng.cc_stats(lab, n), orc.cc_stats(ref, nref)
+            np.testing.assert_array_equal(st["voxel_counts"][1:], sr["voxel_counts"][1:])
+            np.testing.assert_array_equal(st["bounding_boxes"][1:], sr["bounding_boxes"][1:])
+            np.testing.assert_array_equal(st["centroids"][1:], sr["centroids"][1:])
+
+
+def test_resamplers_vs_goldens(eng, golden_dir):
+    g = _g(golden_dir, "scipy_resample.npz")
+    out = eng.block_mean_u16(eng.to_device(g["bm_in"]), tuple(int(v) for v in g["bm_factors"]))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["bm_out"])
+    z = eng.zoom_spline2_u8(eng.to_device(g["zoom_in"]), g["zoom_out"].shape)
+    np.testing.assert_array_equal(z.cpu().numpy(), g["zoom_out"])  # bit-exact incl. ties
+
+
+def test_mask_pad_writer(eng):
+    rng = np.random.default_rng(2)
+    raw = rng.integers(0, 65535, size=(5, 7, 9)).astype(np.uint16)
+    mask = (rng.random((5, 7, 9)) < 0.5).astype(np.uint8)
+    out = eng.mask_pad_u16(eng.to_device(raw), eng.to_device(mask), (16, 16, 16)).cpu().numpy()
+    ref = np.zeros((16, 16, 16), dtype=np.uint16)
+    ref[:5, :7, :9] = raw * mask
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_errors_are_reported_not_crashed(eng):
+    import torch
+    from delivr_cfos_amd._lib import DelivrHipError
+    from delivr_cfos_amd.engine import HipEngine
+
+    fresh = HipEngine(0)
+    x = torch.zeros((1, 1, 16, 16, 16), dtype=torch.float32, device="cuda")
+    with pytest.raises(DelivrHipError):
+        fresh.unet_forward(x, "fp32")  # no weights loaded
+    fresh.close()
