@@ -1,9 +1,828 @@
-// placeholder - replaced by the MFMA implementation
+// unet_bf16.hip - bf16 MFMA U-Net forward for gfx950: the throughput path.
+//
+// Same arithmetic as unet_f32.hip / MONAI BasicUNet.forward (inference/sliding_window_inferer.py:222,
+// ctor inference/inference.py:190-197) with bf16 activations + weights, fp32 MFMA accumulation and
+// fp32 InstanceNorm statistics taken from the un-rounded accumulators.
+//
+// Data layout in HBM ("chunk-planar", z-major slabs per 8-channel chunk):
+//     act[n][C/8][D][H][W] of uint4  (one uint4 = 8 consecutive channels of one voxel, bf16)
+// so that (a) consecutive x voxels of a chunk are consecutive 16-byte elements (coalesced 1 KiB
+// wave loads/stores), and (b) an MFMA B-operand fragment (8 input channels of one voxel per lane)
+// is exactly one ds_read_b128 / global_load_dwordx4.
+//
+// 3x3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x16_bf16 with
+//     A = weights  (rows = 32 output channels, k = 16 input channels of one tap)
+//     B = input    (cols = 32 voxels,          k = same 16 channels, shifted by the tap)
+//     D[row = cout][col = voxel]  ->  each lane ends up with 4 consecutive output channels of its
+//                                     voxel per register quad = one 8-byte bf16 store.
+// K runs over 27 taps x Cin/16.  Weights are pre-packed in A-fragment order (one coalesced 1 KiB
+// load per fragment, L2-resident); the input halo tile is staged through LDS.
+#include <algorithm>
+
 #include "common.h"
-int dlv_pack_weights_bf16(dlv_ctx* ctx) { return DLV_OK; }
-int dlv_unet_forward_bf16(dlv_ctx* ctx, const float*, float*, int, int, int, int) {
-    return dlv_fail(ctx, DLV_EUNSUP, "bf16 path not built yet");
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t*, int, int, const int*, int, int, int, int, int, float, float*) {
-    return dlv_fail(ctx, DLV_EUNSUP, "bf16 path not built yet");
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float mish_fast(float y) {
+    // y * tanh(softplus(y)) = y * (n^2 + 2n) / (n^2 + 2n + 2), n = e^y; identity above the
+    // softplus threshold (20) as in torch
+    const float n = __expf(fminf(y, 20.f));
+    const float t = n * (n + 2.f);
+    const float r = y * __fdividef(t, t + 2.f);
+    return y > 20.f ? y : r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing (device side, once per dlv_unet_load)
+// ---------------------------------------------------------------------------------------------------
+// conv:   out[((cb*27 + t)*KP + kp)*64 + lane][j] = W[cout = cb*32 + (lane&31)][cin = kp*16 + 8*(lane>>5) + j][t]
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin) {
+    const int KP = cin / 16;
+    const long long n = (long long)cout * cin * 27;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        long long r = i >> 9;
+        const int kp = (int)(r % KP);
+        r /= KP;
+        const int t = (int)(r % 27);
+        const int cb = (int)(r / 27);
+        const int co = cb * 32 + (lane & 31);
+        const int ci = kp * 16 + 8 * (lane >> 5) + j;
+        const float v = w[((long long)co * cin + ci) * 27 + t];
+        out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+    }
+}
+// deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
+__global__ void pack_deconv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cin, int cout) {
+    const int KP = cin / 16, CB = cout / 32;
+    const long long n = (long long)cin * cout * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        long long r = i >> 9;
+        const int kp = (int)(r % KP);
+        r /= KP;
+        const int cb = (int)(r % CB);
+        const int par = (int)(r / CB);
+        const int co = cb * 32 + (lane & 31);
+        const int ci = kp * 16 + 8 * (lane >> 5) + j;
+        const float v = w[((long long)ci * cout + co) * 8 + par];
+        out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stem: Conv3d(1 -> C0, k3, p1) in fp32 on the VALU, straight from the uint16 volume window
+// (gather + cast + flip of inference/sliding_window_inferer.py:181-195,218-219 fused in) or from an
+// fp32 patch.  Writes raw (pre-norm) bf16 + per-block partial sums for the InstanceNorm.
+// ---------------------------------------------------------------------------------------------------
+constexpr int STEM_ZR = 4;  // z-run per thread
+
+template <bool FROM_VOLUME>
+__global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict__ xf, const uint16_t* __restrict__ vol,
+                                                        int Yp, int Xp, const int* __restrict__ starts, int flip_dim,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        uint4* __restrict__ out, float* __restrict__ partials, int D,
+                                                        int H, int W) {
+    __shared__ float wl[27 * 32];
+    __shared__ float red[4][64];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+        const int t = i >> 5, co = i & 31;
+        wl[i] = w[co * 27 + t];
+    }
+    __syncthreads();
+    const int n = blockIdx.z;
+    const int hw = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool pvalid = p < hw;
+    const int y = pvalid ? p / W : 0, x = pvalid ? p % W : 0;
+    const int zb = blockIdx.y * STEM_ZR;
+    int z0 = 0, y0 = 0, x0 = 0;
+    if (FROM_VOLUME) {
+        z0 = starts[3 * n];
+        y0 = starts[3 * n + 1];
+        x0 = starts[3 * n + 2];
+    }
+    auto fetch = [&](int zz, int yy, int xx) -> float {
+        if ((unsigned)zz >= (unsigned)D || (unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return 0.f;
+        if (FROM_VOLUME) {
+            if (flip_dim == 2) zz = D - 1 - zz;
+            if (flip_dim == 3) yy = H - 1 - yy;
+            if (flip_dim == 4) xx = W - 1 - xx;
+            return (float)vol[((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx)];
+        }
+        return xf[(long long)n * D * hw + ((long long)zz * H + yy) * W + xx];
+    };
+    float s[32], q[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.f;
+#pragma unroll 1
+    for (int zi = 0; zi < STEM_ZR; ++zi) {
+        const int z = zb + zi;
+        if (z >= D || !pvalid) continue;
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = bias[c];
+#pragma unroll 1
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = fetch(z + dz - 1, y + dy - 1, x + dx - 1);
+                    const float4* wr = reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 32);
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 ww = wr[c4];
+                        acc[4 * c4 + 0] = fmaf(v, ww.x, acc[4 * c4 + 0]);
+                        acc[4 * c4 + 1] = fmaf(v, ww.y, acc[4 * c4 + 1]);
+                        acc[4 * c4 + 2] = fmaf(v, ww.z, acc[4 * c4 + 2]);
+                        acc[4 * c4 + 3] = fmaf(v, ww.w, acc[4 * c4 + 3]);
+                    }
+                }
+        const long long vox = (long long)D * hw;
+        const long long o = (long long)z * hw + p;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            uint4 u;
+            u.x = pack2(acc[8 * c8 + 0], acc[8 * c8 + 1]);
+            u.y = pack2(acc[8 * c8 + 2], acc[8 * c8 + 3]);
+            u.z = pack2(acc[8 * c8 + 4], acc[8 * c8 + 5]);
+            u.w = pack2(acc[8 * c8 + 6], acc[8 * c8 + 7]);
+            out[((long long)n * 4 + c8) * vox + o] = u;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            s[c] += acc[c];
+            q[c] = fmaf(acc[c], acc[c], q[c]);
+        }
+    }
+    // block reduction -> partials[n][block][32][2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        float a = s[c], b = q[c];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (lane == 0) {
+            red[wave][2 * c] = a;
+            red[wave][2 * c + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long nblk = (long long)gridDim.x * gridDim.y;
+        partials[((long long)n * nblk + blk) * 64 + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic 3x3x3 convolution, implicit GEMM on MFMA
+//   workgroup: 256 output voxels (4 z-slices x 64 voxels) x 32*NCB output channels
+//   wave w   : z-slice w, two 32-voxel blocks, NCB cout blocks  -> 2*NCB accumulator tiles
+//   loop     : input channels in slabs of 32 (halo tile staged in LDS) x 27 taps x 2 k-steps
+// ---------------------------------------------------------------------------------------------------
+template <int TX>
+struct ConvTile {
+    static constexpr int TZ = 4;
+    static constexpr int TY = 64 / TX;       // 4 (TX=16) or 8 (TX=8)
+    static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    static constexpr int SLAB = 4 * HZ * HY * HX;  // uint4 elements per 32-channel slab
+    static constexpr int RV = 32 / TX;       // rows per 32-voxel block
+};
+
+template <int NCB, int TX>
+__global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict__ in1, int c1_8,
+                                                         const uint4* __restrict__ in2, int c2_8,
+                                                         const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                         uint4* __restrict__ out, float* __restrict__ partials, int cout,
+                                                         int D, int H, int W, int tilesY, int tilesX) {
+    using T = ConvTile<TX>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* slab = reinterpret_cast<uint4*>(smem_raw);
+    const int n = blockIdx.z;
+    const int tile = blockIdx.x;
+    const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, tz = tile / (tilesX * tilesY);
+    const int z0 = tz * T::TZ, y0 = ty * T::TY, x0 = tx * TX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int vr = col / TX, vx = col % TX;  // row / x of this lane's voxel inside a 32-voxel block
+    const int cin8 = c1_8 + c2_8;
+    const int KP = cin8 / 2;
+    const int cbg0 = blockIdx.y * NCB;
+    const long long vox = (long long)D * H * W;
+
+    f32x16 acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][v][r] = 0.f;
+
+    // per-lane LDS element offset of tap (0,0,0) for the two voxel blocks, chunk h of k-step 0
+    int lbase[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) lbase[v] = ((h * T::HZ + wave) * T::HY + (v * T::RV + vr)) * T::HX + vx;
+
+    const int nslab = cin8 / 4;
+    for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();  // previous slab fully consumed
+        for (int i = threadIdx.x; i < T::SLAB; i += 256) {
+            const int xh = i % T::HX;
+            int r = i / T::HX;
+            const int yh = r % T::HY;
+            r /= T::HY;
+            const int zh = r % T::HZ;
+            const int c = r / T::HZ;
+            const int gz = z0 + zh - 1, gy = y0 + yh - 1, gx = x0 + xh - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                const int cg = sl * 4 + c;
+                const uint4* src = cg < c1_8 ? in1 + ((long long)n * c1_8 + cg) * vox
+                                             : in2 + ((long long)n * c2_8 + (cg - c1_8)) * vox;
+                v = src[((long long)gz * H + gy) * W + gx];
+            }
+            slab[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int t = (kz * 3 + ky) * 3 + kx;
+                    const int toff = (kz * T::HY + ky) * T::HX + kx;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int kp = sl * 2 + ks;
+                        bf16x8 a[NCB];
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            const uint4 u = wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
+                            a[cb] = __builtin_bit_cast(bf16x8, u);
+                        }
+                        bf16x8 b[2];
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const uint4 u = slab[lbase[v] + toff + ks * 2 * T::HZ * T::HY * T::HX];
+                            b[v] = __builtin_bit_cast(bf16x8, u);
+                        }
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                            for (int v = 0; v < 2; ++v)
+                                acc[cb][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[v], acc[cb][v], 0, 0, 0);
+                    }
+                }
+    }
+
+    // ---- epilogue: bias, bf16 store, InstanceNorm partial sums -------------------------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][NCB*32][2]
+    const int oz = z0 + wave;
+    const int cout8 = cout / 8;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        float bs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bs[r] = bias[(cbg0 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        float s[16], q[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = q[r] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int oy = y0 + v * T::RV + vr, ox = x0 + vx;
+            const bool ok = oz < D && oy < H && ox < W;
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                val[r] = acc[cb][v][r] + bs[r];
+                if (ok) {
+                    s[r] += val[r];
+                    q[r] = fmaf(val[r], val[r], q[r]);
+                }
+            }
+            if (ok) {
+                const long long o = ((long long)oz * H + oy) * W + ox;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = pack2(val[4 * g + 2], val[4 * g + 3]);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * cout8 + (cbg0 + cb) * 4 + g) * vox + o);
+                    dst[h] = u;
+                }
+            }
+        }
+        // reduce over the 32 voxels (lanes with equal h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s[r], b = q[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (col == 0) {
+                const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[(wave * NCB * 32 + co) * 2] = a;
+                red[(wave * NCB * 32 + co) * 2 + 1] = b;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NCB * 32 * 2) {
+        const int i = threadIdx.x;
+        const float v = red[i] + red[NCB * 64 + i] + red[2 * NCB * 64 + i] + red[3 * NCB * 64 + i];
+        const int co = cbg0 * 32 + (i >> 1);
+        partials[(((long long)n * gridDim.x + tile) * cout + co) * 2 + (i & 1)] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm statistics: partial sums -> per (n,c) scale/shift   y = x*scale + shift
+// one wave per (n,c); fixed summation order (bitwise reproducible)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                            double inv_count, float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float2* __restrict__ ss) {
+    const int c = blockIdx.x % C, n = blockIdx.x / C;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(partials + (((long long)n * nparts + i) * C + c) * 2);
+        s += v.x;
+        q += v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        q += __shfl_down(q, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double mean = s * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        ss[n * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm apply + Mish (+ MaxPool3d(2) into a second tensor), in place on the raw bf16 tensor
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const float* sh, float* mx) {
+    float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = mish_fast(fmaf(v[k], sc[k], sh[k]));
+        if (mx) mx[k] = fmaxf(mx[k], v[k]);
+    }
+    uint4 r;
+    r.x = pack2(v[0], v[1]);
+    r.y = pack2(v[2], v[3]);
+    r.z = pack2(v[4], v[5]);
+    r.w = pack2(v[6], v[7]);
+    return r;
+}
+
+template <bool POOL>
+__global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C,
+                                                        int D, int H, int W, uint4* __restrict__ pooled) {
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 v = ss[n * C + c8 * 8 + k];
+        sc[k] = v.x;
+        sh[k] = v.y;
+    }
+    const long long vox = (long long)D * H * W;
+    uint4* p = x + ((long long)n * (C / 8) + c8) * vox;
+    if (!POOL) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256)
+            p[i] = norm_mish8(p[i], sc, sh, nullptr);
+    } else {
+        const int d2 = D / 2, h2 = H / 2, w2 = W / 2;
+        const long long pv = (long long)d2 * h2 * w2;
+        uint4* q = pooled + ((long long)n * (C / 8) + c8) * pv;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pv; i += (long long)gridDim.x * 256) {
+            const int xx = (int)(i % w2), yy = (int)((i / w2) % h2), zz = (int)(i / ((long long)w2 * h2));
+            float mx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx[k] = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const long long o = ((long long)(2 * zz + a) * H + (2 * yy + b)) * W + 2 * xx;
+                    p[o] = norm_mish8(p[o], sc, sh, mx);
+                    p[o + 1] = norm_mish8(p[o + 1], sc, sh, mx);
+                }
+            uint4 r;
+            r.x = pack2(mx[0], mx[1]);
+            r.y = pack2(mx[2], mx[3]);
+            r.z = pack2(mx[4], mx[5]);
+            r.w = pack2(mx[6], mx[7]);
+            q[i] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d k2 s2 on MFMA: for each of the 8 output parities a (Cin x Cout) channel GEMM
+//   wave: 32 consecutive input voxels (B fragments straight from HBM, no LDS), all parities/couts
+// ---------------------------------------------------------------------------------------------------
+template <int KP>  // Cin / 16
+__global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
+                                                           const float* __restrict__ bias, uint4* __restrict__ out,
+                                                           int cout, int D, int H, int W) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long vox = (long long)D * H * W;
+    const long long v = ((long long)blockIdx.x * 4 + wave) * 32 + col;
+    const bool ok = v < vox;
+    const long long vc = ok ? v : 0;
+    bf16x8 b[KP];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vc];
+        if (!ok) u = make_uint4(0, 0, 0, 0);
+        b[kp] = __builtin_bit_cast(bf16x8, u);
+    }
+    const int x = (int)(vc % W), y = (int)((vc / W) % H), z = (int)(vc / ((long long)W * H));
+    const int CB = cout / 32, cout8 = cout / 8;
+    const int OH = 2 * H, OW = 2 * W;
+    const long long ovox = vox * 8;
+    for (int par = 0; par < 8; ++par) {
+        const long long o = ((long long)(2 * z + (par >> 2)) * OH + (2 * y + ((par >> 1) & 1))) * OW + 2 * x + (par & 1);
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias[cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                const uint4 u = wpk[(((long long)par * CB + cb) * KP + kp) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u), b[kp], acc, 0, 0, 0);
+            }
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = pack2(acc[4 * g + 0], acc[4 * g + 1]);
+                    u.y = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * cout8 + cb * 4 + g) * ovox + o);
+                    dst[h] = u;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// final: InstanceNorm + Mish of the last block, Conv3d(C5 -> 1, k1), then either plain logits or
+// the blend accumulate of inference/sliding_window_inferer.py:232-251 (acc[window] += logit, un-flipped)
+// ---------------------------------------------------------------------------------------------------
+template <bool BLEND>
+__global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict__ x, const float2* __restrict__ ss,
+                                                         const float* __restrict__ wf, const float* __restrict__ bf,
+                                                         float* __restrict__ logits, const int* __restrict__ starts,
+                                                         int flip_dim, int Yp, int Xp, float scale, float* __restrict__ acc,
+                                                         int D, int H, int W) {
+    __shared__ float sc[32], sh[32], ww[32];
+    const int n = blockIdx.y;
+    if (threadIdx.x < 32) {
+        const float2 v = ss[n * 32 + threadIdx.x];
+        sc[threadIdx.x] = v.x;
+        sh[threadIdx.x] = v.y;
+        ww[threadIdx.x] = wf[threadIdx.x];
+    }
+    __syncthreads();
+    const long long vox = (long long)D * H * W;
+    const float b0 = bf[0];
+    int z0 = 0, y0 = 0, x0 = 0;
+    if (BLEND) {
+        z0 = starts[3 * n];
+        y0 = starts[3 * n + 1];
+        x0 = starts[3 * n + 2];
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
+        float a = b0;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            const uint4 u = x[((long long)n * 4 + c8) * vox + i];
+            const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a = fmaf(mish_fast(fmaf(v[k], sc[8 * c8 + k], sh[8 * c8 + k])), ww[8 * c8 + k], a);
+        }
+        if (!BLEND) {
+            logits[(long long)n * vox + i] = a;
+        } else {
+            int xx = (int)(i % W), yy = (int)((i / W) % H), zz = (int)(i / ((long long)W * H));
+            if (flip_dim == 2) zz = D - 1 - zz;
+            if (flip_dim == 3) yy = H - 1 - yy;
+            if (flip_dim == 4) xx = W - 1 - xx;
+            acc[((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx)] += scale * a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// debug / test conversions: fp32 NCDHW <-> bf16 chunk-planar
+// ---------------------------------------------------------------------------------------------------
+__global__ void f32_to_cp_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C, long long vox) {
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = in[((long long)n * C + c8 * 8 + k) * vox + i];
+        uint4 r;
+        r.x = pack2(v[0], v[1]);
+        r.y = pack2(v[2], v[3]);
+        r.z = pack2(v[4], v[5]);
+        r.w = pack2(v[6], v[7]);
+        out[((long long)n * (C / 8) + c8) * vox + i] = r;
+    }
+}
+__global__ void cp_to_f32_kernel(const uint4* __restrict__ in, float* __restrict__ out, int C, long long vox) {
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
+        const uint4 u = in[((long long)n * (C / 8) + c8) * vox + i];
+        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[((long long)n * C + c8 * 8 + k) * vox + i] = v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct Dims {
+    int D, H, W;
+    long long vox() const { return (long long)D * H * W; }
+};
+
+struct Bf16Net {
+    dlv_ctx* ctx;
+    int B;
+    float* partials;
+    size_t partials_floats;
+    float2* ss;  // [B][256]
+
+    int grid1d(long long n) const { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
+
+    int stats(int nparts, int li, Dims d) {
+        const DlvConvLayer& L = ctx->conv[li];
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(B * L.cout), dim3(64), 0, ctx->stream, partials, nparts, L.cout,
+                           1.0 / (double)d.vox(), 1e-5f, L.gamma, L.beta, ss);
+        DLV_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
+        return DLV_OK;
+    }
+
+    // raw conv output + InstanceNorm scale/shift into ss
+    int conv(int li, const uint4* in1, int c1, const uint4* in2, int c2, uint4* out, Dims d) {
+        const DlvConvLayer& L = ctx->conv[li];
+        if (c1 + c2 != L.cin) return dlv_fail(ctx, DLV_ESTATE, "conv %d: %d+%d input channels, expected %d", li, c1, c2, L.cin);
+        if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
+        const bool tx16 = d.W >= 16;
+        const int TX = tx16 ? 16 : 8, TY = 64 / TX;
+        const int tZ = dlv_cdiv(d.D, 4), tY = dlv_cdiv(d.H, TY), tX = dlv_cdiv(d.W, TX);
+        const int ntiles = tZ * tY * tX;
+        const int ncb = L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1);
+        if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
+        const size_t lds = std::max<size_t>((size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16,
+                                            (size_t)4 * ncb * 32 * 2 * 4);
+        dim3 grid(ntiles, L.cout / (32 * ncb), B);
+        const double flops = 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B;
+        const double bytes = 2.0 * (double)d.vox() * B * (L.cin + L.cout);
+        char name[48];
+        snprintf(name, sizeof(name), "conv3_mfma_bf16_c%dx%d", L.cin, L.cout);
+        DlvProf pr(ctx, name, flops, bytes);
+#define DLV_CONV_LAUNCH(NCB_, TX_)                                                                                    \
+    hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2, c2 / 8,    \
+                       reinterpret_cast<const uint4*>(L.w_bf16), L.bias, out, partials, L.cout, d.D, d.H, d.W, tY, tX)
+        if (tx16) {
+            if (ncb == 1) DLV_CONV_LAUNCH(1, 16);
+            else if (ncb == 2) DLV_CONV_LAUNCH(2, 16);
+            else DLV_CONV_LAUNCH(4, 16);
+        } else {
+            if (ncb == 1) DLV_CONV_LAUNCH(1, 8);
+            else if (ncb == 2) DLV_CONV_LAUNCH(2, 8);
+            else DLV_CONV_LAUNCH(4, 8);
+        }
+#undef DLV_CONV_LAUNCH
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "conv3_mfma_kernel");
+        return stats(ntiles, li, d);
+    }
+
+    int norm_mish(uint4* x, int C, Dims d, uint4* pooled) {
+        const long long work = pooled ? d.vox() / 8 : d.vox();
+        dim3 grid(std::max(1, std::min(grid1d(work), 2048)), C / 8, B);
+        DlvProf pr(ctx, pooled ? "norm_mish_pool_bf16" : "norm_mish_bf16", 0.0,
+                   (double)d.vox() * B * C * 2 * 2 + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
+        if (pooled)
+            hipLaunchKernelGGL(norm_mish_kernel<true>, grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+        else
+            hipLaunchKernelGGL(norm_mish_kernel<false>, grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "norm_mish_kernel");
+        return DLV_OK;
+    }
+
+    int deconv(int j, const uint4* in, uint4* out, Dims din) {
+        const DlvDeconvLayer& L = ctx->deconv[j];
+        dim3 grid(dlv_cdiv(din.vox(), 128), B);
+        const uint4* w = reinterpret_cast<const uint4*>(L.w_bf16);
+        DlvProf pr(ctx, "deconv2_mfma_bf16", 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
+                   2.0 * (double)din.vox() * B * (L.cin + 8.0 * L.cout));
+        switch (L.cin / 16) {
+            case 2: hipLaunchKernelGGL(deconv2_mfma_kernel<2>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
+            case 4: hipLaunchKernelGGL(deconv2_mfma_kernel<4>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
+            case 8: hipLaunchKernelGGL(deconv2_mfma_kernel<8>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
+            case 16: hipLaunchKernelGGL(deconv2_mfma_kernel<16>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
+            default: return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: Cin=%d not in {32,64,128,256}", j, L.cin);
+        }
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "deconv2_mfma_kernel");
+        return DLV_OK;
+    }
+};
+
+// the whole forward; the stem reads either xf (fp32 patches) or the uint16 volume windows, the final
+// layer writes either logits or blends into acc
+int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int flip_dim,
+                 float scale, float* logits, float* acc, int B, int d, int h, int w) {
+    const int* f = ctx->features;
+    if (f[0] != 32 || f[5] != 32)
+        return dlv_fail(ctx, DLV_EUNSUP, "bf16 path: features[0] and features[5] must be 32 (got %d, %d)", f[0], f[5]);
+    Dims dm[5];
+    for (int l = 0; l < 5; ++l) dm[l] = Dims{d >> l, h >> l, w >> l};
+    const int lvlC[5] = {32, f[1], f[2], f[3], f[4]};
+    size_t off = 0, offs[5][4];
+    for (int l = 0; l < 5; ++l)
+        for (int k = 0; k < 4; ++k) {
+            offs[l][k] = off;
+            off += (size_t)B * lvlC[l] * dm[l].vox() * 2;
+            off = (off + 255) & ~(size_t)255;
+        }
+    char* base;
+    DLV_TRY(dlv_ws_get(ctx, WS_BF16_ACT, off, (void**)&base));
+    // partial sums: the level-0 convs have the most tiles (256 voxels each); the stem has fewer blocks
+    const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
+    const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
+    char* sbase;
+    DLV_TRY(dlv_ws_get(ctx, WS_STATS, pfloats * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
+    Bf16Net net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
+    auto buf = [&](int l, int k) { return (uint4*)(base + offs[l][k]); };
+    enum { A = 0, Bf = 1, S = 2, U = 3 };
+
+    // stem
+    {
+        dim3 grid(dlv_cdiv((long long)h * w, 256), dlv_cdiv(d, STEM_ZR), B);
+        const int nblk = grid.x * grid.y;
+        if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
+        const DlvConvLayer& L = ctx->conv[0];
+        DlvProf pr(ctx, "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
+        if (vol)
+            hipLaunchKernelGGL(stem_conv_kernel<true>, grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
+                               flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
+        else
+            hipLaunchKernelGGL(stem_conv_kernel<false>, grid, dim3(256), 0, ctx->stream, xf, nullptr, 0, 0, nullptr, -1,
+                               L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "stem_conv_kernel");
+        DLV_TRY(net.stats(nblk, 0, dm[0]));
+        DLV_TRY(net.norm_mish(buf(0, A), 32, dm[0], nullptr));
+    }
+    DLV_TRY(net.conv(1, buf(0, A), 32, nullptr, 0, buf(0, S), dm[0]));
+    DLV_TRY(net.norm_mish(buf(0, S), 32, dm[0], buf(1, A)));
+    const int encC[5] = {32, f[1], f[2], f[3], f[4]};
+    for (int l = 1; l <= 4; ++l) {
+        DLV_TRY(net.conv(2 * l, buf(l, A), encC[l - 1], nullptr, 0, buf(l, Bf), dm[l]));
+        DLV_TRY(net.norm_mish(buf(l, Bf), encC[l], dm[l], nullptr));
+        DLV_TRY(net.conv(2 * l + 1, buf(l, Bf), encC[l], nullptr, 0, buf(l, S), dm[l]));
+        DLV_TRY(net.norm_mish(buf(l, S), encC[l], dm[l], l < 4 ? buf(l + 1, A) : nullptr));
+    }
+    const uint4* cur = buf(4, S);
+    for (int j = 0; j < 4; ++j) {
+        const int l = 3 - j;
+        DLV_TRY(net.deconv(j, cur, buf(l, U), dm[l + 1]));
+        const int li = 10 + 2 * j;
+        DLV_TRY(net.conv(li, buf(l, S), encC[l], buf(l, U), ctx->deconv[j].cout, buf(l, Bf), dm[l]));
+        DLV_TRY(net.norm_mish(buf(l, Bf), ctx->conv[li].cout, dm[l], nullptr));
+        DLV_TRY(net.conv(li + 1, buf(l, Bf), ctx->conv[li].cout, nullptr, 0, buf(l, A), dm[l]));
+        if (j < 3) DLV_TRY(net.norm_mish(buf(l, A), ctx->conv[li + 1].cout, dm[l], nullptr));
+        cur = buf(l, A);
+    }
+    {
+        dim3 grid(std::min(net.grid1d(dm[0].vox()), 2048), B);
+        DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
+                   (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
+        if (acc)
+            hipLaunchKernelGGL(final_conv_kernel<true>, grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+                               ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w);
+        else
+            hipLaunchKernelGGL(final_conv_kernel<false>, grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+                               ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w);
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "final_conv_kernel");
+    }
+    return DLV_OK;
+}
+
+}  // namespace
+
+int dlv_pack_weights_bf16(dlv_ctx* ctx) {
+    for (int i = 1; i < DLV_N_CONV; ++i) {
+        const DlvConvLayer& L = ctx->conv[i];
+        if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: %d->%d not multiples of 32", i, L.cin, L.cout);
+        hipLaunchKernelGGL(pack_conv_w_kernel, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, L.w_bf16, L.cout, L.cin);
+        DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
+    }
+    for (int j = 0; j < DLV_N_DECONV; ++j) {
+        const DlvDeconvLayer& L = ctx->deconv[j];
+        if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: %d->%d not multiples of 32", j, L.cin, L.cout);
+        hipLaunchKernelGGL(pack_deconv_w_kernel, dim3(64), dim3(256), 0, ctx->stream, L.w_f32, L.w_bf16, L.cin, L.cout);
+        DLV_LAUNCH_CHECK(ctx, "pack_deconv_w_kernel");
+    }
+    return DLV_OK;
+}
+
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w) {
+    return forward_bf16(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
+}
+
+int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d, int h,
+                        int w, int flip_dim, float scale, float* acc) {
+    return forward_bf16(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
+}
+
+// test hook: one conv block (raw conv + InstanceNorm + Mish) or one deconv of the bf16 path on fp32
+// NCDHW tensors (converted on the device)
+extern "C" int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
+                                    int c2, float* out_dev, int B, int D, int H, int W) {
+    if (!ctx || !in1_dev || !out_dev) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "no weights");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const long long vox = (long long)D * H * W;
+    if (kind == 0) {
+        if (index < 1 || index >= DLV_N_CONV) return dlv_fail(ctx, DLV_EINVAL, "conv index must be 1..17");
+        const DlvConvLayer& L = ctx->conv[index];
+        if (c1 + c2 != L.cin || c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EINVAL, "bad channel split");
+        const size_t b1 = (size_t)B * c1 * vox * 2, b2 = (size_t)B * c2 * vox * 2, bo = (size_t)B * L.cout * vox * 2;
+        const long long tiles = (long long)dlv_cdiv(D, 4) * dlv_cdiv(H, 4) * dlv_cdiv(W, 8);
+        const size_t pf = (size_t)B * tiles * L.cout * 2;
+        char* base;
+        DLV_TRY(dlv_ws_get(ctx, WS_BF16_ACT, b1 + b2 + bo + 1024, (void**)&base));
+        char* sbase;
+        DLV_TRY(dlv_ws_get(ctx, WS_STATS, pf * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
+        uint4 *i1 = (uint4*)base, *i2 = (uint4*)(base + ((b1 + 255) & ~(size_t)255)),
+              *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255) + ((b2 + 255) & ~(size_t)255));
+        Bf16Net net{ctx, B, (float*)sbase, pf, (float2*)(sbase + ((pf * 4 + 255) & ~(size_t)255))};
+        const int g = net.grid1d(vox);
+        hipLaunchKernelGGL(f32_to_cp_kernel, dim3(g, c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
+        if (c2) hipLaunchKernelGGL(f32_to_cp_kernel, dim3(g, c2 / 8, B), dim3(256), 0, ctx->stream, in2_dev, i2, c2, vox);
+        DLV_TRY(net.conv(index, i1, c1, c2 ? i2 : nullptr, c2, o, Dims{D, H, W}));
+        DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr));
+        hipLaunchKernelGGL(cp_to_f32_kernel, dim3(g, L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev, L.cout, vox);
+        DLV_LAUNCH_CHECK(ctx, "debug conv");
+        return DLV_OK;
+    }
+    if (kind == 1) {
+        if (index < 0 || index >= DLV_N_DECONV) return dlv_fail(ctx, DLV_EINVAL, "deconv index must be 0..3");
+        const DlvDeconvLayer& L = ctx->deconv[index];
+        if (c1 != L.cin || c2 != 0) return dlv_fail(ctx, DLV_EINVAL, "bad channels");
+        const size_t b1 = (size_t)B * c1 * vox * 2, bo = (size_t)B * L.cout * vox * 8 * 2;
+        char* base;
+        DLV_TRY(dlv_ws_get(ctx, WS_BF16_ACT, b1 + bo + 1024, (void**)&base));
+        uint4 *i1 = (uint4*)base, *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255));
+        Bf16Net net{ctx, B, nullptr, 0, nullptr};
+        hipLaunchKernelGGL(f32_to_cp_kernel, dim3(net.grid1d(vox), c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
+        DLV_TRY(net.deconv(index, i1, o, Dims{D, H, W}));
+        hipLaunchKernelGGL(cp_to_f32_kernel, dim3(net.grid1d(vox * 8), L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev,
+                           L.cout, vox * 8);
+        DLV_LAUNCH_CHECK(ctx, "debug deconv");
+        return DLV_OK;
+    }
+    return dlv_fail(ctx, DLV_EINVAL, "kind must be 0 (conv block) or 1 (deconv)");
 }

@@ -182,6 +182,29 @@ class HipEngine:
         self._leave()
         return out
 
+    def debug_layer_bf16(self, kind: int, index: int, in1, in2=None):
+        """test hook (dlv_debug_layer_bf16): one conv block / deconv of the bf16 path on fp32 tensors."""
+        torch = self.torch
+        B, c1, D, H, W = in1.shape
+        c2 = 0 if in2 is None else int(in2.shape[1])
+        if kind == 0:
+            cout = {i: None for i in range(18)}
+            blk_out = [self.features[0], self.features[0], self.features[1], self.features[1], self.features[2],
+                       self.features[2], self.features[3], self.features[3], self.features[4], self.features[4],
+                       self.features[3], self.features[3], self.features[2], self.features[2], self.features[1],
+                       self.features[1], self.features[5], self.features[5]]
+            out = torch.empty((B, blk_out[index], D, H, W), dtype=torch.float32, device=self.device)
+        else:
+            dco = [self.features[4] // 2, self.features[3] // 2, self.features[2] // 2, self.features[1]]
+            out = torch.empty((B, dco[index], 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_debug_layer_bf16(
+            self.ctx, kind, index, self._dev(in1, torch.float32, "in1"), int(c1),
+            self._dev(in2, torch.float32, "in2") if in2 is not None else None, c2,
+            self._dev(out, torch.float32, "out"), B, D, H, W))
+        self._leave()
+        return out
+
     # ---- sliding window ----------------------------------------------------------------------------
     def make_sw_params(self, padded_shape, roi, overlap=0.5, flip_dim=None, skip_threshold=0, precision="bf16",
                        sw_batch=0, win_range=None, slab=None, repeat=1) -> _lib.SwParams:

@@ -196,6 +196,14 @@ int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch wit
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
 
+/* ---- test hook ------------------------------------------------------------------------------ */
+/* Runs ONE layer of the bf16 MFMA path on fp32 NCDHW device tensors (converted on the device) so
+ * that tests/ can compare each kernel with the oracle in isolation.  kind 0: conv block `index`
+ * (1..17: Conv3d k3 + InstanceNorm + Mish) on the channel concatenation [in1 (c1), in2 (c2, may be
+ * 0)] -> out (B,Cout,D,H,W); kind 1: ConvTranspose3d `index` (0..3) -> out (B,Cout,2D,2H,2W). */
+int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
+                         int c2, float* out_dev, int B, int D, int H, int W);
+
 #ifdef __cplusplus
 }
 #endif

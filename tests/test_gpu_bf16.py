@@ -1,0 +1,154 @@
+"""bf16 MFMA path vs the oracle: every kernel in isolation (dlv_debug_layer_bf16), the whole
+forward, and the fused sliding-window pass.  Tolerances are the bf16 ones stated in DESIGN.md:
+activations/weights carry 8 significant bits, accumulation and InstanceNorm statistics are fp32."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    from oracle import delivr_oracle as orc
+
+    n = orc.build_unet(seed=0)
+    orc.randomize_affine(n, seed=1)
+    return n
+
+
+@pytest.fixture(scope="module")
+def eng(net):
+    from delivr_cfos_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    e.load_state_dict({"state_dict": net.state_dict()})
+    yield e
+    e.close()
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def _conv_block(net, li):
+    from delivr_cfos_amd.engine import CONV_BLOCKS
+
+    mod = net
+    for part in CONV_BLOCKS[li].split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+# (layer, c1, c2, D, H, W): covers NCB 1/2/4, TX 16/8, concat inputs, ragged tile borders
+CONV_CASES = [
+    (1, 32, 0, 8, 8, 32),
+    (1, 32, 0, 6, 10, 24),     # partial tiles in z, y and x
+    (16, 32, 32, 8, 12, 16),   # concat 32+32 -> 32
+    (5, 64, 0, 8, 8, 16),      # 64 -> 64 (NCB 2)
+    (4, 32, 0, 4, 6, 8),       # 32 -> 64, W=8 -> TX 8
+    (9, 256, 0, 4, 4, 8),      # 256 -> 256 (NCB 4), TX 8
+    (10, 128, 128, 2, 6, 12),  # concat 128+128 -> 128, odd sizes
+    (12, 64, 64, 4, 8, 16),
+]
+
+
+@pytest.mark.parametrize("li,c1,c2,D,H,W", CONV_CASES)
+def test_conv_block_bf16(eng, net, li, c1, c2, D, H, W):
+    """Conv3d+InstanceNorm+Mish of one block vs torch fp32 on the SAME bf16-rounded inputs and
+    weights: what remains is fp32 summation order + the bf16 rounding of the stored raw / output
+    tensors -> max abs error 0.06 on O(1) activations, mean abs error 6e-3."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(li * 100 + D)
+    B = 2
+    x1 = _bf(torch.randn((B, c1, D, H, W), generator=g))
+    x2 = _bf(torch.randn((B, c2, D, H, W), generator=g)) if c2 else None
+    blk = _conv_block(net, li)
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    with torch.no_grad():
+        raw = F.conv3d(xin, _bf(blk.conv.weight), blk.conv.bias, padding=1)
+        ref = F.mish(F.instance_norm(raw, weight=blk.adn.N.weight, bias=blk.adn.N.bias, eps=1e-5))
+    out = eng.debug_layer_bf16(0, li, x1.cuda(), None if x2 is None else x2.cuda()).cpu()
+    err = (out - ref).abs()
+    assert err.max() < 0.06, float(err.max())
+    assert err.mean() < 6e-3, float(err.mean())
+
+
+@pytest.mark.parametrize("j,D,H,W", [(0, 2, 2, 4), (1, 3, 4, 5), (2, 4, 8, 8), (3, 8, 8, 16)])
+def test_deconv_bf16(eng, net, j, D, H, W):
+    import torch
+    import torch.nn.functional as F
+
+    up = getattr(net, f"upcat_{4 - j}").upsample.deconv
+    g = torch.Generator().manual_seed(j)
+    x = _bf(torch.randn((2, up.in_channels, D, H, W), generator=g))
+    with torch.no_grad():
+        ref = F.conv_transpose3d(x, _bf(up.weight), up.bias, stride=2)
+    out = eng.debug_layer_bf16(1, j, x.cuda()).cpu()
+    err = (out - ref).abs()
+    scale = float(ref.abs().max())
+    assert err.max() < 8e-3 * max(scale, 1.0), (float(err.max()), scale)
+
+
+def test_forward_bf16_vs_oracle(eng, net, golden_dir):
+    """Whole forward, bf16 vs the torch-fp32 oracle logits.  Stated tolerance: relative RMS error of
+    the logits <= 5e-2 and sign agreement >= 0.97 with SEEDED RANDOM weights (whose logits have
+    std ~0.36 and no margin around 0 - see DESIGN.md 'Precision'); the fp32 path is the IoU>=0.999
+    parity mode."""
+    import os
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "orc_unet.npz"))
+    for xk, lk in (("x32", "logits32"), ("x_odd", "logits_odd")):
+        x = torch.from_numpy(g[xk].astype(np.float32))[None, None].cuda()
+        out = eng.unet_forward(x, "bf16").cpu().numpy()[0, 0]
+        ref = g[lk]
+        rel = float(np.sqrt(np.mean((out - ref) ** 2)) / ref.std())
+        agree = float(((out >= 0) == (ref >= 0)).mean())
+        print(f"{xk}: rel rms {rel:.4f} sign agreement {agree:.4f}")
+        assert rel < 5e-2, rel
+        assert agree > 0.97, agree
+
+
+def test_forward_bf16_batch_independent(eng, golden_dir):
+    import os
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "orc_unet.npz"))
+    x = torch.from_numpy(g["x32"].astype(np.float32))[None, None].cuda()
+    xb = torch.cat([x, x.flip(3), x * 0.25], dim=0).contiguous()
+    a = eng.unet_forward(xb, "bf16")
+    b = eng.unet_forward(x, "bf16")
+    assert torch.equal(a[0], b[0])  # per-sample statistics, deterministic reductions
+
+
+@pytest.mark.parametrize("flip", [None, 2, 3, 4])
+def test_sw_pass_bf16_matches_fp32_engine(eng, golden_dir, flip):
+    """Fused path (stem reads the uint16 volume, final layer blends) vs the fp32 engine pass: same
+    windows, same skips, count map identical; blended logits within the bf16 tolerance."""
+    import os
+    import torch
+
+    vol = np.load(os.path.join(golden_dir, "ref_blend.npz"))["volume"]
+    roi = (32, 32, 16)
+    v = eng.to_device(vol)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(vol.shape, dtype=torch.uint8, device="cuda")
+        st = eng.sw_infer(eng.make_sw_params(vol.shape, roi, 0.5, flip, 0, prec, sw_batch=5), v, acc, cnt)
+        eng.sync()
+        res[prec] = (acc.cpu().numpy(), cnt.cpu().numpy(), st)
+    assert res["fp32"][2] == res["bf16"][2]
+    np.testing.assert_array_equal(res["fp32"][1], res["bf16"][1])
+    a32, a16 = res["fp32"][0], res["bf16"][0]
+    live = a32 > -500
+    np.testing.assert_array_equal(a32[~live] <= -999, a16[~live] <= -999)
+    rel = float(np.sqrt(np.mean((a16 - a32)[live] ** 2)) / a32[live].std())
+    assert rel < 5e-2, rel
+    # repeat=5 equals five passes up to fp32 rounding
+    acc5 = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    eng.sw_infer(eng.make_sw_params(vol.shape, roi, 0.5, flip, 0, "bf16", sw_batch=5, repeat=5), v, acc5)
+    eng.sync()
+    np.testing.assert_allclose(acc5.cpu().numpy(), 5 * a16, rtol=1e-5, atol=1e-3)
