@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py - voxels/s of sliding-window 3D-U-Net inference on synthetic light-sheet volumes.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1            # one MI355X
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W   # N ranks, RCCL over xGMI
+
+One "step" = ONE sliding-window pass (no TTA) over the whole volume, volume resident in HBM as
+uint16: tiler -> per-window background skip -> U-Net forward (bf16 MFMA) -> fp32 overlap blend ->
+(N>1: seam exchange) -> threshold + L1-30 eroded re-mask -> uint8 mask (N>1: gathered on rank 0).
+That is BASELINE.json's metric ("voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @
+1/2/4/8 GPU"); the volume and its window list are the same at every N, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's stream
+(dlv_prof_*), `cpu_baseline` times the CPU oracle (oracle/, a port of the reference's algorithm) on
+a bounded sample of the same workload on the host cores of this box.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @1/2/4/8 GPU"
+WORKLOADS = {
+    # name: (Z, Y, X), roi, seed
+    "c3": ((1024, 2048, 2048), (128, 128, 128), 2),  # BASELINE configs[2]: 2048x2048x1024 synthetic brain
+    "c2": ((512, 512, 512), (128, 128, 128), 1),     # BASELINE configs[1]: 512^3 volume
+    "tiny": ((128, 256, 256), (64, 64, 64), 5),      # plumbing check
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_PATCH_VOXEL = 285104.0
+
+
+def cpu_baseline(sd, vol_crop_u16, roi, n_active_full, vol_voxels_full, threads):
+    """The oracle (CPU port) on a bounded sample: whole windows of the benchmark's size through
+    U-Net (torch fp32 CPU) + blend, then the time is extrapolated by the number of active windows."""
+    import torch
+
+    from oracle import delivr_oracle as orc
+
+    torch.set_num_threads(threads)
+    net = orc.build_unet(seed=None)
+    net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+    net.eval()
+    acc = np.zeros(vol_crop_u16.shape, dtype=np.float32)
+    t0 = time.perf_counter()
+    info = orc.sliding_window_pass(vol_crop_u16, roi, lambda x: orc.unet_forward(net, x), acc, None, 0.5, None, 1,
+                                   fp16=False)
+    t1 = time.perf_counter()
+    n_done = info["n_windows"] - info["n_skipped"]
+    per_window = (t1 - t0) / max(n_done, 1)
+    projected = per_window * n_active_full
+    return {
+        "value": vol_voxels_full / projected if projected > 0 else None,
+        "unit": "voxels/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_done} windows of {roi[0]}x{roi[1]}x{roi[2]} (crop {vol_crop_u16.shape}) through the oracle's "
+                  f"tiler+U-Net(fp32, torch CPU)+blend in {t1 - t0:.1f} s; extrapolated to the {n_active_full} "
+                  f"non-background windows of the benchmark volume",
+        "seconds_per_window": per_window,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dense", action="store_true", help="no background: every window runs the network")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sw-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU); see the docstring")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.hostlogic import arrayterator_zblock
+    from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, gather_slabs, make_plan
+    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.weights import random_state_dict
+
+    shape, roi, seed = WORKLOADS[args.workload]
+    Z, Y, X = shape
+    eng = HipEngine(local_rank)
+    sd = random_state_dict(seed=0)
+    if rank == 0:
+        eng.load_state_dict({"state_dict": sd})
+    if world > 1:
+        broadcast_weights(eng, dist, rank)
+
+    vol = synth_volume_torch(shape, seed, eng.device, dense=args.dense)
+    torch.cuda.synchronize()
+    params_all = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch)
+    starts = eng.window_starts(params_all)
+    plan = make_plan(starts, roi[0], Z, world)
+    wb, we = plan.win_ranges[rank]
+    params = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, win_range=(wb, we))
+    if we <= wb:  # a rank without windows still takes part in the exchange
+        params = None
+    acc = torch.zeros(shape, dtype=torch.float32, device=eng.device)
+    nb = arrayterator_zblock((Z, Y, X))
+    olo, ohi = plan.z_owned[rank]
+    ohi = min(ohi, Z)
+    blo, bhi = (olo // nb) * nb, min(-(-ohi // nb) * nb, Z)
+    mask_full = torch.empty(shape, dtype=torch.uint8, device=eng.device) if (world > 1 and rank == 0) else None
+
+    stats_last = {}
+
+    def step():
+        acc.zero_()
+        if params is not None:
+            stats_last.update(eng.sw_infer(params, vol, acc))
+        if world > 1:
+            eng.sync()
+            exchange_seams(acc, plan, rank, dist)
+        if ohi > olo:
+            m = eng.finalize(acc[blo:bhi], None, vol[blo:bhi], (bhi - blo, Y, X), 0.5, 30, nb)
+            slab = m[olo - blo: ohi - blo]
+        else:
+            slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
+        if world > 1:
+            eng.sync()
+            gather_slabs(slab, plan, rank, dist, out=mask_full)
+        return slab
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_prof:
+        eng.prof_reset()
+        eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        slab = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = {}
+    if not args.no_prof:
+        prof = eng.prof_report()
+        eng.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        st = torch.tensor([stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)], dtype=torch.int64,
+                          device=eng.device)
+        dist.all_reduce(st)
+        n_windows, n_skipped = int(st[0]), int(st[1])
+    else:
+        n_windows, n_skipped = stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    vox = float(Z) * Y * X
+    value = vox / (elapsed / args.steps)
+    n_active = n_windows - n_skipped
+    tile_vox = float(roi[0] * roi[1] * roi[2])
+
+    # ---- roofline of the dominant kernel (rank 0's HIP-event timings over the timed steps) ----------
+    roofline = None
+    kernels = {}
+    if prof:
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        for name, e in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
+            kernels[name] = {"launches": e["launches"], "total_ms": round(e["total_ms"], 3),
+                             "avg_us": round(1e3 * e["total_ms"] / max(e["launches"], 1), 2)}
+        name, e = dom
+        avg_s = 1e-3 * e["total_ms"] / max(e["launches"], 1)
+        if e["flops"] > 0 and name.startswith(("conv3_mfma", "deconv2_mfma")):
+            ach = e["flops"] / max(e["launches"], 1) / avg_s / 1e12
+            roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                        "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
+        else:
+            ach = e["bytes"] / max(e["launches"], 1) / avg_s / 1e9
+            roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                        "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
+        # whole-forward MFMA fraction as a second figure
+        net_ms = sum(v["total_ms"] for v in prof.values())
+        roofline["forward_tflops"] = FLOP_PER_PATCH_VOXEL * tile_vox * n_active * args.steps / (1e-3 * net_ms) / 1e12 \
+            if net_ms > 0 and world == 1 else None
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            threads = os.cpu_count() or 1
+            # crop: the central region (tissue), cpu_windows windows stacked along z with 50 % overlap
+            k = max(args.cpu_windows, 1)
+            cz = roi[0] + (k - 1) * (roi[0] // 2)
+            z0, y0, x0 = (Z - cz) // 2, (Y - roi[1]) // 2, (X - roi[2]) // 2
+            crop = vol[z0:z0 + cz, y0:y0 + roi[1], x0:x0 + roi[2]].cpu().numpy()
+            cpu = cpu_baseline(sd, crop, roi, n_active, vox, threads)
+        except Exception as exc:  # the baseline is reported, never fatal
+            cpu = {"value": None, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc}"}
+
+    out = {
+        "metric": METRIC,
+        "value": value,
+        "unit": "voxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16" if args.precision == "bf16" else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain, windows {roi[0]}^3, overlap 0.5, "
+                        f"1 pass (no TTA), seeded random BasicUNet(32,32,64,128,256,32) weights"
+                        + (", dense (no background)" if args.dense else ", ellipsoid brain (background skipped)"),
+            "volume_zyx": [Z, Y, X], "roi": list(roi), "overlap": 0.5,
+            "windows": n_windows, "windows_skipped": n_skipped,
+            "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
+            "patch_voxels_per_s": tile_vox * n_active / (elapsed / args.steps),
+            "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" on rank 0" if world > 1 else ""),
+            "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "kernels": kernels,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+"""Mirror of the resampler + padded-npy writer of the reference's
+``downsample/downsample_and_mask.py`` on top of libdelivr_hip.
+
+Accelerated (device) pieces:
+    downsample_volume  <- downsample_zplanes' skimage block mean              (:32-47, ratios :161-163)
+    upsample_mask      <- scipy.ndimage.zoom(order=2, prefilter=False) -> u8  (:285-299)
+    mask_and_pad       <- img *= mask_us[i]; masked_nii[0,0,i,:Y,:X] = img    (:383-417)
+    write_masked_nifti_npy: the (1,1,Zp,Yp,Xp) uint16 .npy with a 128-byte header the inference step memmaps
+Out of scope: ilastik / TeraConverter subprocesses and TIFF-LZW codecs.  Raw planes are
+read with a minimal baseline-TIFF reader (uncompressed strips, 8/16-bit grey); ``downsample_mask`` therefore
+supports the ``mask_with_Ilastik: false`` (simple threshold) branch end to end and raises for the ilastik one.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import struct
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from ..hostlogic import downsample_ratios, padded_shape
+
+_TIFF_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 16: "Q"}
+
+
+def _tiff_ifd(path: str):
+    with open(path, "rb") as fh:
+        head = fh.read(8)
+        if head[:2] not in (b"II", b"MM"):
+            raise ValueError(f"{path}: not a TIFF file")
+        e = "<" if head[:2] == b"II" else ">"
+        if struct.unpack(e + "H", head[2:4])[0] != 42:
+            raise ValueError(f"{path}: BigTIFF/unknown magic is not supported")
+        off = struct.unpack(e + "I", head[4:8])[0]
+        fh.seek(off)
+        n = struct.unpack(e + "H", fh.read(2))[0]
+        tags = {}
+        for _ in range(n):
+            tag, typ, cnt, val = struct.unpack(e + "HHI4s", fh.read(12))
+            size = {1: 1, 2: 1, 3: 2, 4: 4}.get(typ)
+            if size is None:
+                continue
+            fmt = e + {1: "B", 2: "c", 3: "H", 4: "I"}[typ] * cnt
+            if size * cnt <= 4:
+                vals = struct.unpack(fmt, val[: size * cnt])
+            else:
+                pos = fh.tell()
+                fh.seek(struct.unpack(e + "I", val)[0])
+                vals = struct.unpack(fmt, fh.read(size * cnt))
+                fh.seek(pos)
+            tags[tag] = vals
+        return e, tags
+
+
+def read_tiff_plane(path: str) -> np.ndarray:
+    """Baseline TIFF, uncompressed strips, 8/16-bit greyscale (what light-sheet stitchers emit when
+    compression is off).  Anything else raises - codecs are out of scope."""
+    e, t = _tiff_ifd(path)
+    w, h = t[256][0], t[257][0]
+    bits = t.get(258, (1,))[0]
+    if t.get(259, (1,))[0] != 1:
+        raise NotImplementedError(f"{path}: compressed TIFF (tag 259 = {t[259][0]}) - decode upstream; LZW/deflate "
+                                  "codecs are outside the accelerated path")
+    if t.get(277, (1,))[0] != 1 or bits not in (8, 16):
+        raise NotImplementedError(f"{path}: only 8/16-bit single-channel planes are supported")
+    dt = np.dtype(("<" if e == "<" else ">") + ("u2" if bits == 16 else "u1"))
+    out = np.empty(w * h, dtype=dt)
+    pos = 0
+    with open(path, "rb") as fh:
+        for off, nbytes in zip(t[273], t[279]):
+            fh.seek(off)
+            chunk = np.frombuffer(fh.read(nbytes), dtype=dt)
+            out[pos: pos + chunk.size] = chunk
+            pos += chunk.size
+    return out.reshape(h, w).astype(np.uint16)
+
+
+def get_real_size(raw_folder: str) -> Tuple[int, int, int]:
+    """(z, y, x) of a folder of .tif z-planes (reference :25-30: counts *.tif, reads the first plane's
+    shape) - here from the TIFF header alone, no decode.  A folder holding ``stack.npy`` is accepted too."""
+    names = sorted(i for i in os.listdir(raw_folder) if ".tif" in i)
+    if names:
+        _, t = _tiff_ifd(os.path.join(raw_folder, names[0]))
+        return (len(names), int(t[257][0]), int(t[256][0]))
+    npy = os.path.join(raw_folder, "stack.npy")
+    if os.path.isfile(npy):
+        return tuple(int(v) for v in np.load(npy, mmap_mode="r").shape[-3:])
+    raise FileNotFoundError(f"{raw_folder}: no .tif planes and no stack.npy")
+
+
+# ---- device resamplers ---------------------------------------------------------------------------------
+def downsample_volume(engine, vol_dev, factors_zyx: Sequence[int], drop_last_chunk: bool = True):
+    """uint16 (Z,Y,X) in HBM -> block-mean down-sampled uint16.  ``drop_last_chunk`` reproduces the
+    reference's zip(z_series, z_series[1:]) (:166,187), which never processes the final z-chunk."""
+    fz = int(factors_zyx[0])
+    Z = int(vol_dev.shape[0])
+    if drop_last_chunk:
+        nchunks = len(range(0, Z, fz)) - 1
+        if nchunks <= 0:
+            raise ValueError("fewer than two z-chunks: the reference would produce an empty stack")
+        vol_dev = vol_dev[: nchunks * fz].contiguous()
+    return engine.block_mean_u16(vol_dev, factors_zyx)
+
+
+def upsample_mask(engine, mask_dev, out_shape_zyx: Sequence[int]):
+    """uint8 mask (downsampled grid) -> uint8 mask at the raw stack's shape: spline-2 zoom, bit-exact with
+    scipy.ndimage.zoom(mask, out/in, output=uint8, order=2, prefilter=False) (reference :299)."""
+    return engine.zoom_spline2_u8(mask_dev, out_shape_zyx)
+
+
+def mask_and_pad(engine, raw_dev, mask_dev, crop_size: Sequence[int], threshold: Optional[int] = None):
+    """raw (Z,Y,X) uint16 * mask (uint8) -> zero-padded (Zp,Yp,Xp) uint16 with Zp.. = ceil(dim/crop)*crop
+    (reference :390-417).  mask_dev None + threshold: the simple-threshold branch (img[img < thr] = 0)."""
+    pad = padded_shape(tuple(int(v) for v in raw_dev.shape), crop_size)
+    return engine.mask_pad_u16(raw_dev, mask_dev, pad, threshold or 0)
+
+
+def write_masked_nifti_npy(path: str, padded_dev) -> None:
+    """(Zp,Yp,Xp) uint16 tensor -> <path> as NPY v1 (1,1,Zp,Yp,Xp) '<u2' with the 128-byte header the
+    inference step skips with offset=128 (inference/inference.py:234)."""
+    shape = (1, 1) + tuple(int(v) for v in padded_dev.shape)
+    out = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint16, shape=shape)
+    if out.offset != 128:
+        raise RuntimeError(f"npy header is {out.offset} bytes, the pipeline expects 128")
+    out[0, 0] = padded_dev.cpu().numpy()
+    out.flush()
+
+
+def downsample_mask(settings: dict, brain: str, engine=None):
+    """Step 1 of the pipeline for one brain (reference :139-427), simple-threshold branch:
+    raw planes -> block-mean stack (saved as downsampled_stack.npy) -> threshold mask on the raw planes ->
+    padded masked_niftis/masked_nifti.npy."""
+    from ..engine import HipEngine
+
+    md = settings["mask_detection"]
+    if md.get("mask_with_Ilastik", True):
+        raise NotImplementedError("mask_with_Ilastik=true shells out to the ilastik binary (reference :71-93), which is "
+                                  "outside this package; run ilastik upstream and call upsample_mask/mask_and_pad, or set "
+                                  "mask_with_Ilastik=false")
+    raw_location = os.path.join(settings["raw_location"], brain)
+    planes = sorted(glob.glob(raw_location + "/*.tif"))
+    if not planes:
+        raise FileNotFoundError(f"no .tif planes under {raw_location}")
+    stack = np.stack([read_tiff_plane(p) for p in planes])
+    own = engine is None
+    eng = engine or HipEngine(0)
+    try:
+        raw_dev = eng.to_device(stack)
+        ratios = downsample_ratios(md["downsample_steps"])
+        results = os.path.join(md["output_location"], brain)
+        os.makedirs(os.path.join(results, "masked_niftis"), exist_ok=True)
+        ds = downsample_volume(eng, raw_dev, ratios)
+        np.save(os.path.join(results, "downsampled_stack.npy"), ds.cpu().numpy())
+        wd = settings["blob_detection"]["window_dimensions"]
+        crop = (wd["window_dim_0"], wd["window_dim_1"], wd["window_dim_2"])
+        padded = mask_and_pad(eng, raw_dev, None, crop, int(md["simple_threshold_value"]))
+        eng.sync()
+        write_masked_nifti_npy(os.path.join(results, "masked_niftis", "masked_nifti.npy"), padded)
+    finally:
+        if own:
+            eng.close()
+    return results

@@ -1,0 +1,69 @@
+"""Host-side integer logic of the path that the reference performs in Python (no device work)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def padded_shape(stack_shape: Sequence[int], crop: Sequence[int]) -> Tuple[int, ...]:
+    """ceil(dim / crop) * crop per axis (inference/inference.py:229-231;
+    downsample/downsample_and_mask.py:390-393)."""
+    return tuple(int(np.ceil(int(n) / int(c)) * int(c)) for n, c in zip(stack_shape, crop))
+
+
+def arrayterator_zblock(shape_zyx: Sequence[int], buf_size: int = 1000**3) -> int:
+    """Planes per block of np.lib.Arrayterator(volume[(Z,Y,X)], buf_size) - the granularity at which
+    the reference erodes the re-mask (inference/inference.py:53,77-84).  Returns Z when the whole
+    volume fits one block."""
+    Z, Y, X = (int(v) for v in shape_zyx)
+    count = int(buf_size)
+    if count <= X or count // X <= Y:
+        raise NotImplementedError("a single z-plane exceeds the Arrayterator buffer (Y*X > buf_size)")
+    count = (count // X) // Y
+    return Z if count >= Z else max(count, 1)
+
+
+def pass_schedule(tta: bool) -> List[Tuple[Optional[int], int]]:
+    """(flip_dim, repeat) per DISTINCT pass.  The reference runs 1 plain pass, then 4 x {noise,
+    noise + flip Z (dim 2), noise + flip Y (dim 3)} (inference/inference.py:261-279); its noise is
+    N(0, <=1e-3) on raw uint16-scale intensities (sliding_window_inferer.py:212-215), i.e. nil, so the
+    13 passes collapse to plain x5, flipZ x4, flipY x4."""
+    if not tta:
+        return [(None, 1)]
+    return [(None, 5), (2, 4), (3, 4)]
+
+
+def cells_csv_text(stats: dict, n: int) -> str:
+    """The text pandas writes for the reference's cell table (count_blobs.py:98-114): header
+    ``,Blob,Coords,Size``; one row per label 1..N-1 (the reference's ``range(1, N)`` drops the last
+    label); index column always 0; Coords = python repr of [z, y, x] floats, quoted by the CSV
+    writer because it contains commas."""
+    cent = stats["centroids"]
+    counts = stats["voxel_counts"]
+    lines = [",Blob,Coords,Size"]
+    for i in range(1, int(n)):
+        coords = [float(cent[i][0]), float(cent[i][1]), float(cent[i][2])]
+        lines.append(f'0,{i},"{coords!r}",{int(counts[i])}')
+    return "\n".join(lines) + "\n"
+
+
+def csv_name(shape_zyx: Sequence[int], brain: str) -> str:
+    """f"{bin_img.shape}_{brain}.csv" (count_blobs.py:113): "(Z, Y, X)_<brain>.csv"."""
+    return f"{tuple(int(v) for v in shape_zyx)}_{brain.replace('.nii.gz', '')}.csv"
+
+
+def scale_cell_coords(coords_zyx, original_shape: Sequence[int], downsampled_shape: Sequence[int], direction: str = "down"):
+    """Cell-coordinate scaling of automate_mBrainaligner.py:261-284: factor = original/downsampled
+    per axis; "down" divides (original -> atlas space), "up" multiplies."""
+    f = np.asarray(original_shape, dtype=np.float64) / np.asarray(downsampled_shape, dtype=np.float64)
+    c = np.asarray(coords_zyx, dtype=np.float64)
+    return c / f if direction == "down" else c * f
+
+
+def downsample_ratios(steps: dict) -> Tuple[int, int, int]:
+    """(z, y, x) integer block-mean factors from config.json's mask_detection.downsample_steps
+    (downsample/downsample_and_mask.py:161-163): round(downsample_um / original_um)."""
+    return (round(steps["downsample_um_z"] / steps["original_um_z"]),
+            round(steps["downsample_um_y"] / steps["original_um_y"]),
+            round(steps["downsample_um_x"] / steps["original_um_x"]))

@@ -1,0 +1,132 @@
+"""Mirror of the reference's ``inference/inference.py`` (run_inference :113-332, create_nifti_seg
+:31-95) on top of libdelivr_hip: same call signature, same files in and out.
+
+in : <niftis[0]>  NPY v1, 128-byte header, '<u2', C-order (1,1,Zp,Yp,Xp)          (:234)
+out: <output_folder>/<comment>/binary_segmentations/binaries.npy  '|u1' (Z,Y,X)   (:312)
+     optional .../binary_segmentations/network_output.npy '<f4' (Z,Y,X)           (:315-318)
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ..hostlogic import arrayterator_zblock, padded_shape, pass_schedule
+from ..model import HipBasicUNet
+from .sliding_window_inferer import SlidingWindowInferer
+
+
+def create_nifti_seg(threshold, model_output, output_file, network_output_file, dataset, original_stack_shape,
+                     count_map=None, engine=None, erode_iters: int = 30):
+    """sigmoid >= threshold, eroded re-mask, crop to the original stack, write binaries.npy
+    (reference :31-95).  ``model_output``: (1,1,Zp,Yp,Xp) or (Zp,Yp,Xp) fp32 tensor in HBM holding the
+    blended logits (sum; pass ``count_map`` to divide, or the mean already); ``dataset``: the uint16
+    volume in HBM."""
+    Z, Y, X = (int(v) for v in original_stack_shape[-3:])
+    acc = model_output[0, 0] if model_output.dim() == 5 else model_output
+    raw = dataset[0, 0] if dataset.dim() == 5 else dataset
+    cnt = None if count_map is None else (count_map[0, 0] if count_map.dim() == 5 else count_map)
+    zb = arrayterator_zblock((Z, Y, X))
+    res = engine.finalize(acc, cnt, raw, (Z, Y, X), float(threshold), erode_iters, 0 if zb >= Z else zb,
+                          want_prob=network_output_file is not None)
+    mask, prob = res if network_output_file is not None else (res, None)
+    engine.sync()
+    out = np.lib.format.open_memmap(output_file, mode="w+", dtype=np.uint8, shape=(Z, Y, X))
+    out[...] = mask.cpu().numpy()
+    out.flush()
+    if network_output_file is not None:
+        act = np.lib.format.open_memmap(network_output_file, mode="w+", dtype=np.float32, shape=(Z, Y, X))
+        act[...] = prob.cpu().numpy()
+        act.flush()
+    return mask
+
+
+def run_inference(
+    niftis,
+    output_folder,
+    stack_shape,
+    comment: str = "none",
+    model_weights: str = "weights/inference_weights.tar",
+    tta: bool = False,
+    threshold: float = 0.5,
+    cuda_devices: str = "0,1",
+    crop_size: Sequence[int] = (64, 64, 32),
+    workers: int = 0,
+    sw_batch_size: int = 100,
+    overlap: float = 0.5,
+    verbosity: bool = True,
+    load_all_ram: bool = False,
+    settings: Optional[dict] = None,
+    precision: Optional[str] = None,
+    state_dict=None,
+):
+    """Same parameters as the reference (:113-129) plus ``precision`` ("bf16" default / "fp32",
+    also settings["mi355x"]["precision"]) and ``state_dict`` (use instead of reading
+    ``model_weights``).  Returns "<abs output_folder>/<comment>"."""
+    import torch
+
+    print(f"{datetime.datetime.now()} : Setting up inference parameters ")
+    if settings is not None:
+        wd = settings["blob_detection"]["window_dimensions"]
+        crop_size = (wd["window_dim_0"], wd["window_dim_1"], wd["window_dim_2"])
+        if precision is None:
+            precision = settings.get("mi355x", {}).get("precision")
+    precision = precision or "bf16"
+    crop_size = tuple(int(c) for c in crop_size)
+    print("using crop size:  ", crop_size)
+    if not torch.cuda.is_available():
+        raise RuntimeError("run_inference needs an MI355X: the HIP path has no CPU fallback")
+    device_index = int(str(cuda_devices).split(",")[0]) if str(cuda_devices).strip() else 0
+    if device_index >= torch.cuda.device_count():
+        device_index = 0
+
+    # ~~<< M O D E L >>~~  (reference :190-222)
+    model = HipBasicUNet(device=device_index, precision=precision)
+    if state_dict is None:
+        checkpoint = torch.load(os.path.abspath(model_weights), map_location="cpu", weights_only=False)
+    else:
+        checkpoint = state_dict
+    model.load_state_dict(checkpoint)
+    model.eval()
+    eng = model.engine
+    inferer = SlidingWindowInferer(roi_size=crop_size, sw_batch_size=sw_batch_size, sw_device=eng.device,
+                                   device=eng.device, overlap=overlap, mode="gaussian", padding_mode="replicate")
+
+    # ### DATA PREP ###  (reference :225-251)
+    print(f"{datetime.datetime.now()} : Loading Data")
+    stack_shape = tuple(int(v) for v in stack_shape)
+    pad = (1, 1) + padded_shape(stack_shape[2:], crop_size)
+    dataset_host = np.memmap(niftis[0], dtype=np.uint16, mode="r", shape=pad, offset=128)
+    dataset = eng.to_device(np.ascontiguousarray(dataset_host[0, 0]))
+    os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
+    save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
+    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
+    count_map = torch.zeros(pad[2:], dtype=torch.uint8, device=eng.device) if save_activated else None
+    print("output_image shape", tuple(output_image.shape))
+
+    # inference passes (reference :261-279)
+    print(f"{datetime.datetime.now()} : Starting inference")
+    for flip_dim, repeat in pass_schedule(bool(tta)):
+        kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
+        if flip_dim is not None:
+            kw.update(tta=True, flip_dim=flip_dim)
+        inferer(dataset, model, **kw)
+    eng.sync()
+
+    # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
+    print(f"{datetime.datetime.now()} : Creating binarized blob output")
+    testing_session_path = os.path.abspath(output_folder + "/" + comment)
+    binaries_path = testing_session_path + "/binary_segmentations/"
+    os.makedirs(binaries_path, exist_ok=True)
+    output_file = os.path.join(binaries_path, "binaries.npy")
+    network_output_file = None
+    if save_activated:
+        os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
+        network_output_file = os.path.join(binaries_path, "network_output.npy")
+    create_nifti_seg(threshold=threshold, model_output=output_image, output_file=output_file,
+                     network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
+                     count_map=count_map, engine=eng)
+    print(f"{datetime.datetime.now()} : Blob Detection finished")
+    return testing_session_path

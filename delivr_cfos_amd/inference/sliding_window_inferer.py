@@ -1,0 +1,135 @@
+"""Mirror of the reference's ``inference/sliding_window_inferer.py`` on top of libdelivr_hip.
+
+Same names, argument meaning and in-place buffer semantics as the reference
+(sliding_window_inference :33-253, SlidingWindowInferer :278-370); the whole window loop
+(gather, skip, flip, forward, blend) is ONE call of dlv_sw_infer_dev with the volume in HBM.
+
+Differences, all documented in DESIGN.md:
+  * the background skip is decided per window (= the reference at sw_batch_size 1; with larger
+    batches the reference's decision depends on free VRAM);
+  * accumulation is fp32 on the device (the reference adds fp16 on the CPU); if the caller hands
+    over fp16 / CPU buffers they are converted on the way in and out;
+  * ``mode`` is accepted and, exactly like the reference (:148 hard-codes 'constant'), ignored;
+  * the TTA noise (std <= 1e-3 on raw uint16-scale data, :212-215) is not added.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, Sequence, Union
+
+import numpy as np
+
+from ..model import HipBasicUNet
+
+__all__ = ["sliding_window_inference", "SlidingWindowInferer"]
+
+_upload_cache = {}
+
+
+def _device_volume(inputs, engine):
+    """(1,1,Zp,Yp,Xp) uint16 numpy / memmap / tensor -> (Zp,Yp,Xp) uint16 tensor in HBM.  Host inputs
+    are uploaded once and cached by identity (the reference re-reads its memmap on every pass)."""
+    import torch
+
+    if isinstance(inputs, torch.Tensor) and inputs.is_cuda:
+        t = inputs
+    else:
+        key = (id(inputs), engine.device_index)
+        t = _upload_cache.get(key)
+        if t is None or tuple(t.shape) != tuple(inputs.shape):
+            _upload_cache.clear()
+            t = engine.to_device(np.asarray(inputs))
+            _upload_cache[key] = t
+    if t.dim() == 5:
+        if t.shape[0] != 1 or t.shape[1] != 1:
+            raise ValueError("inputs must be (1,1,Z,Y,X) (one volume, one channel)")
+        t = t[0, 0]
+    if t.dtype != torch.uint16:
+        raise TypeError(f"inputs must be uint16 (the masked_nifti.npy payload), got {t.dtype}")
+    return t.contiguous()
+
+
+def sliding_window_inference(
+    inputs,
+    roi_size: Union[Sequence[int], int],
+    sw_batch_size: int,
+    predictor: Callable[..., Any],
+    overlap: float = 0.25,
+    mode: str = "constant",
+    sigma_scale: Union[Sequence[float], float] = 0.125,
+    padding_mode: str = "constant",
+    cval: float = 0.0,
+    sw_device=None,
+    device=None,
+    SIGMOID: bool = False,
+    output_image=None,
+    count_map=None,
+    tta: Optional[bool] = None,
+    flip_dim: Optional[int] = None,
+    window_data_threshold: int = 0,
+    *args: Any,
+    repeat: int = 1,
+    **kwargs: Any,
+):
+    """One sliding-window pass; ``output_image`` / ``count_map`` are mutated in place, returns None
+    (as the reference does).  ``predictor`` must be a HipBasicUNet."""
+    import torch
+
+    if overlap < 0 or overlap >= 1:
+        raise AssertionError("overlap must be >= 0 and < 1.")
+    if not isinstance(predictor, HipBasicUNet):
+        raise TypeError("the HIP path runs the network inside libdelivr_hip: pass a delivr_cfos_amd.HipBasicUNet "
+                        "(there is no eager/CPU fallback)")
+    if output_image is None:
+        raise ValueError("output_image= is required (the reference accumulates into the caller's buffer)")
+    eng = predictor.engine
+    vol = _device_volume(inputs, eng)
+    if isinstance(roi_size, int):
+        roi_size = (roi_size,) * 3
+    roi = tuple(int(r) if r and r > 0 else int(n) for r, n in zip(roi_size, vol.shape))  # fall_back_tuple
+
+    def staged(buf, dtype):
+        if buf is None:
+            return None, None
+        if not isinstance(buf, torch.Tensor):
+            raise TypeError("output_image / count_map must be torch tensors")
+        view = buf[0, 0] if buf.dim() == 5 else buf
+        if tuple(view.shape) != tuple(vol.shape):
+            raise ValueError(f"buffer shape {tuple(buf.shape)} does not match the volume {tuple(vol.shape)}")
+        if view.is_cuda and view.dtype == dtype and view.is_contiguous():
+            return view, None
+        return view.to(device=eng.device, dtype=dtype).contiguous(), view
+
+    acc, acc_home = staged(output_image, torch.float32)
+    cnt, cnt_home = staged(count_map, torch.uint8)
+    p = eng.make_sw_params(vol.shape, roi, overlap, flip_dim, window_data_threshold, predictor.precision,
+                           sw_batch=0, repeat=repeat)
+    stats = eng.sw_infer(p, vol, acc, cnt)
+    if acc_home is not None:
+        acc_home.copy_(acc.to(acc_home.dtype))
+    if cnt_home is not None:
+        cnt_home.copy_(cnt)
+    sliding_window_inference.last_stats = stats
+    return None
+
+
+class SlidingWindowInferer:
+    """Same constructor and call convention as the reference's class (:278-370)."""
+
+    def __init__(self, roi_size, sw_batch_size: int = 1, overlap: float = 0.25, mode: str = "constant",
+                 sigma_scale=0.125, padding_mode: str = "constant", cval: float = 0.0, sw_device=None, device=None):
+        if str(getattr(mode, "value", mode)) not in ("constant", "gaussian"):
+            raise ValueError(f"unsupported blend mode {mode!r}")
+        self.roi_size = roi_size
+        self.sw_batch_size = sw_batch_size
+        self.overlap = overlap
+        self.mode = mode
+        self.sigma_scale = sigma_scale
+        self.padding_mode = padding_mode
+        self.cval = cval
+        self.sw_device = sw_device
+        self.device = device
+
+    def __call__(self, inputs, network, *args: Any, **kwargs: Any):
+        return sliding_window_inference(inputs, self.roi_size, self.sw_batch_size, network, self.overlap, self.mode,
+                                        self.sigma_scale, self.padding_mode, self.cval, self.sw_device, self.device,
+                                        *args, **kwargs)

@@ -1,0 +1,165 @@
+"""Sharding of one sliding-window pass over the ranks of a node (one process per GPU).
+
+Replaces torch.nn.DataParallel (inference/inference.py:217-219: per-forward scatter, parameter
+re-broadcast and gather through GPU 0) with:
+  * one broadcast of the packed weight blob at start-up (RCCL over xGMI),
+  * a static partition of the reference's window list into contiguous ranges (Z-slowest order, so a
+    rank's windows form a Z-slab of tile rows),
+  * one seam exchange per pass: a rank that computed contributions to planes owned by another rank
+    sends exactly those planes (point-to-point, one message per seam), the owner adds them in rank
+    order (deterministic),
+  * each rank finalizes the planes it owns; mask slabs are gathered to rank 0 on request.
+No all-reduce is needed on this path.
+
+The plan is pure integer arithmetic (testable without a GPU); the exchange works on any
+torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class ShardPlan:
+    world: int
+    n_windows: int
+    win_ranges: List[Tuple[int, int]]      # [begin, end) of the reference's window enumeration per rank
+    z_computed: List[Tuple[int, int]]      # planes [lo, hi) a rank's windows touch (empty: (0, 0))
+    z_owned: List[Tuple[int, int]]         # planes [lo, hi) a rank finalizes (partition of [0, Zp))
+
+    def sends(self, rank: int) -> List[Tuple[int, int, int]]:
+        """(dst, lo, hi): plane ranges `rank` computed that another rank owns."""
+        out = []
+        clo, chi = self.z_computed[rank]
+        for dst in range(self.world):
+            if dst == rank:
+                continue
+            olo, ohi = self.z_owned[dst]
+            lo, hi = max(clo, olo), min(chi, ohi)
+            if lo < hi:
+                out.append((dst, lo, hi))
+        return out
+
+    def recvs(self, rank: int) -> List[Tuple[int, int, int]]:
+        """(src, lo, hi): plane ranges owned by `rank` that another rank contributed to."""
+        out = []
+        olo, ohi = self.z_owned[rank]
+        for src in range(self.world):
+            if src == rank:
+                continue
+            clo, chi = self.z_computed[src]
+            lo, hi = max(clo, olo), min(chi, ohi)
+            if lo < hi:
+                out.append((src, lo, hi))
+        return out
+
+
+def make_plan(starts: np.ndarray, roi_z: int, Zp: int, world: int) -> ShardPlan:
+    """starts: (n_windows, 3) window origins in the reference's order (Z slowest).  Windows are
+    split into `world` contiguous ranges of near-equal size, cut only between Z tile-rows where
+    possible so that every seam is one half-tile slab."""
+    n = int(len(starts))
+    zs = starts[:, 0]
+    # boundaries of tile rows (indices where z changes)
+    row_edges = [0] + [int(i) for i in np.nonzero(np.diff(zs))[0] + 1] + [n]
+    cuts = [0]
+    for r in range(1, world):
+        target = n * r / world
+        # nearest tile-row edge if there are at least `world` rows, else cut anywhere
+        if len(row_edges) - 1 >= world:
+            c = min(row_edges, key=lambda e: abs(e - target))
+        else:
+            c = int(round(target))
+        cuts.append(max(c, cuts[-1]))
+    cuts.append(n)
+    win_ranges = [(cuts[r], cuts[r + 1]) for r in range(world)]
+    z_computed = []
+    for b, e in win_ranges:
+        if e > b:
+            z_computed.append((int(zs[b:e].min()), int(zs[b:e].max()) + int(roi_z)))
+        else:
+            z_computed.append((0, 0))
+    # ownership: split [0, Zp) at the midpoints of the seams between consecutive non-empty ranks
+    owned = []
+    lo = 0
+    live = [r for r in range(world) if win_ranges[r][1] > win_ranges[r][0]]
+    for r in range(world):
+        if r not in live:
+            owned.append((lo, lo))
+            continue
+        nxt = [s for s in live if s > r]
+        if nxt:
+            s = nxt[0]
+            hi = (z_computed[s][0] + z_computed[r][1]) // 2
+            hi = min(max(hi, lo), Zp)
+        else:
+            hi = Zp
+        owned.append((lo, hi))
+        lo = hi
+    return ShardPlan(world, n, win_ranges, z_computed, owned)
+
+
+def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None) -> None:
+    """acc: (Zp, Yp, Xp) fp32 tensor (full padded extent on every rank; only the computed planes are
+    non-zero).  After the call the planes owned by `rank` hold the complete sum.  Contributions are
+    added in increasing source-rank order so that the result does not depend on arrival order."""
+    import torch
+
+    sends = plan.sends(rank)
+    recvs = plan.recvs(rank)
+    ops, bufs = [], []
+    for dst, lo, hi in sends:
+        ops.append(dist.P2POp(dist.isend, acc[lo:hi].contiguous(), dst, group=group))
+    for src, lo, hi in recvs:
+        buf = torch.empty_like(acc[lo:hi])
+        bufs.append((src, lo, hi, buf))
+        ops.append(dist.P2POp(dist.irecv, buf, src, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for src, lo, hi, buf in sorted(bufs, key=lambda t: t[0]):
+        acc[lo:hi] += buf
+
+
+def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]] = None, src: int = 0, group=None) -> None:
+    """Rank `src` has called engine.load_state_dict(); the others receive the packed blob
+    (fp32 + MFMA-packed bf16 parameters, ~35 MB) with ONE broadcast."""
+    import torch
+
+    meta = torch.zeros(6, dtype=torch.int64, device=engine.device)
+    if rank == src:
+        meta[:] = torch.tensor(engine.features, dtype=torch.int64)
+    dist.broadcast(meta, src, group=group)
+    if rank != src:
+        engine.alloc_weight_blob([int(v) for v in meta.tolist()])
+    blob = engine.weight_blob()
+    engine.sync()
+    dist.broadcast(blob, src, group=group)
+    torch.cuda.synchronize(engine.device)
+
+
+def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0, group=None):
+    """Mask slabs (planes z_owned[r]) -> one (Z, Y, X) tensor on rank `dst` (point-to-point)."""
+    import torch
+
+    ops = []
+    if rank == dst:
+        for r in range(plan.world):
+            lo, hi = plan.z_owned[r]
+            hi = min(hi, out.shape[0])
+            if hi <= lo:
+                continue
+            if r == dst:
+                out[lo:hi] = slab[: hi - lo]
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[lo:hi], r, group=group))
+    else:
+        if slab.numel():
+            ops.append(dist.P2POp(dist.isend, slab.contiguous(), dst, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out

@@ -144,7 +144,7 @@ def test_sw_pass_bf16_matches_fp32_engine(eng, golden_dir, flip):
     np.testing.assert_array_equal(res["fp32"][1], res["bf16"][1])
     a32, a16 = res["fp32"][0], res["bf16"][0]
     live = a32 > -500
-    np.testing.assert_array_equal(a32[~live] <= -999, a16[~live] <= -999)
+    assert np.abs(a32[~live] - a16[~live]).max() < 0.5  # skipped windows add exactly -1000 in both
     rel = float(np.sqrt(np.mean((a16 - a32)[live] ** 2)) / a32[live].std())
     assert rel < 5e-2, rel
     # repeat=5 equals five passes up to fp32 rounding
