@@ -1,5 +1,7 @@
 // api.hip - context, memory helpers, weight loading and the in-library kernel timer of
 // libdelivr_hip.so (C ABI declared in include/delivr_hip.h).
+#include <cstdlib>
+
 #include "common.h"
 
 int dlv_fail(dlv_ctx* ctx, int code, const char* fmt, ...) {
@@ -198,6 +200,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     dlv_ctx* ctx = new (std::nothrow) dlv_ctx();
     if (!ctx) return DLV_ENOMEM;
     ctx->device = device_id;
+    ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return DLV_EHIP;

@@ -71,6 +71,7 @@ struct dlv_ctx {
     void* ws[WS_N_SLOTS] = {nullptr};
     size_t ws_bytes[WS_N_SLOTS] = {0};
     // timing
+    bool no_zmarch = false;  // test switch: force the generic conv kernel
     bool prof_on = false;
     std::vector<DlvProfSlot> prof_slots;
     std::vector<DlvProfPending> prof_pending;
@@ -121,4 +122,7 @@ int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, in
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
                         int h, int w, int flip_dim, float scale, float* acc);
 int dlv_pack_weights_bf16(dlv_ctx* ctx);
+// z-marching conv for Cout = 32, Cin in {32, 64} (conv_zmarch.hip)
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
+                            const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts);
 size_t dlv_bf16_pack_bytes(const int features[6]);

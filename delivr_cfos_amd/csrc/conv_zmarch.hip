@@ -1,0 +1,265 @@
+// conv_zmarch.hip - the hot 3x3x3 convolutions of the U-Net (Cout = 32, Cin = 32 or 32+32 at levels
+// 0 and 1: 91 % of the network's FLOPs) as a z-marching, input-stationary implicit GEMM on
+// v_mfma_f32_32x32x16_bf16.
+//
+// One workgroup owns an (8 rows x 32 columns) in-plane tile of one sample and marches along z
+// ("z-major slabs"): for every input plane p it
+//     - has the halo plane (10 x 34 voxels x Cin channels) in LDS, staged through registers from the
+//       coalesced chunk-planar tensor while the previous plane is being computed (issue-early /
+//       write-late),
+//     - multiplies it with ALL 27 taps: the kz = 0/1/2 slices of the weights feed three rotating
+//       accumulators (output planes p+1, p, p-1), so each input fragment read from LDS is used by
+//       three MFMAs and only ONE plane has to be resident,
+//     - emits output plane p-1 (bias, bf16 store, InstanceNorm partial sums kept per lane and
+//       reduced once per column).
+// The complete weight set (27 x Cin x 32 bf16 = 54 / 108 KiB) is LDS-resident in MFMA A-fragment
+// order.  LDS reads per MFMA: 0.83 x ds_read_b128 (weights shared by the wave's two voxel blocks).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned zm_pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+constexpr int ZM_TY = 8, ZM_TX = 32, ZM_HY = 10, ZM_HX = 34;
+constexpr int ZM_PLANE = ZM_HY * ZM_HX;  // 340 voxels
+
+template <int CIN>
+struct ZmCfg {
+    static constexpr int C8 = CIN / 8;           // chunks
+    static constexpr int KP = CIN / 16;          // k-steps per tap
+    static constexpr int WELEMS = 27 * KP * 64;  // uint4 elements of weights in LDS
+    static constexpr int PELEMS = C8 * ZM_PLANE; // uint4 elements of one halo plane
+    static constexpr int NPRE = (PELEMS + 255) / 256;
+    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
+                                                           const uint4* __restrict__ in2, int c2_8,
+                                                           const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                           uint4* __restrict__ out, float* __restrict__ partials, int D,
+                                                           int H, int W, int tilesY, int tilesX, int zseg) {
+    using C = ZmCfg<CIN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* lds_w = reinterpret_cast<uint4*>(smem_raw);
+    uint4* lds_p = lds_w + C::WELEMS;
+
+    const int n = blockIdx.z;
+    const int seg = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int y0 = ty * ZM_TY, x0 = tx * ZM_TX;
+    const int zs = seg * zseg, ze = min(zs + zseg, D);  // output planes [zs, ze)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long plane = (long long)H * W;
+    const long long vox = (long long)D * plane;
+
+    // ---- weights -> LDS (A-fragment order, lane-linear) ------------------------------------------------
+    for (int i = threadIdx.x; i < C::WELEMS; i += 256) lds_w[i] = wpk[i];
+
+    // ---- per-thread staging map of the halo plane (constant along z) ----------------------------------
+    long long goff[C::NPRE];
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < C::NPRE; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        goff[j] = -1;
+        if (i < C::PELEMS) {
+            const int xh = i % ZM_HX, yh = (i / ZM_HX) % ZM_HY, c = i / ZM_PLANE;
+            const int gy = y0 + yh - 1, gx = x0 + xh - 1;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                const long long base = c < c1_8 ? ((long long)n * c1_8 + c) * vox : ((long long)n * c2_8 + (c - c1_8)) * vox;
+                goff[j] = base + (long long)gy * W + gx;
+                valid |= 1u << j;
+            }
+        }
+    }
+    auto src_of = [&](int j) -> const uint4* {
+        const int c = (threadIdx.x + 256 * j) / ZM_PLANE;
+        return c < c1_8 ? in1 : in2;
+    };
+    uint4 pre[C::NPRE];
+    auto issue_loads = [&](int p) {
+#pragma unroll
+        for (int j = 0; j < C::NPRE; ++j) {
+            pre[j] = make_uint4(0, 0, 0, 0);
+            if (valid & (1u << j)) pre[j] = src_of(j)[goff[j] + (long long)p * plane];
+        }
+    };
+    auto write_plane = [&]() {
+#pragma unroll
+        for (int j = 0; j < C::NPRE; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < C::PELEMS) lds_p[i] = pre[j];
+        }
+    };
+
+    // per-lane LDS offsets: voxel block v = row 2*wave + v, column col; chunk half h
+    int lb[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) lb[v] = (h * ZM_HY + (2 * wave + v)) * ZM_HX + col;
+
+    f32x16 a0[2], a1[2], a2[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[v][r] = a1[v][r] = a2[v][r] = 0.f;
+    float bs[16], ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+        ssum[r] = ssq[r] = 0.f;
+    }
+
+    // one z step: plane p is in LDS (when 0 <= p < D).  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]),
+    // kz=0 -> accC (out[p+1]).  Then out[p-1] is emitted from accA, which is cleared for reuse.
+    auto step = [&](int p, f32x16(&accA)[2], f32x16(&accB)[2], f32x16(&accC)[2]) __attribute__((always_inline)) {
+        const bool next_needed = (p + 1 <= ze) && (p + 1 >= 0) && (p + 1 < D);
+        if (next_needed) issue_loads(p + 1);
+        if (p >= 0 && p < D) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < C::KP; ++ks) {
+                        bf16x8 b[2];
+#pragma unroll
+                        for (int v = 0; v < 2; ++v)
+                            b[v] = __builtin_bit_cast(bf16x8, lds_p[lb[v] + (ks * 2 * ZM_HY + ky) * ZM_HX + kx]);
+                        const bf16x8 w0 = __builtin_bit_cast(bf16x8, lds_w[(((0 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
+                        const bf16x8 w1 = __builtin_bit_cast(bf16x8, lds_w[(((1 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
+                        const bf16x8 w2 = __builtin_bit_cast(bf16x8, lds_w[(((2 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            accC[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[v], accC[v], 0, 0, 0);
+                            accB[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[v], accB[v], 0, 0, 0);
+                            accA[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[v], accA[v], 0, 0, 0);
+                        }
+                    }
+        }
+        const int oz = p - 1;
+        if (oz >= zs && oz < ze) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int oy = y0 + 2 * wave + v, ox = x0 + col;
+                const bool ok = oy < H && ox < W;
+                float val[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    val[r] = accA[v][r] + bs[r];
+                    if (ok) {
+                        ssum[r] += val[r];
+                        ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                    }
+                }
+                if (ok) {
+                    const long long o = (long long)oz * plane + (long long)oy * W + ox;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 u;
+                        u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
+                        u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+                        uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                        dst[h] = u;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[v][r] = 0.f;
+        __syncthreads();  // every wave is done reading plane p
+        if (next_needed) write_plane();
+        __syncthreads();
+    };
+
+    // prologue: first input plane of the segment (zs-1, or zs when zs == 0)
+    {
+        const int p0 = zs - 1;
+        if (p0 >= 0) {
+            issue_loads(p0);
+            write_plane();
+        }
+        __syncthreads();
+    }
+    for (int p = zs - 1; p <= ze; p += 3) {
+        step(p, a0, a1, a2);
+        if (p + 1 <= ze) step(p + 1, a1, a2, a0);
+        if (p + 2 <= ze) step(p + 2, a2, a0, a1);
+    }
+
+    // ---- InstanceNorm partial sums of this column -> partials[n][column][32][2] ----------------------
+    float* red = reinterpret_cast<float*>(lds_p);  // [4 waves][32][2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = ssum[r], b = ssq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (col == 0) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[(wave * 32 + co) * 2] = a;
+            red[(wave * 32 + co) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        const float v = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
+        const long long ncols = (long long)gridDim.x * gridDim.y;
+        const long long colid = (long long)seg * gridDim.x + tile;
+        partials[(((long long)n * ncols + colid) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
+    }
+}
+
+}  // namespace
+
+// returns the number of partial-sum rows per sample (columns) or a negative error
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
+                            const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts) {
+    const int tilesY = dlv_cdiv(H, ZM_TY), tilesX = dlv_cdiv(W, ZM_TX);
+    // split long columns so that small batches still fill 256 CUs
+    int zseg = D;
+    while ((long long)B * tilesY * tilesX * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = (zseg + 1) / 2;
+    const int nseg = dlv_cdiv(D, zseg);
+    dim3 grid(tilesY * tilesX, nseg, B);
+    *nparts = tilesY * tilesX * nseg;
+    if (cin == 32) {
+        static bool attr32 = false;
+        if (!attr32) {
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)ZmCfg<32>::LDS_BYTES));
+            attr32 = true;
+        }
+        hipLaunchKernelGGL(conv3_zmarch_kernel<32>, grid, dim3(256), ZmCfg<32>::LDS_BYTES, ctx->stream, (const uint4*)in1,
+                           c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W,
+                           tilesY, tilesX, zseg);
+    } else if (cin == 64) {
+        static bool attr64 = false;
+        if (!attr64) {
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)ZmCfg<64>::LDS_BYTES));
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(conv3_zmarch_kernel<64>, grid, dim3(256), ZmCfg<64>::LDS_BYTES, ctx->stream, (const uint4*)in1,
+                           c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W,
+                           tilesY, tilesX, zseg);
+    } else {
+        return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
+    }
+    DLV_LAUNCH_CHECK(ctx, "conv3_zmarch_kernel");
+    return DLV_OK;
+}

@@ -603,6 +603,16 @@ struct Bf16Net {
         const DlvConvLayer& L = ctx->conv[li];
         if (c1 + c2 != L.cin) return dlv_fail(ctx, DLV_ESTATE, "conv %d: %d+%d input channels, expected %d", li, c1, c2, L.cin);
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
+        if (L.cout == 32 && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
+            char zname[48];
+            snprintf(zname, sizeof(zname), "conv3_zmarch_bf16_c%dx32", L.cin);
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * 32 * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + 32));
+            int np = 0;
+            DLV_TRY(dlv_conv3_zmarch_launch(ctx, L.cin, in1, c1, in2, c2, L.w_bf16, L.bias, out, partials, B, d.D, d.H, d.W, &np));
+            zp.end();
+            if ((size_t)B * np * 64 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
+            return stats(np, li, d);
+        }
         const bool tx16 = d.W >= 16;
         const int TX = tx16 ? 16 : 8, TY = 64 / TX;
         const int tZ = dlv_cdiv(d.D, 4), tY = dlv_cdiv(d.H, TY), tX = dlv_cdiv(d.W, TX);

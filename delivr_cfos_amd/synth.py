@@ -45,8 +45,6 @@ def synth_volume_torch(shape: Sequence[int], seed: int, device, dense: bool = Fa
     z-chunk so that the fp32 temporaries stay ~1 GB.  Returns a uint16 torch tensor (Z,Y,X) on
     ``device`` (torch is the memory container here, not the product)."""
     import torch
-    import torch.nn.functional as F
-
     Z, Y, X = shape
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty((Z, Y, X), dtype=torch.uint16, device=device)
@@ -59,11 +57,21 @@ def synth_volume_torch(shape: Sequence[int], seed: int, device, dense: bool = Fa
         t = torch.randn((n, Y, X), generator=g, device=device).mul_(600.0).add_(2500.0).clamp_(200.0, 20000.0)
         imp = (torch.rand((n, Y, X), generator=g, device=device) < CELL_DENSITY).float()
         imp.mul_(torch.rand((n, Y, X), generator=g, device=device).mul_(27000.0).add_(3000.0))
-        c = imp[None, None]
-        c = F.conv3d(c, k1.view(1, 1, 5, 1, 1), padding=(2, 0, 0))
-        c = F.conv3d(c, k1.view(1, 1, 1, 5, 1), padding=(0, 2, 0))
-        c = F.conv3d(c, k1.view(1, 1, 1, 1, 5), padding=(0, 0, 2))
-        t.add_(c[0, 0]).clamp_(0.0, 65535.0)
+        c = imp
+        for ax in range(3):  # separable 5-tap blur as shifted adds (no library convolution)
+            acc = torch.zeros_like(c)
+            for k in range(-2, 3):
+                wgt = float(k1[k + 2])
+                n_ax = c.shape[ax]
+                if abs(k) >= n_ax:
+                    continue
+                dst = [slice(None)] * 3
+                src = [slice(None)] * 3
+                dst[ax] = slice(max(0, -k), n_ax - max(0, k))
+                src[ax] = slice(max(0, k), n_ax - max(0, -k))
+                acc[tuple(dst)].add_(c[tuple(src)], alpha=wgt)
+            c = acc
+        t.add_(c).clamp_(0.0, 65535.0)
         if not dense:
             zz = ((torch.arange(z0, z1, device=device) - (Z - 1) / 2) / (0.45 * Z)) ** 2
             inside = (zz[:, None, None] + yy[None, :, None] + xx[None, None, :]) <= 1.0

@@ -49,6 +49,11 @@ CONV_CASES = [
     (9, 256, 0, 4, 4, 8),      # 256 -> 256 (NCB 4), TX 8
     (10, 128, 128, 2, 6, 12),  # concat 128+128 -> 128, odd sizes
     (12, 64, 64, 4, 8, 16),
+    # W >= 32 and Cout = 32: the z-marching kernel (ragged tiles, z segments, concat)
+    (1, 32, 0, 6, 12, 40),
+    (17, 32, 0, 40, 16, 64),
+    (16, 32, 32, 9, 8, 32),
+    (14, 32, 32, 24, 20, 72),
 ]
 
 
