@@ -206,7 +206,7 @@ def main():
                              "avg_us": round(1e3 * e["total_ms"] / max(e["launches"], 1), 2)}
         name, e = dom
         avg_s = 1e-3 * e["total_ms"] / max(e["launches"], 1)
-        if e["flops"] > 0 and name.startswith(("conv3_mfma", "deconv2_mfma")):
+        if e["flops"] > 0 and name.startswith(("conv3_", "deconv2_mfma")):
             ach = e["flops"] / max(e["launches"], 1) / avg_s / 1e12
             roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,

@@ -278,8 +278,9 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
 
     int sw_batch = p->sw_batch;
     if (sw_batch <= 0) {
-        // default: ~2^24 patch voxels per forward (8 windows of 128^3, 64 of 64^3, ...), capped
-        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 24) / tile_vox, 1), 64);
+        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 64 of 96x96x64, ...), capped:
+        // ~10 GB of bf16 activations, and enough tiles at the deep levels to fill 256 CUs
+        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 64);
     }
     int64_t launches = 0;
     const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);

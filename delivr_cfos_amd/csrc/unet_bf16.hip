@@ -617,7 +617,10 @@ struct Bf16Net {
         const int TX = tx16 ? 16 : 8, TY = 64 / TX;
         const int tZ = dlv_cdiv(d.D, 4), tY = dlv_cdiv(d.H, TY), tX = dlv_cdiv(d.W, TX);
         const int ntiles = tZ * tY * tX;
-        const int ncb = L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1);
+        // cout blocks per workgroup: as many as keeps >= 2 workgroups per CU in flight (the deep levels
+        // have few voxel tiles; there the grid is widened over output channels instead)
+        int ncb = L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1);
+        while (ncb > 1 && (long long)B * ntiles * (L.cout / (32 * ncb)) < 512) ncb >>= 1;
         if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
         const size_t lds = std::max<size_t>((size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16,
                                             (size_t)4 * ncb * 32 * 2 * 4);

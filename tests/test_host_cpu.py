@@ -1,0 +1,181 @@
+"""Host-side logic of the package on the CPU: integer rules, file formats, the shard plan and the
+world_size-2 seam exchange over gloo.  The compute engine is replaced by the oracle here (tests may);
+the product path itself never runs without the HIP library + a GPU."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from delivr_cfos_amd import hostlogic
+from delivr_cfos_amd.parallel import make_plan
+from oracle import delivr_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arrayterator_zblock_matches_numpy():
+    for shape, buf in (((40, 70, 66), 12 * 70 * 66), ((10, 7, 5), 1000**3), ((9, 4, 5), 41), ((64, 8, 8), 64 * 5 + 3)):
+        blocks = [b.shape[0] for b in np.lib.Arrayterator(np.zeros(shape, np.uint8), buf)]
+        zb = hostlogic.arrayterator_zblock(shape, buf)
+        assert blocks[0] == min(zb, shape[0]), (shape, buf, blocks, zb)
+    assert hostlogic.arrayterator_zblock((1024, 2048, 2048)) == 238
+    with pytest.raises(NotImplementedError):
+        hostlogic.arrayterator_zblock((4, 40000, 40000))
+
+
+def test_pass_schedule_collapses_the_13_reference_passes():
+    ref = orc.pass_schedule(True)
+    assert len(ref) == 13
+    mine = hostlogic.pass_schedule(True)
+    assert sum(r for _, r in mine) == 13
+    for flip, rep in mine:
+        assert ref.count(flip) == rep
+    assert hostlogic.pass_schedule(False) == [(None, 1)]
+
+
+def test_padded_shape_and_ratios():
+    assert hostlogic.padded_shape((100, 70, 50), (32, 32, 16)) == (128, 96, 64) == orc.padded_shape((100, 70, 50), (32, 32, 16))
+    steps = {"original_um_x": 1.62, "original_um_y": 1.62, "original_um_z": 6.0, "downsample_um_x": 25.0,
+             "downsample_um_y": 25.0, "downsample_um_z": 25.0}
+    assert hostlogic.downsample_ratios(steps) == (4, 15, 15)
+    c = hostlogic.scale_cell_coords([[10.0, 30.0, 45.0]], (1024, 2048, 2048), (256, 137, 137), "down")
+    np.testing.assert_allclose(c, orc.scale_coords([[10.0, 30.0, 45.0]], (1024, 2048, 2048), (256, 137, 137)))
+    np.testing.assert_allclose(hostlogic.scale_cell_coords(c, (1024, 2048, 2048), (256, 137, 137), "up"), [[10.0, 30.0, 45.0]])
+
+
+def test_csv_text_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_csv.npz"))
+    c = np.load(os.path.join(golden_dir, "orc_ccl.npz"))
+    stats = {"voxel_counts": c["gt0_counts"], "centroids": c["gt0_centroids"]}
+    assert hostlogic.cells_csv_text(stats, int(c["gt0_n"])) == str(g["csv_text"])
+    assert hostlogic.csv_name(tuple(c["gt0_shape"]), "brainA.nii.gz") == str(g["csv_name"])
+
+
+def test_random_state_dict_fits_the_architecture():
+    from delivr_cfos_amd.weights import random_state_dict
+
+    net = orc.build_unet(seed=None)
+    sd = {k.replace("module.", ""): v for k, v in random_state_dict(3).items()}
+    net.load_state_dict(sd, strict=True)
+    assert sum(v.numel() for v in sd.values()) == orc.N_PARAMS
+
+
+def test_shard_plan_is_a_partition():
+    for shape, roi, world in (((1024, 2048, 2048), (128, 128, 128), 8), ((512, 512, 512), (128, 128, 128), 4),
+                              ((64, 64, 32), (32, 32, 16), 2), ((128, 64, 64), (64, 64, 64), 3), ((64, 64, 64), (64, 64, 64), 2)):
+        starts = orc.window_list(shape, roi, 0.5)
+        plan = make_plan(starts, roi[0], shape[0], world)
+        assert plan.win_ranges[0][0] == 0 and plan.win_ranges[-1][1] == len(starts)
+        assert all(plan.win_ranges[r][1] == plan.win_ranges[r + 1][0] for r in range(world - 1))
+        assert plan.z_owned[0][0] == 0 and plan.z_owned[-1][1] == shape[0]
+        assert all(plan.z_owned[r][1] == plan.z_owned[r + 1][0] for r in range(world - 1))
+        # every plane a rank computed is either owned by it or sent to exactly one owner
+        for r in range(world):
+            lo, hi = plan.z_computed[r]
+            covered = np.zeros(shape[0], dtype=int)
+            olo, ohi = plan.z_owned[r]
+            covered[max(lo, olo):min(hi, ohi)] += 1
+            for dst, a, b in plan.sends(r):
+                covered[a:b] += 1
+                assert (r, a, b) in plan.recvs(dst)
+            assert np.all(covered[lo:hi] == 1)
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from delivr_cfos_amd.parallel import exchange_seams, gather_slabs, make_plan
+    from oracle import delivr_oracle as orc2
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    vol = rng.integers(1, 4000, size=(96, 32, 32)).astype(np.uint16)
+    vol[:, :, 20:] = 0
+    roi = (32, 32, 16)
+    starts = orc2.window_list(vol.shape, roi, 0.5)
+    plan = make_plan(starts, roi[0], vol.shape[0], world)
+    det = lambda x: (x - 2000.0) / 1000.0  # noqa: E731
+    acc = np.zeros(vol.shape, dtype=np.float32)
+    wb, we = plan.win_ranges[rank]
+    for z, y, x in starts[wb:we]:
+        win = vol[z:z + 32, y:y + 32, x:x + 16].astype(np.float32)
+        acc[z:z + 32, y:y + 32, x:x + 16] += det(win) if win.max() > 0 else -1000.0
+    t = torch.from_numpy(acc)
+    exchange_seams(t, plan, rank, dist)
+    lo, hi = plan.z_owned[rank]
+    slab = (t[lo:hi] >= 0).to(torch.uint8)
+    out = torch.zeros(vol.shape, dtype=torch.uint8) if rank == 0 else None
+    gather_slabs(slab, plan, rank, dist, out=out)
+    if rank == 0:
+        np.save(os.path.join(tmp, "mask.npy"), out.numpy())
+        np.save(os.path.join(tmp, "acc0.npy"), t[lo:hi].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pass_equals_single_rank_over_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_gloo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    vol = rng.integers(1, 4000, size=(96, 32, 32)).astype(np.uint16)
+    vol[:, :, 20:] = 0
+    ref = np.zeros(vol.shape, dtype=np.float32)
+    orc.sliding_window_pass(vol, (32, 32, 16), lambda x: (x - 2000.0) / 1000.0, ref, None, 0.5, None, 1, fp16=False)
+    mask = np.load(tmp_path / "mask.npy")
+    np.testing.assert_array_equal(mask, (ref >= 0).astype(np.uint8))
+
+
+def _write_tiff(path, arr):
+    h, w = arr.shape
+    data = arr.astype("<u2").tobytes()
+    tags = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, 8),
+            (277, 3, 1, 1), (278, 3, 1, h), (279, 4, 1, len(data))]
+    ifd_off = 8 + len(data)
+    with open(path, "wb") as fh:
+        fh.write(b"II" + struct.pack("<HI", 42, ifd_off))
+        fh.write(data)
+        fh.write(struct.pack("<H", len(tags)))
+        for tag, typ, cnt, val in tags:
+            fh.write(struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val)))
+        fh.write(struct.pack("<I", 0))
+
+
+def test_tiff_header_reader_and_get_real_size(tmp_path):
+    from delivr_cfos_amd.downsample.downsample_and_mask import get_real_size, read_tiff_plane
+
+    rng = np.random.default_rng(1)
+    planes = [rng.integers(0, 65535, size=(7, 11)).astype(np.uint16) for _ in range(3)]
+    for i, p in enumerate(planes):
+        _write_tiff(tmp_path / f"Z{i:04d}.tif", p)
+    assert get_real_size(str(tmp_path)) == (3, 7, 11)
+    np.testing.assert_array_equal(read_tiff_plane(str(tmp_path / "Z0001.tif")), planes[1])
+
+
+def test_product_modules_never_import_the_oracle():
+    """The oracle is test infrastructure: nothing under delivr_cfos_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "delivr_cfos_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), encoding="utf-8", errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_device_api_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from delivr_cfos_amd.engine import HipEngine
+
+    with pytest.raises(RuntimeError):
+        HipEngine(0)
