@@ -128,7 +128,8 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         float* b = (float*)take((size_t)cout[i] * 4);
         float* g = (float*)take((size_t)cout[i] * 4);
         float* be = (float*)take((size_t)cout[i] * 4);
-        uint16_t* wb = (uint16_t*)take(nw * 2);
+        // the stem (i == 0) keeps a 4-k-step hi/lo A-fragment pack for the MFMA stem (4 KiB)
+        uint16_t* wb = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
         if (base) {
             ctx->conv[i].cin = cin[i];
             ctx->conv[i].cout = cout[i];

@@ -65,6 +65,19 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __rest
         out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
     }
 }
+// stem (Cin = 1, Cout = 32): K = 64 = {hi byte, lo byte} x 32 tap slots (27 used).  The uint16 input is split
+// exactly into x = 256*hi + lo (both exact in bf16), the weights carry the factor 256 for the hi half:
+//   out[(s*64 + lane)*8 + j]: k = 16 s + 8 (lane>>5) + j, part = k>>5, tap = k&31, cout = lane&31
+__global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 64 * 8) return;
+    const int j = i & 7, lane = (i >> 3) & 63, s = i >> 9;
+    const int k = 16 * s + 8 * (lane >> 5) + j;
+    const int part = k >> 5, tap = k & 31, co = lane & 31;
+    float v = 0.f;
+    if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f);
+    out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+}
 // deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
 __global__ void pack_deconv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cin, int cout) {
     const int KP = cin / 16, CB = cout / 32;
@@ -190,6 +203,128 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
         const long long blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         const long long nblk = (long long)gridDim.x * gridDim.y;
         partials[((long long)n * nblk + blk) * 64 + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA stem for the fused sliding-window path: the uint16 window is staged (with flip and the
+// zero padding of the window border) as a halo tile in LDS; every lane gathers the taps of its voxel,
+// splits them into hi/lo bytes (exact in bf16) and feeds 4 MFMAs (K = 64) per 32-voxel block.
+//   workgroup: 4 (z) x 8 (y) x 32 (x) output voxels; wave w = z-slice w, 8 row blocks
+// ---------------------------------------------------------------------------------------------------
+constexpr int SM_TZ = 4, SM_TY = 8, SM_TX = 32, SM_HZ = 6, SM_HY = 10, SM_HX = 34;
+
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
+                                                        const int* __restrict__ starts, int flip_dim,
+                                                        const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                        uint4* __restrict__ out, float* __restrict__ partials, int D, int H,
+                                                        int W, int tilesY, int tilesX) {
+    __shared__ unsigned short tile_u16[SM_HZ * SM_HY * SM_HX + 2];
+    __shared__ float red[4 * 64];
+    const int n = blockIdx.z;
+    const int t = blockIdx.x;
+    const int tx = t % tilesX, ty = (t / tilesX) % tilesY, tz = t / (tilesX * tilesY);
+    const int z0 = tz * SM_TZ, y0 = ty * SM_TY, x0 = tx * SM_TX;
+    const int wz = starts[3 * n], wy = starts[3 * n + 1], wx = starts[3 * n + 2];
+    for (int i = threadIdx.x; i < SM_HZ * SM_HY * SM_HX; i += 256) {
+        const int xh = i % SM_HX, yh = (i / SM_HX) % SM_HY, zh = i / (SM_HX * SM_HY);
+        int gz = z0 + zh - 1, gy = y0 + yh - 1, gx = x0 + xh - 1;
+        unsigned short v = 0;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            if (flip_dim == 2) gz = D - 1 - gz;
+            if (flip_dim == 3) gy = H - 1 - gy;
+            if (flip_dim == 4) gx = W - 1 - gx;
+            v = vol[((long long)(wz + gz) * Yp + (wy + gy)) * Xp + (wx + gx)];
+        }
+        tile_u16[i] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    bf16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(bf16x8, wpk[s * 64 + lane]);
+    float bs[16], ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+        ssum[r] = ssq[r] = 0.f;
+    }
+    __syncthreads();
+    const long long vox = (long long)D * H * W;
+    const int oz = z0 + wave;
+    for (int row = 0; row < SM_TY; ++row) {
+        // taps of this lane: slots 8h..8h+7 (k-steps 0 and 2) and 16+8h..16+8h+7 (k-steps 1 and 3)
+        const int base = (wave * SM_HY + row) * SM_HX + col;
+        unsigned hi0[4], lo0[4], hi1[4], lo1[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float fh[2], fl[2], gh[2], gl[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * jj + e;
+                const int t0 = 8 * h + j, t1 = 16 + 8 * h + j;  // tap slots (h is wave-half uniform per lane)
+                const int o0 = ((t0 / 9) * SM_HY + (t0 / 3) % 3) * SM_HX + t0 % 3;
+                const int o1 = ((t1 / 9) * SM_HY + (t1 / 3) % 3) * SM_HX + t1 % 3;
+                const unsigned u0 = tile_u16[base + o0];
+                const unsigned u1 = t1 < 27 ? tile_u16[base + o1] : 0u;
+                fh[e] = (float)(u0 >> 8);
+                fl[e] = (float)(u0 & 255u);
+                gh[e] = (float)(u1 >> 8);
+                gl[e] = (float)(u1 & 255u);
+            }
+            hi0[jj] = pack2(fh[0], fh[1]);
+            lo0[jj] = pack2(fl[0], fl[1]);
+            hi1[jj] = pack2(gh[0], gh[1]);
+            lo1[jj] = pack2(gl[0], gl[1]);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], __builtin_bit_cast(bf16x8, make_uint4(hi0[0], hi0[1], hi0[2], hi0[3])), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], __builtin_bit_cast(bf16x8, make_uint4(hi1[0], hi1[1], hi1[2], hi1[3])), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], __builtin_bit_cast(bf16x8, make_uint4(lo0[0], lo0[1], lo0[2], lo0[3])), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], __builtin_bit_cast(bf16x8, make_uint4(lo1[0], lo1[1], lo1[2], lo1[3])), acc, 0, 0, 0);
+        const int oy = y0 + row, ox = x0 + col;
+        const bool ok = oz < D && oy < H && ox < W;
+        float val[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            val[r] = acc[r] + bs[r];
+            if (ok) {
+                ssum[r] += val[r];
+                ssq[r] = fmaf(val[r], val[r], ssq[r]);
+            }
+        }
+        if (ok) {
+            const long long o = ((long long)oz * H + oy) * W + ox;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = pack2(val[4 * g + 0], val[4 * g + 1]);
+                u.y = pack2(val[4 * g + 2], val[4 * g + 3]);
+                uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                dst[h] = u;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float sa = ssum[r], sb = ssq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+        }
+        if (col == 0) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[(wave * 32 + co) * 2] = sa;
+            red[(wave * 32 + co) * 2 + 1] = sb;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        partials[((long long)n * gridDim.x + t) * 64 + i] = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
     }
 }
 
@@ -712,11 +847,18 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
     // stem
     {
         dim3 grid(dlv_cdiv((long long)h * w, 256), dlv_cdiv(d, STEM_ZR), B);
-        const int nblk = grid.x * grid.y;
+        int nblk = grid.x * grid.y;
         if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
         const DlvConvLayer& L = ctx->conv[0];
-        DlvProf pr(ctx, "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
-        if (vol)
+        DlvProf pr(ctx, (vol && !ctx->no_zmarch) ? "stem_mfma_u16" : "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
+        if (vol && !ctx->no_zmarch) {
+            const int tY = dlv_cdiv(h, SM_TY), tX = dlv_cdiv(w, SM_TX), tZ = dlv_cdiv(d, SM_TZ);
+            grid = dim3(tZ * tY * tX, 1, B);
+            nblk = grid.x;
+            if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
+            hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim,
+                               reinterpret_cast<const uint4*>(L.w_bf16), L.bias, buf(0, A), net.partials, d, h, w, tY, tX);
+        } else if (vol)
             hipLaunchKernelGGL(stem_conv_kernel<true>, grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
                                flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
         else
@@ -766,6 +908,8 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
 }  // namespace
 
 int dlv_pack_weights_bf16(dlv_ctx* ctx) {
+    hipLaunchKernelGGL(pack_stem_w_kernel, dim3(8), dim3(256), 0, ctx->stream, ctx->conv[0].w_f32, ctx->conv[0].w_bf16);
+    DLV_LAUNCH_CHECK(ctx, "pack_stem_w_kernel");
     for (int i = 1; i < DLV_N_CONV; ++i) {
         const DlvConvLayer& L = ctx->conv[i];
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: %d->%d not multiples of 32", i, L.cin, L.cout);
