@@ -168,7 +168,7 @@ def test_sw_pass_fast_kernels_vs_generic_and_fp32(net):
     from delivr_cfos_amd.synth import synth_volume_np
 
     vol = synth_volume_np((32, 64, 96), seed=11, dense=True)
-    vol[:, :, 70:] = 0
+    vol[:, :, 40:] = 0
     roi = (16, 32, 48)
     out = {}
     for tag, env, prec in (("fast", None, "bf16"), ("generic", "1", "bf16"), ("fp32", None, "fp32")):
