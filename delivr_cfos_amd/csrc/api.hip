@@ -18,7 +18,8 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
     if (slot < 0 || slot >= WS_N_SLOTS) return dlv_fail(ctx, DLV_EINVAL, "bad scratch slot %d", slot);
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
-            DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+            if (ctx->aux_stream) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
             DLV_HIP(ctx, hipFree(ctx->ws[slot]));
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
@@ -74,7 +75,8 @@ void DlvProf::end() {
 
 static int prof_drain(dlv_ctx* ctx) {
     if (ctx->prof_pending.empty()) return DLV_OK;
-    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    if (ctx->aux_stream) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
     for (auto& p : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -215,6 +217,14 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         }
         ctx->own_stream = true;
     }
+    ctx->main_stream = ctx->stream;
+    if (!getenv("DLV_ONE_LANE") && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess)
+        ctx->aux_stream = nullptr;
+    if (ctx->aux_stream && (hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(ctx->aux_stream);
+        ctx->aux_stream = nullptr;
+    }
     *out = ctx;
     return DLV_OK;
 }
@@ -222,7 +232,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
 int dlv_ctx_destroy(dlv_ctx* ctx) {
     if (!ctx) return DLV_EINVAL;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->main_stream);
     for (auto& p : ctx->prof_pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -231,7 +241,13 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
     for (int i = 0; i < WS_N_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->blob) (void)hipFree(ctx->blob);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+        if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->main_stream);
     delete ctx;
     return DLV_OK;
 }
@@ -240,11 +256,11 @@ const char* dlv_last_error(dlv_ctx* ctx) { return ctx ? ctx->err.c_str() : "null
 
 int dlv_sync(dlv_ctx* ctx) {
     if (!ctx) return DLV_EINVAL;
-    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
     return DLV_OK;
 }
 
-void* dlv_stream(dlv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* dlv_stream(dlv_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
 
 int dlv_malloc(dlv_ctx* ctx, size_t bytes, void** out_dev) {
     if (!ctx || !out_dev) return DLV_EINVAL;

@@ -50,12 +50,19 @@ enum DlvWsSlot {
     WS_ERODE,         // distance maps
     WS_CCL,           // CCL scratch
     WS_MISC,
+    WS_BF16_ACT_B,    // second pipeline lane (aux stream)
+    WS_STATS_B,
     WS_N_SLOTS
 };
 
 struct dlv_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream the NEXT launch goes to (main or aux lane)
+    hipStream_t main_stream = nullptr;  // the ctx stream proper
+    hipStream_t aux_stream = nullptr;   // second lane: batches alternate between the two so that the
+                                        // HBM-bound kernels of one batch overlap the MFMA kernels of the other
+    int lane = 0;
+    hipEvent_t ev_main = nullptr, ev_aux = nullptr;  // lane joins
     bool own_stream = false;
     std::string err;
     // weights

@@ -14,6 +14,8 @@
 //       reduced once per column).
 // The complete weight set (27 x Cin x 32 bf16 = 54 / 108 KiB) is LDS-resident in MFMA A-fragment
 // order.  LDS reads per MFMA: 0.83 x ds_read_b128 (weights shared by the wave's two voxel blocks).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -38,7 +40,7 @@ struct ZmCfg {
     static constexpr int WELEMS = 27 * KP * 64;  // uint4 elements of weights in LDS
     static constexpr int PELEMS = C8 * ZM_PLANE; // uint4 elements of one halo plane
     static constexpr int NPRE = (PELEMS + 255) / 256;
-    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16;
+    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 1024;  // + 4x64 floats for the stats flush
 };
 
 template <int CIN>
@@ -51,6 +53,7 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* lds_w = reinterpret_cast<uint4*>(smem_raw);
     uint4* lds_p = lds_w + C::WELEMS;
+    float* red = reinterpret_cast<float*>(lds_p + C::PELEMS);  // [4 waves][32][2]
 
     const int n = blockIdx.z;
     const int seg = blockIdx.y;
@@ -120,6 +123,36 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         ssum[r] = ssq[r] = 0.f;
     }
 
+    // InstanceNorm partial sums are flushed every 16 output planes (absolute z / 16), so that their
+    // grouping - and with it every bit of the statistics - does not depend on zseg or the batch size
+    const int nzc = (D + 15) / 16;
+    auto flush_stats = [&](int zc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = ssum[r], b = ssq[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (col == 0) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[(wave * 32 + co) * 2] = a;
+                red[(wave * 32 + co) * 2 + 1] = b;
+            }
+            ssum[r] = ssq[r] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int i = threadIdx.x;
+            const float v = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
+            const long long nparts = (long long)gridDim.x * nzc;
+            const long long part = (long long)zc * gridDim.x + tile;
+            partials[(((long long)n * nparts + part) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
+        }
+        __syncthreads();
+    };
+
     // one z step: plane p is in LDS (when 0 <= p < D).  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]),
     // kz=0 -> accC (out[p+1]).  Then out[p-1] is emitted from accA, which is cleared for reuse.
     auto step = [&](int p, f32x16(&accA)[2], f32x16(&accB)[2], f32x16(&accC)[2]) __attribute__((always_inline)) {
@@ -179,6 +212,7 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accA[v][r] = 0.f;
+        if (oz >= zs && oz < ze && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
         __syncthreads();  // every wave is done reading plane p
         if (next_needed) write_plane();
         __syncthreads();
@@ -199,30 +233,6 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         if (p + 2 <= ze) step(p + 2, a2, a0, a1);
     }
 
-    // ---- InstanceNorm partial sums of this column -> partials[n][column][32][2] ----------------------
-    float* red = reinterpret_cast<float*>(lds_p);  // [4 waves][32][2]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float a = ssum[r], b = ssq[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            a += __shfl_xor(a, o, 64);
-            b += __shfl_xor(b, o, 64);
-        }
-        if (col == 0) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            red[(wave * 32 + co) * 2] = a;
-            red[(wave * 32 + co) * 2 + 1] = b;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x;
-        const float v = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
-        const long long ncols = (long long)gridDim.x * gridDim.y;
-        const long long colid = (long long)seg * gridDim.x + tile;
-        partials[(((long long)n * ncols + colid) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
-    }
 }
 
 }  // namespace
@@ -231,12 +241,12 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
                             const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts) {
     const int tilesY = dlv_cdiv(H, ZM_TY), tilesX = dlv_cdiv(W, ZM_TX);
-    // split long columns so that small batches still fill 256 CUs
-    int zseg = D;
-    while ((long long)B * tilesY * tilesX * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = (zseg + 1) / 2;
+    // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
+    int zseg = ((D + 15) / 16) * 16;
+    while ((long long)B * tilesY * tilesX * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
     const int nseg = dlv_cdiv(D, zseg);
     dim3 grid(tilesY * tilesX, nseg, B);
-    *nparts = tilesY * tilesX * nseg;
+    *nparts = tilesY * tilesX * ((D + 15) / 16);
     if (cin == 32) {
         static bool attr32 = false;
         if (!attr32) {

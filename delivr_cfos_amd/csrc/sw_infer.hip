@@ -284,40 +284,68 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     }
     int64_t launches = 0;
     const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);
+    // Two pipeline lanes (HIP streams): consecutive batches of the bf16 path alternate between them so
+    // that the HBM-bound kernels of one batch (stem, norm, deconv, blend) overlap the MFMA-bound
+    // convolutions of the other.  Windows of one colour class are disjoint, so their blends may run
+    // concurrently; the lanes are joined at every class boundary, which keeps the per-voxel summation
+    // order (colour by colour) and therefore the bits of the result.
+    const bool two_lanes = p->precision == DLV_PREC_BF16 && ctx->aux_stream != nullptr;
+    hipEvent_t ev_main = ctx->ev_main, ev_aux = ctx->ev_aux;
+    auto join_lanes = [&]() -> int {
+        if (!two_lanes) return DLV_OK;
+        DLV_HIP(ctx, hipEventRecord(ev_main, ctx->main_stream));
+        DLV_HIP(ctx, hipEventRecord(ev_aux, ctx->aux_stream));
+        DLV_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ev_main, 0));
+        DLV_HIP(ctx, hipStreamWaitEvent(ctx->main_stream, ev_aux, 0));
+        return DLV_OK;
+    };
+    int rc = join_lanes();  // the aux lane starts after everything queued on the main stream so far
+    int lane = 0;
     for (const Seg& s : segs) {
-        for (int b0 = 0; b0 < s.n_active; b0 += sw_batch) {
+        if (rc != DLV_OK) break;
+        for (int b0 = 0; b0 < s.n_active && rc == DLV_OK; b0 += sw_batch) {
             const int B = std::min(sw_batch, s.n_active - b0);
             const int* st_dev = list_dev + (s.off + b0) * 3;
             if (p->precision == DLV_PREC_BF16) {
-                DLV_TRY(dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev));
-                if (cnt_dev) {
+                ctx->lane = two_lanes ? lane : 0;
+                ctx->stream = ctx->lane ? ctx->aux_stream : ctx->main_stream;
+                rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev);
+                if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
                                        Xp, 0.0f, rep, acc_dev, cnt_dev);
-                    DLV_LAUNCH_CHECK(ctx, "fill_add_kernel(count)");
+                    if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel(count) failed");
                 }
+                lane ^= 1;
             } else {
                 float *tin, *tout;
-                DLV_TRY(dlv_ws_get(ctx, WS_TILE_IN, (size_t)sw_batch * tile_vox * 4, (void**)&tin));
-                DLV_TRY(dlv_ws_get(ctx, WS_TILE_OUT, (size_t)sw_batch * tile_vox * 4, (void**)&tout));
+                rc = dlv_ws_get(ctx, WS_TILE_IN, (size_t)sw_batch * tile_vox * 4, (void**)&tin);
+                if (rc == DLV_OK) rc = dlv_ws_get(ctx, WS_TILE_OUT, (size_t)sw_batch * tile_vox * 4, (void**)&tout);
+                if (rc != DLV_OK) break;
                 hipLaunchKernelGGL(gather_f32_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, vol_dev, Yp, Xp,
                                    st_dev, d, h, w, p->flip_dim, tin);
-                DLV_LAUNCH_CHECK(ctx, "gather_f32_kernel");
-                DLV_TRY(dlv_unet_forward_f32(ctx, tin, tout, B, d, h, w));
+                rc = dlv_unet_forward_f32(ctx, tin, tout, B, d, h, w);
+                if (rc != DLV_OK) break;
                 hipLaunchKernelGGL(blend_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, tout, st_dev, d, h, w,
                                    p->flip_dim, Yp, Xp, (float)rep, rep, acc_dev, cnt_dev);
-                DLV_LAUNCH_CHECK(ctx, "blend_add_kernel");
+                if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of gather/blend kernel failed");
             }
             ++launches;
         }
-        if (s.n_skipped > 0) {
+        ctx->stream = ctx->main_stream;
+        ctx->lane = 0;
+        if (rc == DLV_OK && s.n_skipped > 0) {
             const int* st_dev = list_dev + (s.off + s.n_active) * 3;
             DlvProf pr(ctx, "skip_fill_f32", 0.0, 8.0 * tile_vox * s.n_skipped);
             hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, s.n_skipped), dim3(256), 0, ctx->stream, st_dev, d, h, w,
                                Yp, Xp, -1000.0f * rep, rep, acc_dev, cnt_dev);
             pr.end();
-            DLV_LAUNCH_CHECK(ctx, "fill_add_kernel");
+            if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel failed");
         }
+        if (rc == DLV_OK) rc = join_lanes();  // colour-class boundary
     }
+    ctx->stream = ctx->main_stream;
+    ctx->lane = 0;
+    if (rc != DLV_OK) return rc;
     if (stats) {
         stats->n_skipped = n_skipped;
         stats->n_forward_launches = launches;

@@ -1,0 +1,132 @@
+"""BASELINE-size checks through size-independent properties (the oracle cannot run at these sizes
+in seconds): 512^3 volume, 128^3 windows, 50 % overlap (BASELINE configs[1])."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPE, ROI = (512, 512, 512), (128, 128, 128)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    eng.load_state_dict({"state_dict": random_state_dict(0)})
+    vol = synth_volume_torch(SHAPE, 1, eng.device)
+    vol[:, :, :130] = 0  # make sure some windows are pure background
+    torch.cuda.synchronize()
+    yield eng, vol
+    eng.close()
+
+
+def test_full_pass_properties(setup):
+    """count map == analytic coverage (7x7x7 windows: 1/2/4/8 per voxel, separable); shards compose;
+    skipped windows contribute exactly -1000; the blended field is finite."""
+    import torch
+
+    eng, vol = setup
+    p = eng.make_sw_params(SHAPE, ROI, 0.5, None, 0, "bf16")
+    n = eng.num_windows(p)
+    assert n == 343
+    acc = torch.zeros(SHAPE, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(SHAPE, dtype=torch.uint8, device="cuda")
+    st = eng.sw_infer(p, vol, acc, cnt)
+    eng.sync()
+    assert st["n_windows"] == 343 and 0 < st["n_skipped"] < 343
+    cov1 = np.ones(512, dtype=np.int64)
+    cov1[64:448] = 2
+    cov = torch.from_numpy(cov1).cuda()
+    expect = (cov[:, None, None] * cov[None, :, None] * cov[None, None, :]).to(torch.uint8)
+    assert torch.equal(cnt, expect)
+    assert torch.isfinite(acc).all()
+    # windows made only of background voxels: every voxel covered ONLY by skipped windows holds -1000 * coverage
+    bg_only = acc[:, :, :64]  # x < 64 is covered only by windows starting at x = 0, which lie inside x < 130
+    assert torch.equal(bg_only, -1000.0 * expect[:, :, :64].float())
+    # two shards (cut between z tile rows) compose to the same sums bit for bit
+    parts = torch.zeros_like(acc)
+    for rng in ((0, 147), (147, 343)):
+        eng.sw_infer(eng.make_sw_params(SHAPE, ROI, 0.5, None, 0, "bf16", win_range=rng), vol, parts)
+    eng.sync()
+    assert torch.equal(parts, acc)
+    # determinism: a second run is bitwise identical
+    again = torch.zeros_like(acc)
+    eng.sw_infer(p, vol, again)
+    eng.sync()
+    assert torch.equal(again, acc)
+
+
+def test_finalize_and_ccl_properties(setup):
+    import torch
+
+    eng, vol = setup
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acc = torch.randn(SHAPE, generator=g, device="cuda") - 2.0  # ~2 % foreground
+    mask = eng.finalize(acc, None, vol, SHAPE, 0.5, 30, 0)
+    eng.sync()
+    raw_fg = vol.to(torch.int32) > 0
+    assert int(mask.sum()) > 0
+    assert not bool((mask.bool() & ~raw_fg).any())            # mask is inside raw > 0
+    assert not bool((mask.bool() & (acc < 0)).any())           # and only where logit >= 0
+    assert int(mask[:, :, :160].sum()) == 0                    # background x<130 + L1 radius 30
+    # erosion is idempotent w.r.t. a count map: acc*4 with cnt=4 gives the same mask
+    cnt = torch.full(SHAPE, 4, dtype=torch.uint8, device="cuda")
+    assert torch.equal(eng.finalize(acc * 4, cnt, vol, SHAPE, 0.5, 30, 0), mask)
+    # z-blocked erosion keeps at least what the whole-volume erosion keeps (out-of-block counts as foreground)
+    blocked = eng.finalize(acc, None, vol, SHAPE, 0.5, 30, 238)
+    assert not bool((mask.bool() & ~blocked.bool()).any())
+
+    labels, n = eng.ccl26(mask)
+    st = eng.cc_stats(labels, n)
+    lab = labels.view(torch.int32)
+    assert n > 1000
+    assert int(st["voxel_counts"][1:].sum()) == int(mask.sum())
+    assert torch.equal(lab > 0, mask.bool())
+    assert int(lab.max()) == n
+    # idempotence: labelling the labelled foreground again gives identical labels
+    labels2, n2 = eng.ccl26((lab > 0).to(torch.uint8))
+    assert n2 == n and torch.equal(labels2, labels)
+    # raster-order numbering: first voxel of label k precedes first voxel of label k+1
+    flat = lab.flatten()
+    idx = torch.nonzero(flat, as_tuple=False).flatten()
+    first = torch.full((n + 1,), flat.numel(), dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, flat[idx].long(), idx, reduce="amin")
+    assert bool((first[2:] > first[1:-1]).all())
+    # 26-connectivity: no two different labels touch (checked along the 13 forward offsets on a sub-volume)
+    sub = lab[:128, :256, :256]
+    for dz in (0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if (dz, dy, dx) <= (0, 0, 0):
+                    continue
+                a = sub[: sub.shape[0] - dz, max(0, -dy): sub.shape[1] - max(0, dy), max(0, -dx): sub.shape[2] - max(0, dx)]
+                b = sub[dz:, max(0, dy): sub.shape[1] - max(0, -dy), max(0, dx): sub.shape[2] - max(0, -dx)]
+                both = (a > 0) & (b > 0)
+                assert bool((a[both] == b[both]).all())
+    # centroid inside the bounding box
+    bb, ce = st["bounding_boxes"][1:], st["centroids"][1:]
+    for k in range(3):
+        assert np.all(ce[:, k] >= bb[:, 2 * k]) and np.all(ce[:, k] <= bb[:, 2 * k + 1])
+
+
+def test_resamplers_fullsize_properties(setup):
+    import torch
+
+    eng, vol = setup
+    ds = eng.block_mean_u16(vol, (4, 15, 15))
+    assert tuple(ds.shape) == (128, 35, 35)
+    # exact integer check of a few blocks against torch
+    v = vol[:8, :30, :30].to(torch.int64).reshape(2, 4, 2, 15, 2, 15).sum(dim=(1, 3, 5)) // 900
+    assert torch.equal(ds[:2, :2, :2].to(torch.int64), v)
+    m = (ds.to(torch.int32) > 0).to(torch.uint8)
+    up = eng.zoom_spline2_u8(m, SHAPE)
+    assert set(torch.unique(up).tolist()) <= {0, 1}
+    # align-corners mapping reproduces the samples at the corners
+    assert int(up[0, 0, 0]) == int(m[0, 0, 0]) and int(up[-1, -1, -1]) == int(m[-1, -1, -1])
+    padded = eng.mask_pad_u16(vol, up, (512, 512, 640))
+    assert torch.equal(padded[:, :, :512].to(torch.int32), vol.to(torch.int32) * up.to(torch.int32))
+    assert int(padded[:, :, 512:].to(torch.int32).abs().sum()) == 0
