@@ -15,6 +15,7 @@
 // The complete weight set (27 x Cin x 32 bf16 = 54 / 108 KiB) is LDS-resident in MFMA A-fragment
 // order.  LDS reads per MFMA: 0.83 x ds_read_b128 (weights shared by the wave's two voxel blocks).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -39,17 +40,18 @@ struct ZmCfg {
     static constexpr int KP = CIN / 16;          // k-steps per tap
     static constexpr int WELEMS = 27 * KP * 64;  // uint4 elements of weights in LDS
     static constexpr int PELEMS = C8 * ZM_PLANE; // uint4 elements of one halo plane
-    static constexpr int NPRE = (PELEMS + 255) / 256;
-    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 1024;  // + 4x64 floats for the stats flush
+    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN>
-__global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
+template <int CIN, int VB, int MINW>
+__global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                            uint4* __restrict__ out, float* __restrict__ partials, int D,
                                                            int H, int W, int tilesY, int tilesX, int zseg) {
     using C = ZmCfg<CIN>;
+    constexpr int NT = 512 / VB;                 // threads: 8 rows / VB rows per wave
+    constexpr int NPRE = (C::PELEMS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* lds_w = reinterpret_cast<uint4*>(smem_raw);
     uint4* lds_p = lds_w + C::WELEMS;
@@ -67,14 +69,14 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
     const long long vox = (long long)D * plane;
 
     // ---- weights -> LDS (A-fragment order, lane-linear) ------------------------------------------------
-    for (int i = threadIdx.x; i < C::WELEMS; i += 256) lds_w[i] = wpk[i];
+    for (int i = threadIdx.x; i < C::WELEMS; i += NT) lds_w[i] = wpk[i];
 
     // ---- per-thread staging map of the halo plane (constant along z) ----------------------------------
-    long long goff[C::NPRE];
+    long long goff[NPRE];
     unsigned valid = 0;
 #pragma unroll
-    for (int j = 0; j < C::NPRE; ++j) {
-        const int i = threadIdx.x + 256 * j;
+    for (int j = 0; j < NPRE; ++j) {
+        const int i = threadIdx.x + NT * j;
         goff[j] = -1;
         if (i < C::PELEMS) {
             const int xh = i % ZM_HX, yh = (i / ZM_HX) % ZM_HY, c = i / ZM_PLANE;
@@ -87,33 +89,39 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         }
     }
     auto src_of = [&](int j) -> const uint4* {
-        const int c = (threadIdx.x + 256 * j) / ZM_PLANE;
+        const int c = (threadIdx.x + NT * j) / ZM_PLANE;
         return c < c1_8 ? in1 : in2;
     };
-    uint4 pre[C::NPRE];
-    auto issue_loads = [&](int p) {
+    uint4 pre[NPRE];
+    // loads are unconditional (invalid lanes read element 0 of their source and are zeroed by a select):
+    // no exec-masked branch per load, all of a plane's loads are in flight together
+    auto issue_loads = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < C::NPRE; ++j) {
-            pre[j] = make_uint4(0, 0, 0, 0);
-            if (valid & (1u << j)) pre[j] = src_of(j)[goff[j] + (long long)p * plane];
+        for (int j = 0; j < NPRE; ++j) {
+            const bool ok = (valid >> j) & 1u;
+            const uint4 v = src_of(j)[ok ? goff[j] + (long long)p * plane : 0];
+            pre[j] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
     auto write_plane = [&]() {
 #pragma unroll
-        for (int j = 0; j < C::NPRE; ++j) {
-            const int i = threadIdx.x + 256 * j;
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = threadIdx.x + NT * j;
             if (i < C::PELEMS) lds_p[i] = pre[j];
         }
     };
 
     // per-lane LDS offsets: voxel block v = row 2*wave + v, column col; chunk half h
-    int lb[2];
+    int lb[VB];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) lb[v] = (h * ZM_HY + (2 * wave + v)) * ZM_HX + col;
+    for (int v = 0; v < VB; ++v) lb[v] = (h * ZM_HY + (VB * wave + v)) * ZM_HX + col;
 
-    f32x16 a0[2], a1[2], a2[2];
+    f32x16 fzero;
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int r = 0; r < 16; ++r) fzero[r] = 0.f;
+    f32x16 a0[VB], a1[VB], a2[VB];
+#pragma unroll
+    for (int v = 0; v < VB; ++v)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a0[v][r] = a1[v][r] = a2[v][r] = 0.f;
     float bs[16], ssum[16], ssq[16];
@@ -145,7 +153,9 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         __syncthreads();
         if (threadIdx.x < 64) {
             const int i = threadIdx.x;
-            const float v = red[i] + red[64 + i] + red[128 + i] + red[192 + i];
+            float v = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8 / VB; ++w8) v += red[w8 * 64 + i];
             const long long nparts = (long long)gridDim.x * nzc;
             const long long part = (long long)zc * gridDim.x + tile;
             partials[(((long long)n * nparts + part) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
@@ -154,37 +164,46 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
     };
 
     // one z step: plane p is in LDS (when 0 <= p < D).  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]),
-    // kz=0 -> accC (out[p+1]).  Then out[p-1] is emitted from accA, which is cleared for reuse.
-    auto step = [&](int p, f32x16(&accA)[2], f32x16(&accB)[2], f32x16(&accC)[2]) __attribute__((always_inline)) {
+    // kz=0 -> accC (out[p+1], started here).  Then out[p-1] is emitted from accA.
+    auto step = [&](int p, f32x16(&accA)[VB], f32x16(&accB)[VB], f32x16(&accC)[VB]) __attribute__((always_inline)) {
         const bool next_needed = (p + 1 <= ze) && (p + 1 >= 0) && (p + 1 < D);
         if (next_needed) issue_loads(p + 1);
-        if (p >= 0 && p < D) {
+        if (p >= 0 && p < D && p <= ze) {
+            // software-pipelined over the 9*KP (ky,kx,ks) groups: the 5 LDS fragment reads of group g+1
+            // are issued before the 6 MFMAs of group g (one wave per SIMD: nothing else hides LDS latency)
+            constexpr int NG = 9 * C::KP;
+            uint4 fb[2][VB], fw[2][3];
+            auto load_group = [&](int g, uint4(&b)[VB], uint4(&w)[3]) __attribute__((always_inline)) {
+                const int ks = g % C::KP, kx = (g / C::KP) % 3, ky = g / (3 * C::KP);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int v = 0; v < VB; ++v) b[v] = lds_p[lb[v] + (ks * 2 * ZM_HY + ky) * ZM_HX + kx];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int kz = 0; kz < 3; ++kz) w[kz] = lds_w[(((kz * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane];
+            };
+            load_group(0, fb[0], fw[0]);
 #pragma unroll
-                    for (int ks = 0; ks < C::KP; ++ks) {
-                        bf16x8 b[2];
+            for (int g = 0; g < NG; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < NG) load_group(g + 1, fb[cur ^ 1], fw[cur ^ 1]);
 #pragma unroll
-                        for (int v = 0; v < 2; ++v)
-                            b[v] = __builtin_bit_cast(bf16x8, lds_p[lb[v] + (ks * 2 * ZM_HY + ky) * ZM_HX + kx]);
-                        const bf16x8 w0 = __builtin_bit_cast(bf16x8, lds_w[(((0 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
-                        const bf16x8 w1 = __builtin_bit_cast(bf16x8, lds_w[(((1 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
-                        const bf16x8 w2 = __builtin_bit_cast(bf16x8, lds_w[(((2 * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane]);
+                for (int v = 0; v < VB; ++v) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[cur][v]);
+                    // accC starts a new output plane: its first MFMA takes a zero C operand
+                    accC[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][0]), bv,
+                                                                      g == 0 ? fzero : accC[v], 0, 0, 0);
+                    accB[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), bv, accB[v], 0, 0, 0);
+                    accA[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][2]), bv, accA[v], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            accC[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b[v], accC[v], 0, 0, 0);
-                            accB[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b[v], accB[v], 0, 0, 0);
-                            accA[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b[v], accA[v], 0, 0, 0);
-                        }
-                    }
+            for (int v = 0; v < VB; ++v) accC[v] = fzero;
         }
         const int oz = p - 1;
         if (oz >= zs && oz < ze) {
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int oy = y0 + 2 * wave + v, ox = x0 + col;
+            for (int v = 0; v < VB; ++v) {
+                const int oy = y0 + VB * wave + v, ox = x0 + col;
                 const bool ok = oy < H && ox < W;
                 float val[16];
 #pragma unroll
@@ -208,10 +227,6 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
                 }
             }
         }
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[v][r] = 0.f;
         if (oz >= zs && oz < ze && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
         __syncthreads();  // every wave is done reading plane p
         if (next_needed) write_plane();
@@ -227,10 +242,11 @@ __global__ void __launch_bounds__(256) conv3_zmarch_kernel(const uint4* __restri
         }
         __syncthreads();
     }
+    // steps beyond ze are no-ops (compute, loads and emit are all guarded), so the triple needs no branches
     for (int p = zs - 1; p <= ze; p += 3) {
         step(p, a0, a1, a2);
-        if (p + 1 <= ze) step(p + 1, a1, a2, a0);
-        if (p + 2 <= ze) step(p + 2, a2, a0, a1);
+        step(p + 1, a1, a2, a0);
+        step(p + 2, a2, a0, a1);
     }
 
 }
@@ -247,29 +263,37 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
     const int nseg = dlv_cdiv(D, zseg);
     dim3 grid(tilesY * tilesX, nseg, B);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
+    // kernel variants: VB = voxel blocks (rows) per wave -> 8/VB waves per workgroup; MINW = waves per SIMD the
+    // register allocation is bounded for.  DLV_ZM_VARIANT selects one for A/B timing.
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("DLV_ZM_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_)                                                                                  \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_>,                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_>::LDS_BYTES));  \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
+                           ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
+                           (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
+    } while (0)
+    // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     if (cin == 32) {
-        static bool attr32 = false;
-        if (!attr32) {
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)ZmCfg<32>::LDS_BYTES));
-            attr32 = true;
-        }
-        hipLaunchKernelGGL(conv3_zmarch_kernel<32>, grid, dim3(256), ZmCfg<32>::LDS_BYTES, ctx->stream, (const uint4*)in1,
-                           c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W,
-                           tilesY, tilesX, zseg);
+        if (variant == 1) DLV_ZM_LAUNCH(32, 2, 1);
+        else if (variant == 2) DLV_ZM_LAUNCH(32, 2, 2);
+        else DLV_ZM_LAUNCH(32, 1, 2);
     } else if (cin == 64) {
-        static bool attr64 = false;
-        if (!attr64) {
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)ZmCfg<64>::LDS_BYTES));
-            attr64 = true;
-        }
-        hipLaunchKernelGGL(conv3_zmarch_kernel<64>, grid, dim3(256), ZmCfg<64>::LDS_BYTES, ctx->stream, (const uint4*)in1,
-                           c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W,
-                           tilesY, tilesX, zseg);
+        if (variant == 1) DLV_ZM_LAUNCH(64, 2, 1);
+        else DLV_ZM_LAUNCH(64, 1, 2);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }
+#undef DLV_ZM_LAUNCH
     DLV_LAUNCH_CHECK(ctx, "conv3_zmarch_kernel");
     return DLV_OK;
 }
