@@ -43,7 +43,7 @@ struct ZmCfg {
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN, int VB, int MINW>
+template <int CIN, int VB, int MINW, bool LATE, bool PIN>
 __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -99,15 +99,18 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
             const bool ok = (valid >> j) & 1u;
-            const uint4 v = src_of(j)[ok ? goff[j] + (long long)p * plane : 0];
-            pre[j] = ok ? v : make_uint4(0, 0, 0, 0);
+            const uint4* src = ok ? src_of(j) : in1;  // lanes without an element read (and discard) in1[0]
+            pre[j] = src[ok ? goff[j] + (long long)p * plane : 0];
         }
     };
-    auto write_plane = [&]() {
+    // the zero-select of out-of-window lanes happens here, at the first use of the loaded registers, so
+    // that the wait for the loads sits in front of the LDS write and not in front of the MFMAs
+    auto write_plane = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
             const int i = threadIdx.x + NT * j;
-            if (i < C::PELEMS) lds_p[i] = pre[j];
+            const bool ok = (valid >> j) & 1u;
+            if (i < C::PELEMS) lds_p[i] = ok ? pre[j] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -185,6 +188,9 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
             for (int g = 0; g < NG; ++g) {
                 const int cur = g & 1;
                 if (g + 1 < NG) load_group(g + 1, fb[cur ^ 1], fw[cur ^ 1]);
+                // pin the order: left alone, hipcc sinks every ds_read next to its MFMA (read, wait, mfma),
+                // which exposes the full LDS latency on each MFMA
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < VB; ++v) {
                     const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[cur][v]);
@@ -194,43 +200,59 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
                     accB[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), bv, accB[v], 0, 0, 0);
                     accA[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][2]), bv, accA[v], 0, 0, 0);
                 }
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
             for (int v = 0; v < VB; ++v) accC[v] = fzero;
         }
+        // epilogue part 1 (registers only): bias, statistics, bf16 packing of output plane p-1
         const int oz = p - 1;
-        if (oz >= zs && oz < ze) {
+        const bool emit = oz >= zs && oz < ze;
+        uint2 ost[VB][4];
+        bool okv[VB];
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            const int oy = y0 + VB * wave + v, ox = x0 + col;
+            okv[v] = emit && oy < H && ox < W;
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                val[r] = accA[v][r] + bs[r];
+                if (okv[v]) {
+                    ssum[r] += val[r];
+                    ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ost[v][g].x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
+                ost[v][g].y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+            }
+        }
+        auto store_out = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int v = 0; v < VB; ++v) {
-                const int oy = y0 + VB * wave + v, ox = x0 + col;
-                const bool ok = oy < H && ox < W;
-                float val[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    val[r] = accA[v][r] + bs[r];
-                    if (ok) {
-                        ssum[r] += val[r];
-                        ssq[r] = fmaf(val[r], val[r], ssq[r]);
-                    }
-                }
-                if (ok) {
+                if (okv[v]) {
+                    const int oy = y0 + VB * wave + v, ox = x0 + col;
                     const long long o = (long long)oz * plane + (long long)oy * W + ox;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        uint2 u;
-                        u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
-                        u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
                         uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
-                        dst[h] = u;
+                        dst[h] = ost[v][g];
                     }
                 }
             }
-        }
-        if (oz >= zs && oz < ze && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
+        };
+        if (!LATE) store_out();
+        if (emit && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
         __syncthreads();  // every wave is done reading plane p
         if (next_needed) write_plane();
         __syncthreads();
+        // epilogue part 2: the global stores go out AFTER the next plane is staged, so that their
+        // completion latency overlaps the next step's MFMAs instead of sitting in front of the LDS write
+        // (vmcnt counts stores too: waiting for the staged loads would otherwise wait for these stores)
+        if (LATE) store_out();
     };
 
     // prologue: first input plane of the segment (zs-1, or zs when zs == 0)
@@ -270,26 +292,27 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         const char* e = getenv("DLV_ZM_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_)                                                                                  \
+#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, LATE_, PIN_)                                                                                  \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_>,                         \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_>,                         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_>::LDS_BYTES));  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
                            (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     if (cin == 32) {
-        if (variant == 1) DLV_ZM_LAUNCH(32, 2, 1);
-        else if (variant == 2) DLV_ZM_LAUNCH(32, 2, 2);
-        else DLV_ZM_LAUNCH(32, 1, 2);
+        if (variant == 1) DLV_ZM_LAUNCH(32, 2, 1, false, true);
+        else if (variant == 2) DLV_ZM_LAUNCH(32, 1, 2, false, false);
+        else DLV_ZM_LAUNCH(32, 1, 2, false, true);
     } else if (cin == 64) {
-        if (variant == 1) DLV_ZM_LAUNCH(64, 2, 1);
-        else DLV_ZM_LAUNCH(64, 1, 2);
+        if (variant == 1) DLV_ZM_LAUNCH(64, 2, 1, false, true);
+        else if (variant == 2) DLV_ZM_LAUNCH(64, 1, 2, false, false);
+        else DLV_ZM_LAUNCH(64, 1, 2, false, true);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }
