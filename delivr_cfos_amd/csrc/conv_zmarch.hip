@@ -43,7 +43,7 @@ struct ZmCfg {
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN, int VB, int MINW, bool LATE, bool PIN>
+template <int CIN, int VB, int MINW, bool LATE, bool PIN, int DIST, int ABL = 0>
 __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -169,13 +169,13 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
     // one z step: plane p is in LDS (when 0 <= p < D).  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]),
     // kz=0 -> accC (out[p+1], started here).  Then out[p-1] is emitted from accA.
     auto step = [&](int p, f32x16(&accA)[VB], f32x16(&accB)[VB], f32x16(&accC)[VB]) __attribute__((always_inline)) {
-        const bool next_needed = (p + 1 <= ze) && (p + 1 >= 0) && (p + 1 < D);
+        const bool next_needed = !(ABL & 2) && (p + 1 <= ze) && (p + 1 >= 0) && (p + 1 < D);
         if (next_needed) issue_loads(p + 1);
         if (p >= 0 && p < D && p <= ze) {
             // software-pipelined over the 9*KP (ky,kx,ks) groups: the 5 LDS fragment reads of group g+1
             // are issued before the 6 MFMAs of group g (one wave per SIMD: nothing else hides LDS latency)
             constexpr int NG = 9 * C::KP;
-            uint4 fb[2][VB], fw[2][3];
+            uint4 fb[DIST + 1][VB], fw[DIST + 1][3];
             auto load_group = [&](int g, uint4(&b)[VB], uint4(&w)[3]) __attribute__((always_inline)) {
                 const int ks = g % C::KP, kx = (g / C::KP) % 3, ky = g / (3 * C::KP);
 #pragma unroll
@@ -183,11 +183,12 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
 #pragma unroll
                 for (int kz = 0; kz < 3; ++kz) w[kz] = lds_w[(((kz * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane];
             };
-            load_group(0, fb[0], fw[0]);
+#pragma unroll
+            for (int g = 0; g < DIST; ++g) load_group(g, fb[g], fw[g]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const int cur = g & 1;
-                if (g + 1 < NG) load_group(g + 1, fb[cur ^ 1], fw[cur ^ 1]);
+                const int cur = g % (DIST + 1);
+                if (g + DIST < NG) load_group(g + DIST, fb[(g + DIST) % (DIST + 1)], fw[(g + DIST) % (DIST + 1)]);
                 // pin the order: left alone, hipcc sinks every ds_read next to its MFMA (read, wait, mfma),
                 // which exposes the full LDS latency on each MFMA
                 if (PIN) __builtin_amdgcn_sched_barrier(0);
@@ -211,10 +212,16 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
         const bool emit = oz >= zs && oz < ze;
         uint2 ost[VB][4];
         bool okv[VB];
+        if (ABL & 1) {  // timing-only build: no epilogue (accumulators kept alive, outputs are garbage)
+#pragma unroll
+            for (int v = 0; v < VB; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(accA[v][r]));
+        }
 #pragma unroll
         for (int v = 0; v < VB; ++v) {
             const int oy = y0 + VB * wave + v, ox = x0 + col;
-            okv[v] = emit && oy < H && ox < W;
+            okv[v] = !(ABL & 1) && emit && oy < H && ox < W;
             float val[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -292,27 +299,30 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         const char* e = getenv("DLV_ZM_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, LATE_, PIN_)                                                                                  \
+#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_)                                                                                  \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_>,                         \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_>,                         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_>::LDS_BYTES));  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
                            (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
+    // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
     if (cin == 32) {
-        if (variant == 1) DLV_ZM_LAUNCH(32, 2, 1, false, true);
-        else if (variant == 2) DLV_ZM_LAUNCH(32, 1, 2, false, false);
-        else DLV_ZM_LAUNCH(32, 1, 2, false, true);
+        if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 1);
+        else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 2);
+        else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 3);
+        else DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 0);
     } else if (cin == 64) {
-        if (variant == 1) DLV_ZM_LAUNCH(64, 2, 1, false, true);
-        else if (variant == 2) DLV_ZM_LAUNCH(64, 1, 2, false, false);
-        else DLV_ZM_LAUNCH(64, 1, 2, false, true);
+        if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 1);
+        else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 2);
+        else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 3);
+        else DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 0);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }
