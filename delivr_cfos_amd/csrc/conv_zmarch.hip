@@ -16,6 +16,7 @@
 // order.  LDS reads per MFMA: 0.83 x ds_read_b128 (weights shared by the wave's two voxel blocks).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -280,6 +281,222 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
 
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// v2: double-buffered 32-channel half-planes.  Every (plane p, source s) pair is one sub-step with its own
+// 10x34x32ch halo plane (21.8 KB); two LDS buffers alternate, so the next sub-step's data is written
+// while the current one is being multiplied and ONE barrier per sub-step suffices.  A 64-channel
+// (concat) layer is simply two sub-steps per plane, which also makes its LDS budget fit:
+// weights 108 KB + 2 x 21.8 KB.  8 waves (one output row each), 2 waves per SIMD.
+// ---------------------------------------------------------------------------------------------------
+template <int NSRC>
+struct Zm2Cfg {
+    static constexpr int KP = 2 * NSRC;              // k-steps per tap
+    static constexpr int WELEMS = 27 * KP * 64;      // uint4
+    static constexpr int PELEMS = 4 * ZM_PLANE;      // one 32-channel halo plane, uint4
+    static constexpr int NT = 512;
+    static constexpr int NPRE = (PELEMS + NT - 1) / NT;  // 3
+    static constexpr size_t LDS_BYTES = (size_t)(WELEMS + 2 * PELEMS) * 16 + 2048;
+};
+
+template <int NSRC, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __restrict__ in1, const uint4* __restrict__ in2,
+                                                              const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                              uint4* __restrict__ out, float* __restrict__ partials, int D,
+                                                              int H, int W, int tilesY, int tilesX, int zseg) {
+    using C = Zm2Cfg<NSRC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* lds_w = reinterpret_cast<uint4*>(smem_raw);
+    uint4* lds_p = lds_w + C::WELEMS;  // two buffers of PELEMS
+    float* red = reinterpret_cast<float*>(lds_p + 2 * C::PELEMS);
+
+    const int n = blockIdx.z, seg = blockIdx.y, tile = blockIdx.x;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int y0 = ty * ZM_TY, x0 = tx * ZM_TX;
+    const int zs = seg * zseg, ze = min(zs + zseg, D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long plane = (long long)H * W;
+    const long long vox = (long long)D * plane;
+
+    for (int i = threadIdx.x; i < C::WELEMS; i += C::NT) lds_w[i] = wpk[i];
+
+    // staging map (constant along z and identical for both sources: each has 4 chunks of 8 channels)
+    long long goff[C::NPRE];
+    unsigned valid = 0;
+#pragma unroll
+    for (int j = 0; j < C::NPRE; ++j) {
+        const int i = threadIdx.x + C::NT * j;
+        goff[j] = 0;
+        if (i < C::PELEMS) {
+            const int xh = i % ZM_HX, yh = (i / ZM_HX) % ZM_HY, c = i / ZM_PLANE;
+            const int gy = y0 + yh - 1, gx = x0 + xh - 1;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                goff[j] = ((long long)n * 4 + c) * vox + (long long)gy * W + gx;
+                valid |= 1u << j;
+            }
+        }
+    }
+    uint4 pre[C::NPRE];
+    auto issue_loads = [&](int p, int s) __attribute__((always_inline)) {
+        const uint4* src = (NSRC == 2 && s == 1) ? in2 : in1;
+#pragma unroll
+        for (int j = 0; j < C::NPRE; ++j) {
+            const bool ok = (valid >> j) & 1u;
+            pre[j] = src[ok ? goff[j] + (long long)p * plane : 0];
+        }
+    };
+    auto write_plane = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < C::NPRE; ++j) {
+            const int i = threadIdx.x + C::NT * j;
+            const bool ok = (valid >> j) & 1u;
+            if (i < C::PELEMS) lds_p[buf * C::PELEMS + i] = ok ? pre[j] : make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    const int lb = (h * ZM_HY + wave) * ZM_HX + col;  // this lane's voxel (row = wave, column col), chunk half h
+    f32x16 fzero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fzero[r] = 0.f;
+    f32x16 a0 = fzero, a1 = fzero, a2 = fzero;
+    float bs[16], ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+        ssum[r] = ssq[r] = 0.f;
+    }
+    const int nzc = (D + 15) / 16;
+    auto flush_stats = [&](int zc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = ssum[r], b = ssq[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (col == 0) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[(wave * 32 + co) * 2] = a;
+                red[(wave * 32 + co) * 2 + 1] = b;
+            }
+            ssum[r] = ssq[r] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int i = threadIdx.x;
+            float v = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) v += red[w8 * 64 + i];
+            const long long nparts = (long long)gridDim.x * nzc;
+            const long long part = (long long)zc * gridDim.x + tile;
+            partials[(((long long)n * nparts + part) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
+        }
+        __syncthreads();
+    };
+
+    // one sub-step: (plane p, source S) sits in buffer BUF; the data of the NEXT sub-step is fetched and written
+    // into the other buffer meanwhile.  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]), kz=0 -> accC (out[p+1]).
+    auto substep = [&](int p, auto S_, auto BUF_, f32x16& accA, f32x16& accB, f32x16& accC) __attribute__((always_inline)) {
+        constexpr int S = decltype(S_)::value, BUF = decltype(BUF_)::value;
+        constexpr bool LAST = (S == NSRC - 1);
+        // next sub-step's data
+        const int pn = LAST ? p + 1 : p;
+        constexpr int sn = LAST ? 0 : S + 1;
+        const bool next_needed = !(ABL & 2) && pn <= ze && pn >= 0 && pn < D;
+        if (next_needed) issue_loads(pn, sn);
+        if (p >= 0 && p < D && p <= ze) {
+            constexpr int NG = 18;  // 9 (ky,kx) x 2 k-steps of this source
+            const uint4* pb = lds_p + BUF * C::PELEMS;
+            uint4 fb[2], fw[2][3];
+            auto load_group = [&](int g, uint4& b, uint4(&w)[3]) __attribute__((always_inline)) {
+                const int ks = g & 1, kx = (g >> 1) % 3, ky = g / 6;
+                b = pb[lb + (ks * 2 * ZM_HY + ky) * ZM_HX + kx];
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz) w[kz] = lds_w[(((kz * 3 + ky) * 3 + kx) * C::KP + S * 2 + ks) * 64 + lane];
+            };
+            load_group(0, fb[0], fw[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < NG) load_group(g + 1, fb[cur ^ 1], fw[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[cur]);
+                accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][0]), bv,
+                                                               (S == 0 && g == 0) ? fzero : accC, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), bv, accB, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][2]), bv, accA, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (S == 0) {
+            accC = fzero;
+        }
+        if (LAST) {
+            const int oz = p - 1;
+            const bool emit = !(ABL & 1) && oz >= zs && oz < ze;
+            if (ABL & 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(accA[r]));
+            }
+            const int oy = y0 + wave, ox = x0 + col;
+            const bool ok = emit && oy < H && ox < W;
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                val[r] = accA[r] + bs[r];
+                if (ok) {
+                    ssum[r] += val[r];
+                    ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                }
+            }
+            if (ok) {
+                const long long o = (long long)oz * plane + (long long)oy * W + ox;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                    dst[h] = u;
+                }
+            }
+            if (emit && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
+        }
+        if (next_needed) write_plane(BUF ^ 1);
+        __syncthreads();  // next data visible; everybody is done reading BUF
+    };
+
+    // prologue: data of the first sub-step (plane zs-1, source 0) into buffer 0
+    if (zs - 1 >= 0 && !(ABL & 2)) {
+        issue_loads(zs - 1, 0);
+        write_plane(0);
+    }
+    __syncthreads();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (NSRC == 1) {
+        // 6 planes per iteration: buffer parity and accumulator roles are both static
+        for (int p = zs - 1; p <= ze; p += 6) {
+            substep(p + 0, I0{}, I0{}, a0, a1, a2);
+            substep(p + 1, I0{}, I1{}, a1, a2, a0);
+            substep(p + 2, I0{}, I0{}, a2, a0, a1);
+            substep(p + 3, I0{}, I1{}, a0, a1, a2);
+            substep(p + 4, I0{}, I0{}, a1, a2, a0);
+            substep(p + 5, I0{}, I1{}, a2, a0, a1);
+        }
+    } else {
+        for (int p = zs - 1; p <= ze; p += 3) {
+            substep(p + 0, I0{}, I0{}, a0, a1, a2);
+            substep(p + 0, I1{}, I1{}, a0, a1, a2);
+            substep(p + 1, I0{}, I0{}, a1, a2, a0);
+            substep(p + 1, I1{}, I1{}, a1, a2, a0);
+            substep(p + 2, I0{}, I0{}, a2, a0, a1);
+            substep(p + 2, I1{}, I1{}, a2, a0, a1);
+        }
+    }
+}
+
 }  // namespace
 
 // returns the number of partial-sum rows per sample (columns) or a negative error
@@ -313,6 +530,31 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
+#define DLV_ZM2_LAUNCH(NSRC_, ABL_)                                                                                       \
+    do {                                                                                                                 \
+        static bool attr_set2 = false;                                                                                   \
+        if (!attr_set2) {                                                                                                \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch2_kernel<NSRC_, ABL_>,                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Zm2Cfg<NSRC_>::LDS_BYTES)); \
+            attr_set2 = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv3_zmarch2_kernel<NSRC_, ABL_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES, ctx->stream,  \
+                           (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W, \
+                           tilesY, tilesX, zseg);                                                                        \
+    } while (0)
+    if (variant >= 20 && variant < 30 && ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
+        if (cin == 32) {
+            if (variant == 21) DLV_ZM2_LAUNCH(1, 1);
+            else if (variant == 22) DLV_ZM2_LAUNCH(1, 2);
+            else if (variant == 23) DLV_ZM2_LAUNCH(1, 3);
+            else DLV_ZM2_LAUNCH(1, 0);
+        } else {
+            if (variant == 21) DLV_ZM2_LAUNCH(2, 1);
+            else if (variant == 22) DLV_ZM2_LAUNCH(2, 2);
+            else if (variant == 23) DLV_ZM2_LAUNCH(2, 3);
+            else DLV_ZM2_LAUNCH(2, 0);
+        }
+    } else
     if (cin == 32) {
         if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 1);
         else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 2);
@@ -327,6 +569,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }
 #undef DLV_ZM_LAUNCH
+#undef DLV_ZM2_LAUNCH
     DLV_LAUNCH_CHECK(ctx, "conv3_zmarch_kernel");
     return DLV_OK;
 }
