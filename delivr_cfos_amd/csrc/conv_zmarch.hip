@@ -530,30 +530,30 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
-#define DLV_ZM2_LAUNCH(NSRC_, ABL_)                                                                                       \
+#define DLV_ZM2_LAUNCH(KERNEL_, NSRC_, ABL_)                                                                                       \
     do {                                                                                                                 \
         static bool attr_set2 = false;                                                                                   \
         if (!attr_set2) {                                                                                                \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch2_kernel<NSRC_, ABL_>,                             \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)KERNEL_<NSRC_, ABL_>,                             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Zm2Cfg<NSRC_>::LDS_BYTES)); \
             attr_set2 = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch2_kernel<NSRC_, ABL_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES, ctx->stream,  \
+        hipLaunchKernelGGL((KERNEL_<NSRC_, ABL_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES, ctx->stream,  \
                            (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W, \
                            tilesY, tilesX, zseg);                                                                        \
     } while (0)
     if (variant >= 20 && variant < 30 && ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
-        if (cin == 32) {
-            if (variant == 21) DLV_ZM2_LAUNCH(1, 1);
-            else if (variant == 22) DLV_ZM2_LAUNCH(1, 2);
-            else if (variant == 23) DLV_ZM2_LAUNCH(1, 3);
-            else DLV_ZM2_LAUNCH(1, 0);
-        } else {
-            if (variant == 21) DLV_ZM2_LAUNCH(2, 1);
-            else if (variant == 22) DLV_ZM2_LAUNCH(2, 2);
-            else if (variant == 23) DLV_ZM2_LAUNCH(2, 3);
-            else DLV_ZM2_LAUNCH(2, 0);
-        }
+        const int abl = variant % 10;
+#define DLV_ZM2_DISPATCH(NSRC_)                                                      \
+    do {                                                                             \
+        if (abl == 1) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 1);                \
+        else if (abl == 2) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 2);           \
+        else if (abl == 3) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 3);           \
+        else DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 0);                         \
+    } while (0)
+        if (cin == 32) DLV_ZM2_DISPATCH(1);
+        else DLV_ZM2_DISPATCH(2);
+#undef DLV_ZM2_DISPATCH
     } else
     if (cin == 32) {
         if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 1);
