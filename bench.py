@@ -229,6 +229,19 @@ def main():
             roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None,
                         "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
+        # HBM traffic per launch of that kernel from the committed PMC passes of this same command
+        # (profiles/run_pmc_traffic.sh; FETCH_SIZE doubled as the gfx950 guide prescribes), if available
+        try:
+            tfile = os.path.join(ROOT, "profiles", f"traffic_r01_{args.workload}.json")
+            if os.path.isfile(tfile) and not args.dense and args.sw_batch == 0:
+                tj = json.load(open(tfile))
+                if name in tj["kernels"]:
+                    roofline["traffic"] = tj["kernels"][name]["traffic_bytes"]
+                    roofline["traffic_source"] = os.path.relpath(tfile, ROOT)
+                    roofline["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
+        except Exception:
+            pass
+        roofline["lanes"] = 1 if os.environ.get("DLV_ONE_LANE") else 2
         # whole-forward MFMA fraction as a second figure
         net_ms = sum(v["total_ms"] for v in prof.values())
         roofline["forward_tflops"] = FLOP_PER_PATCH_VOXEL * tile_vox * n_active * args.steps / (1e-3 * net_ms) / 1e12 \

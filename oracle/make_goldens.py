@@ -281,7 +281,65 @@ def main():
     golden_ccl_and_csv()
     golden_unet()
     golden_resample()
+    golden_swc()
 
 
-if __name__ == "__main__":
+
+
+def golden_swc():
+    """SWC files written by the reference's own rewrite_swc (automate_mBrainaligner.py:75-197), imported
+    under stubs (tifffile, more_itertools absent), from the CSV golden."""
+    import importlib.util
+
+    g = np.load(os.path.join(GOLD, "ref_csv.npz"))
+    for name in ("tifffile",):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "more_itertools" not in sys.modules:
+        mi = types.ModuleType("more_itertools")
+
+        def sliced(seq, n):
+            for i in range(0, len(seq), n):
+                yield seq[i:i + n]
+
+        mi.sliced = sliced
+        sys.modules["more_itertools"] = mi
+    spec = importlib.util.spec_from_file_location("delivr_ref_mba", os.path.join(ref_harness.REFERENCE_ROOT, "automate_mBrainaligner.py"))
+    mba = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mba)
+    out = {}
+    # the reference pins pandas 1.4.3 (requirements.txt), where Series.str.replace defaults to regex=True;
+    # pandas 2.x defaults to regex=False, which makes the reference's re.escape()'d patterns literal.
+    import pandas as pd
+    from pandas.core.strings.accessor import StringMethods
+
+    real_replace = StringMethods.replace
+
+    def replace_pd14(self, pat, repl, n=-1, case=None, flags=0, regex=True):
+        return real_replace(self, pat, repl, n=n, case=case, flags=flags, regex=regex)
+
+    StringMethods.replace = replace_pd14
+    with tempfile.TemporaryDirectory() as td:
+        csv_path = os.path.join(td, str(g["csv_name"]))
+        open(csv_path, "w").write(str(g["csv_text"]))
+        single = mba.rewrite_swc(csv_path, td)
+        out["single_name"] = np.array(os.path.basename(single[0]))
+        out["single_text"] = np.array(open(single[0]).read())
+        real_cpu = os.cpu_count
+        os.cpu_count = lambda: 5  # 4 chunks, deterministic
+        try:
+            chunks = mba.rewrite_swc(csv_path, td, parallel_processing=True)
+        finally:
+            os.cpu_count = real_cpu
+        out["chunk_names"] = np.array([os.path.basename(c) for c in chunks])
+        out["chunk_texts"] = np.array([open(c).read() for c in chunks])
+        out["params"] = np.array(mba.split_parameters(csv_path))
+    StringMethods.replace = real_replace
+    np.savez_compressed(os.path.join(GOLD, "ref_swc.npz"), **out)
+    print("ref_swc.npz", out["single_name"], len(str(out["single_text"])), "bytes;", len(out["chunk_names"]), "chunks")
+
+
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "swc":
+    golden_swc()
+elif __name__ == "__main__":
     main()

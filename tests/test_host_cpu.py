@@ -179,3 +179,23 @@ def test_device_api_fails_loudly_without_gpu():
 
     with pytest.raises(RuntimeError):
         HipEngine(0)
+
+
+def test_swc_writer_matches_reference_golden(golden_dir, tmp_path):
+    """the CSV -> SWC rewrite the atlas step performs (automate_mBrainaligner.py:75-197),
+    pinned by the reference's own function (run under pandas-1.4 regex semantics)."""
+    from delivr_cfos_amd.swc import rewrite_swc, sampling_factors, split_parameters
+
+    g = np.load(os.path.join(golden_dir, "ref_csv.npz"))
+    s = np.load(os.path.join(golden_dir, "ref_swc.npz"))
+    p = os.path.join(tmp_path, str(g["csv_name"]))
+    open(p, "w").write(str(g["csv_text"]))
+    one = rewrite_swc(p, str(tmp_path))
+    assert os.path.basename(one[0]) == str(s["single_name"])
+    assert open(one[0]).read() == str(s["single_text"])
+    chunks = rewrite_swc(p, str(tmp_path), parallel_processing=True, n_chunks=4)
+    assert [os.path.basename(c) for c in chunks] == [str(x) for x in s["chunk_names"]]
+    for c, t in zip(chunks, s["chunk_texts"]):
+        assert open(c).read() == str(t)
+    assert split_parameters(p) == [int(v) for v in s["params"]]
+    assert sampling_factors(p, (25, 10, 10)) == (10.0, 10.0, 4.0)
