@@ -1,0 +1,142 @@
+"""The step-level mirror end to end on the GPU: files in, files out, same names/dtypes/headers as the
+reference's steps 2 and 3 (inference/inference.py:113-332, count_blobs.py:36-118, __main__.py:106-166)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_padded_npy(path, vol, crop):
+    from delivr_cfos_amd.hostlogic import padded_shape
+
+    pad = padded_shape(vol.shape, crop)
+    out = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint16, shape=(1, 1) + pad)
+    assert out.offset == 128
+    out[0, 0, : vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+    out.flush()
+    return pad
+
+
+def _uncompressed_tiff(path, plane):
+    import struct
+
+    h, w = plane.shape
+    data = plane.astype("<u2").tobytes()
+    tags = [(256, 3, w), (257, 3, h), (258, 3, 16), (259, 3, 1), (262, 3, 1), (273, 4, 8), (277, 3, 1), (278, 3, h),
+            (279, 4, len(data))]
+    with open(path, "wb") as fh:
+        fh.write(b"II" + struct.pack("<HI", 42, 8 + len(data)))
+        fh.write(data)
+        fh.write(struct.pack("<H", len(tags)))
+        for tag, typ, val in tags:
+            fh.write(struct.pack("<HHI", tag, typ, 1) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val)))
+        fh.write(struct.pack("<I", 0))
+
+
+@pytest.mark.parametrize("precision,tta", [("fp32", False), ("bf16", True)])
+def test_cli_steps_2_and_3(tmp_path, precision, tta):
+    import torch
+    from delivr_cfos_amd.__main__ import main
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    brain = "brainA"
+    crop = (32, 32, 32)
+    vol = synth_volume_np((40, 70, 66), seed=21, dense=True)  # not a multiple of the window -> padding matters
+    vol[:, :, :8] = 0
+    root = str(tmp_path)
+    raw_dir = os.path.join(root, "raw", brain)
+    os.makedirs(raw_dir)
+    for z in range(vol.shape[0]):
+        _uncompressed_tiff(os.path.join(raw_dir, f"Z{z:04d}.tif"), vol[z])
+    mask_dir = os.path.join(root, "out", "01_mask", brain, "masked_niftis")
+    os.makedirs(mask_dir)
+    pad = _write_padded_npy(os.path.join(mask_dir, "masked_nifti.npy"), vol, crop)
+    sd = random_state_dict(5)
+    wfile = os.path.join(root, "weights.tar")
+    torch.save({"state_dict": sd}, wfile)
+    cfg = {
+        "raw_location": os.path.join(root, "raw") + "/", "output_location": os.path.join(root, "out") + "/",
+        "mask_detection": {"output_location": os.path.join(root, "out", "01_mask") + "/"},
+        "blob_detection": {"input_location": os.path.join(root, "out", "01_mask") + "/", "model_location": wfile,
+                           "output_location": os.path.join(root, "out", "02_blob") + "/",
+                           "window_dimensions": {"window_dim_0": crop[0], "window_dim_1": crop[1], "window_dim_2": crop[2]}},
+        "postprocessing": {"input_location": os.path.join(root, "out", "02_blob") + "/",
+                           "output_location": os.path.join(root, "out", "03_post") + "/", "min_size": -1, "max_size": -1},
+        "mi355x": {"precision": precision},
+        "FLAGS": {"ABSPATHS": True, "LOAD_ALL_RAM": True, "TEST_TIME_AUGMENTATION": tta, "MASK_DOWNSAMPLE": False,
+                  "BLOB_DETECTION": True, "POSTPROCESSING": True, "ATLAS_ALIGNMENT": False, "REGION_ASSIGNMENT": False,
+                  "VISUALIZATION": False, "SAVE_ACTIVATED_OUTPUT": precision == "fp32"},
+    }
+    cfg_path = os.path.join(root, "config.json")
+    json.dump(cfg, open(cfg_path, "w"))
+    assert main([cfg_path]) == 0
+
+    bin_path = os.path.join(root, "out", "02_blob", brain, "binary_segmentations", "binaries.npy")
+    with open(bin_path, "rb") as fh:
+        assert len(np.lib.format.read_magic(fh)) == 2
+    binaries = np.load(bin_path)
+    assert binaries.dtype == np.uint8 and binaries.shape == vol.shape
+    assert np.memmap(bin_path, dtype=np.uint8, mode="r", shape=vol.shape, offset=128).sum() == binaries.sum()
+
+    if precision == "fp32":
+        # oracle run of the same steps (fp32 accumulate): identical mask except where |mean logit| < 1e-3
+        net = orc.build_unet(seed=None)
+        net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+        padded = np.zeros(pad, dtype=np.uint16)
+        padded[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+        acc = np.zeros(pad, dtype=np.float32)
+        cnt = np.zeros(pad, dtype=np.uint8)
+        orc.sliding_window_pass(padded, crop, lambda x: orc.unet_forward(net, x), acc, cnt, 0.5, None, 1, fp16=False)
+        ref = orc.finalize(acc, cnt, padded, vol.shape, 0.5, 30)
+        margin = np.abs(acc[: vol.shape[0], : vol.shape[1], : vol.shape[2]] / np.maximum(cnt[: vol.shape[0], : vol.shape[1], : vol.shape[2]], 1)) < 1e-3
+        assert np.array_equal(binaries[~margin], ref[~margin])
+        inter = np.logical_and(binaries, ref).sum()
+        union = np.logical_or(binaries, ref).sum()
+        assert union == 0 or inter / union >= 0.999  # north_star: mask IoU >= 0.999 vs the reference path
+        prob = np.load(os.path.join(root, "out", "02_blob", brain, "binary_segmentations", "network_output.npy"))
+        assert prob.dtype == np.float32 and prob.shape == vol.shape
+
+    post = os.path.join(root, "out", "03_post")
+    files = sorted(os.listdir(post))
+    labels_file = [f for f in files if f.endswith("-cc3d.npy")][0]
+    n = int(labels_file.split("-")[1])
+    labels = np.load(os.path.join(post, labels_file))
+    lab_ref, n_ref = orc.ccl26(binaries)
+    assert n == n_ref and np.array_equal(labels.astype(np.uint32), lab_ref)
+    stats = pickle.load(open(os.path.join(post, f"{brain}-stats.pickle"), "rb"))
+    ref_stats = orc.cc_stats(lab_ref, n_ref)
+    np.testing.assert_array_equal(stats["voxel_counts"][1:], ref_stats["voxel_counts"][1:])
+    csv = [f for f in os.listdir(os.path.join(root, "out")) if f.endswith(".csv")]
+    csv_path = os.path.join(root, "out", csv[0]) if csv else post + f"{vol.shape}_{brain}.csv"
+    assert os.path.isfile(csv_path), files
+    assert open(csv_path).read() == orc.cells_csv_text(ref_stats, n_ref)
+
+
+def test_default_config_window_96_96_64():
+    """config.json's default window (96,96,64): level sizes 96/48/24/12/6 x 64/32/16/8/4 exercise every tile
+    shape (z-march with 6x2 tiles, generic TX 16 and TX 8 with masked x)."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    eng.load_state_dict({"state_dict": random_state_dict(9)})
+    vol = synth_volume_np((96, 96, 128), seed=4, dense=True)
+    v = eng.to_device(vol)
+    accs = {}
+    for prec in ("fp32", "bf16"):
+        acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+        st = eng.sw_infer(eng.make_sw_params(vol.shape, (96, 96, 64), 0.5, None, 0, prec), v, acc)
+        eng.sync()
+        assert st["n_windows"] == 3
+        accs[prec] = acc.cpu().numpy()
+    rel = float(np.sqrt(np.mean((accs["bf16"] - accs["fp32"]) ** 2)) / accs["fp32"].std())
+    assert rel < 5e-2, rel
+    eng.close()
