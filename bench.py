@@ -116,8 +116,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from delivr_cfos_amd.engine import HipEngine
-    from delivr_cfos_amd.hostlogic import arrayterator_zblock
-    from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, gather_slabs, make_plan
+    from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, finalize_owned, gather_slabs, make_plan
     from delivr_cfos_amd.synth import synth_volume_torch
     from delivr_cfos_amd.weights import random_state_dict
 
@@ -140,10 +139,6 @@ def main():
     if we <= wb:  # a rank without windows still takes part in the exchange
         params = None
     acc = torch.zeros(shape, dtype=torch.float32, device=eng.device)
-    nb = arrayterator_zblock((Z, Y, X))
-    olo, ohi = plan.z_owned[rank]
-    ohi = min(ohi, Z)
-    blo, bhi = (olo // nb) * nb, min(-(-ohi // nb) * nb, Z)
     mask_full = torch.empty(shape, dtype=torch.uint8, device=eng.device) if (world > 1 and rank == 0) else None
 
     stats_last = {}
@@ -155,10 +150,8 @@ def main():
         if world > 1:
             eng.sync()
             exchange_seams(acc, plan, rank, dist)
-        if ohi > olo:
-            m = eng.finalize(acc[blo:bhi], None, vol[blo:bhi], (bhi - blo, Y, X), 0.5, 30, nb)
-            slab = m[olo - blo: ohi - blo]
-        else:
+        slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30)
+        if slab is None:
             slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
         if world > 1:
             eng.sync()

@@ -78,19 +78,34 @@ def run_inference(
     print("using crop size:  ", crop_size)
     if not torch.cuda.is_available():
         raise RuntimeError("run_inference needs an MI355X: the HIP path has no CPU fallback")
-    device_index = int(str(cuda_devices).split(",")[0]) if str(cuda_devices).strip() else 0
+    # one process per GPU (torch.distributed.run): the window list is sharded over the ranks, see parallel.py.
+    # Single process: the first entry of cuda_devices (the reference's DataParallel spans all of them).
+    import torch.distributed as dist
+
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if sharded else 0
+    world = dist.get_world_size() if sharded else 1
+    if sharded:
+        device_index = int(os.environ.get("LOCAL_RANK", rank))
+    else:
+        device_index = int(str(cuda_devices).split(",")[0]) if str(cuda_devices).strip() else 0
     if device_index >= torch.cuda.device_count():
         device_index = 0
 
     # ~~<< M O D E L >>~~  (reference :190-222)
     model = HipBasicUNet(device=device_index, precision=precision)
-    if state_dict is None:
-        checkpoint = torch.load(os.path.abspath(model_weights), map_location="cpu", weights_only=False)
-    else:
-        checkpoint = state_dict
-    model.load_state_dict(checkpoint)
-    model.eval()
     eng = model.engine
+    if rank == 0:
+        if state_dict is None:
+            checkpoint = torch.load(os.path.abspath(model_weights), map_location="cpu", weights_only=False)
+        else:
+            checkpoint = state_dict
+        model.load_state_dict(checkpoint)
+    if sharded:
+        from ..parallel import broadcast_weights
+
+        broadcast_weights(eng, dist, rank)  # ONE broadcast instead of DataParallel's per-forward replicate
+    model.eval()
     inferer = SlidingWindowInferer(roi_size=crop_size, sw_batch_size=sw_batch_size, sw_device=eng.device,
                                    device=eng.device, overlap=overlap, mode="gaussian", padding_mode="replicate")
 
@@ -100,33 +115,74 @@ def run_inference(
     pad = (1, 1) + padded_shape(stack_shape[2:], crop_size)
     dataset_host = np.memmap(niftis[0], dtype=np.uint16, mode="r", shape=pad, offset=128)
     dataset = eng.to_device(np.ascontiguousarray(dataset_host[0, 0]))
-    os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
+    if rank == 0:
+        os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
     save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
     output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
     count_map = torch.zeros(pad[2:], dtype=torch.uint8, device=eng.device) if save_activated else None
     print("output_image shape", tuple(output_image.shape))
 
-    # inference passes (reference :261-279)
-    print(f"{datetime.datetime.now()} : Starting inference")
-    for flip_dim, repeat in pass_schedule(bool(tta)):
-        kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
-        if flip_dim is not None:
-            kw.update(tta=True, flip_dim=flip_dim)
-        inferer(dataset, model, **kw)
-    eng.sync()
-
-    # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
-    print(f"{datetime.datetime.now()} : Creating binarized blob output")
     testing_session_path = os.path.abspath(output_folder + "/" + comment)
     binaries_path = testing_session_path + "/binary_segmentations/"
-    os.makedirs(binaries_path, exist_ok=True)
     output_file = os.path.join(binaries_path, "binaries.npy")
-    network_output_file = None
-    if save_activated:
-        os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
-        network_output_file = os.path.join(binaries_path, "network_output.npy")
-    create_nifti_seg(threshold=threshold, model_output=output_image, output_file=output_file,
-                     network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
-                     count_map=count_map, engine=eng)
+    network_output_file = os.path.join(binaries_path, "network_output.npy") if save_activated else None
+
+    # inference passes (reference :261-279)
+    print(f"{datetime.datetime.now()} : Starting inference")
+    if not sharded:
+        for flip_dim, repeat in pass_schedule(bool(tta)):
+            kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
+            if flip_dim is not None:
+                kw.update(tta=True, flip_dim=flip_dim)
+            inferer(dataset, model, **kw)
+        eng.sync()
+        # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
+        print(f"{datetime.datetime.now()} : Creating binarized blob output")
+        os.makedirs(binaries_path, exist_ok=True)
+        if save_activated:
+            os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
+        create_nifti_seg(threshold=threshold, model_output=output_image, output_file=output_file,
+                         network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
+                         count_map=count_map, engine=eng)
+    else:
+        from ..parallel import exchange_seams, finalize_owned, gather_slabs, make_plan
+
+        Zp = pad[2]
+        p_all = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
+        plan = make_plan(eng.window_starts(p_all), int(p_all.roi[0]), Zp, world)
+        for flip_dim, repeat in pass_schedule(bool(tta)):
+            wb, we = plan.win_ranges[rank]
+            if we > wb:
+                eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
+                                                repeat=repeat), dataset, output_image, count_map)
+        eng.sync()
+        exchange_seams(output_image, plan, rank, dist)
+        if count_map is not None:
+            exchange_seams(count_map, plan, rank, dist)
+        Z, Y, X = stack_shape[2:]
+        slab, prob, _ = finalize_owned(eng, plan, rank, output_image, count_map, dataset, (Z, Y, X), threshold, 30,
+                                       want_prob=save_activated)
+        eng.sync()
+        if slab is None:
+            slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
+        full = torch.empty((Z, Y, X), dtype=torch.uint8, device=eng.device) if rank == 0 else None
+        gather_slabs(slab, plan, rank, dist, out=full)
+        if save_activated:
+            if prob is None:
+                prob = torch.empty((0, Y, X), dtype=torch.float32, device=eng.device)
+            pfull = torch.empty((Z, Y, X), dtype=torch.float32, device=eng.device) if rank == 0 else None
+            gather_slabs(prob, plan, rank, dist, out=pfull)
+        if rank == 0:
+            print(f"{datetime.datetime.now()} : Creating binarized blob output")
+            os.makedirs(binaries_path, exist_ok=True)
+            out = np.lib.format.open_memmap(output_file, mode="w+", dtype=np.uint8, shape=(Z, Y, X))
+            out[...] = full.cpu().numpy()
+            out.flush()
+            if save_activated:
+                os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
+                act = np.lib.format.open_memmap(network_output_file, mode="w+", dtype=np.float32, shape=(Z, Y, X))
+                act[...] = pfull.cpu().numpy()
+                act.flush()
+        dist.barrier()
     print(f"{datetime.datetime.now()} : Blob Detection finished")
     return testing_session_path

@@ -163,3 +163,24 @@ def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0,
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out
+
+
+def finalize_owned(engine, plan: ShardPlan, rank: int, acc, cnt, vol, stack_shape, threshold=0.5, erode_iters=30,
+                   want_prob=False):
+    """Threshold + eroded re-mask of the planes `rank` owns.  The erosion is evaluated on the reference's
+    Arrayterator z-block grid (inference/inference.py:53), so the sub-volume handed to the kernel starts and
+    ends on block boundaries; every rank holds the whole raw volume, only the accumulator is sharded.
+    Returns (slab uint8 (n_owned, Y, X), prob or None, (lo, hi))."""
+    from .hostlogic import arrayterator_zblock
+
+    Z, Y, X = (int(v) for v in stack_shape)
+    nb = arrayterator_zblock((Z, Y, X))
+    lo, hi = plan.z_owned[rank]
+    hi = min(hi, Z)
+    if hi <= lo:
+        return None, None, (lo, lo)
+    blo, bhi = (lo // nb) * nb, min(-(-hi // nb) * nb, Z)
+    res = engine.finalize(acc[blo:bhi], None if cnt is None else cnt[blo:bhi], vol[blo:bhi], (bhi - blo, Y, X),
+                          threshold, erode_iters, nb, want_prob=want_prob)
+    mask, prob = res if want_prob else (res, None)
+    return mask[lo - blo: hi - blo], (None if prob is None else prob[lo - blo: hi - blo]), (lo, hi)
