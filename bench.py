@@ -108,12 +108,20 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU); see the docstring")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # functional check of the N>1 path on a single GPU: DLV_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # uses gloo (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank + RCCL
+    same_device = os.environ.get("DLV_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from delivr_cfos_amd.engine import HipEngine
     from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, finalize_owned, gather_slabs, make_plan

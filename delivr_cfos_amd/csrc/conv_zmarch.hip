@@ -35,23 +35,26 @@ __device__ __forceinline__ unsigned zm_pack2(float a, float b) {
 constexpr int ZM_TY = 8, ZM_TX = 32, ZM_HY = 10, ZM_HX = 34;
 constexpr int ZM_PLANE = ZM_HY * ZM_HX;  // 340 voxels
 
-template <int CIN>
+template <int CIN, int TYT>
 struct ZmCfg {
+    static constexpr int HY = TYT + 2;
+    static constexpr int PLANE = HY * ZM_HX;     // halo plane voxels
     static constexpr int C8 = CIN / 8;           // chunks
     static constexpr int KP = CIN / 16;          // k-steps per tap
     static constexpr int WELEMS = 27 * KP * 64;  // uint4 elements of weights in LDS
-    static constexpr int PELEMS = C8 * ZM_PLANE; // uint4 elements of one halo plane
+    static constexpr int PELEMS = C8 * PLANE; // uint4 elements of one halo plane
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN, int VB, int MINW, bool LATE, bool PIN, int DIST, int ABL = 0>
-__global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
+template <int CIN, int VB, int MINW, int TYT, bool PIN, int DIST, int ABL = 0>
+__global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                            uint4* __restrict__ out, float* __restrict__ partials, int D,
                                                            int H, int W, int tilesY, int tilesX, int zseg) {
-    using C = ZmCfg<CIN>;
-    constexpr int NT = 512 / VB;                 // threads: 8 rows / VB rows per wave
+    using C = ZmCfg<CIN, TYT>;
+    constexpr bool LATE = false;
+    constexpr int NT = 64 * TYT / VB;            // threads: TYT rows / VB rows per wave
     constexpr int NPRE = (C::PELEMS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* lds_w = reinterpret_cast<uint4*>(smem_raw);
@@ -62,7 +65,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
     const int seg = blockIdx.y;
     const int tile = blockIdx.x;
     const int tx = tile % tilesX, ty = tile / tilesX;
-    const int y0 = ty * ZM_TY, x0 = tx * ZM_TX;
+    const int y0 = ty * TYT, x0 = tx * ZM_TX;
     const int zs = seg * zseg, ze = min(zs + zseg, D);  // output planes [zs, ze)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
         const int i = threadIdx.x + NT * j;
         goff[j] = -1;
         if (i < C::PELEMS) {
-            const int xh = i % ZM_HX, yh = (i / ZM_HX) % ZM_HY, c = i / ZM_PLANE;
+            const int xh = i % ZM_HX, yh = (i / ZM_HX) % C::HY, c = i / C::PLANE;
             const int gy = y0 + yh - 1, gx = x0 + xh - 1;
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
                 const long long base = c < c1_8 ? ((long long)n * c1_8 + c) * vox : ((long long)n * c2_8 + (c - c1_8)) * vox;
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
         }
     }
     auto src_of = [&](int j) -> const uint4* {
-        const int c = (threadIdx.x + NT * j) / ZM_PLANE;
+        const int c = (threadIdx.x + NT * j) / C::PLANE;
         return c < c1_8 ? in1 : in2;
     };
     uint4 pre[NPRE];
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
     // per-lane LDS offsets: voxel block v = row 2*wave + v, column col; chunk half h
     int lb[VB];
 #pragma unroll
-    for (int v = 0; v < VB; ++v) lb[v] = (h * ZM_HY + (VB * wave + v)) * ZM_HX + col;
+    for (int v = 0; v < VB; ++v) lb[v] = (h * C::HY + (VB * wave + v)) * ZM_HX + col;
 
     f32x16 fzero;
 #pragma unroll
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
             const int i = threadIdx.x;
             float v = 0.f;
 #pragma unroll
-            for (int w8 = 0; w8 < 8 / VB; ++w8) v += red[w8 * 64 + i];
+            for (int w8 = 0; w8 < TYT / VB; ++w8) v += red[w8 * 64 + i];
             const long long nparts = (long long)gridDim.x * nzc;
             const long long part = (long long)zc * gridDim.x + tile;
             partials[(((long long)n * nparts + part) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(512 / VB, MINW) conv3_zmarch_kernel(const uint
             auto load_group = [&](int g, uint4(&b)[VB], uint4(&w)[3]) __attribute__((always_inline)) {
                 const int ks = g % C::KP, kx = (g / C::KP) % 3, ky = g / (3 * C::KP);
 #pragma unroll
-                for (int v = 0; v < VB; ++v) b[v] = lds_p[lb[v] + (ks * 2 * ZM_HY + ky) * ZM_HX + kx];
+                for (int v = 0; v < VB; ++v) b[v] = lds_p[lb[v] + (ks * 2 * C::HY + ky) * ZM_HX + kx];
 #pragma unroll
                 for (int kz = 0; kz < 3; ++kz) w[kz] = lds_w[(((kz * 3 + ky) * 3 + kx) * C::KP + ks) * 64 + lane];
             };
@@ -502,69 +505,46 @@ __global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __re
 // returns the number of partial-sum rows per sample (columns) or a negative error
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
                             const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts) {
-    const int tilesY = dlv_cdiv(H, ZM_TY), tilesX = dlv_cdiv(W, ZM_TX);
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("DLV_ZM_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+    // 16-row tiles (8 waves x 2 rows) for the single-source layers unless a variant asks otherwise
+    const int tyt = (cin == 32 && variant != 2 && !(variant >= 10 && variant < 30)) ? 16 : 8;
+    const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, ZM_TX);
     // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
     int zseg = ((D + 15) / 16) * 16;
     while ((long long)B * tilesY * tilesX * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
     const int nseg = dlv_cdiv(D, zseg);
     dim3 grid(tilesY * tilesX, nseg, B);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
-    // kernel variants: VB = voxel blocks (rows) per wave -> 8/VB waves per workgroup; MINW = waves per SIMD the
-    // register allocation is bounded for.  DLV_ZM_VARIANT selects one for A/B timing.
-    static int variant = -1;
-    if (variant < 0) {
-        const char* e = getenv("DLV_ZM_VARIANT");
-        variant = e ? atoi(e) : 0;
-    }
-#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_)                                                                                  \
+    // kernel variants (DLV_ZM_VARIANT selects one for A/B timing): VB rows per wave, TYT tile rows -> TYT/VB waves
+#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_)                                                                                  \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_>,                         \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_>::LDS_BYTES));  \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_>,                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_, TYT_>::LDS_BYTES));  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, LATE_, PIN_, DIST_, ABL_>), grid, dim3(512 / VB_), ZmCfg<CIN_>::LDS_BYTES,       \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
                            (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
-#define DLV_ZM2_LAUNCH(KERNEL_, NSRC_, ABL_)                                                                                       \
-    do {                                                                                                                 \
-        static bool attr_set2 = false;                                                                                   \
-        if (!attr_set2) {                                                                                                \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)KERNEL_<NSRC_, ABL_>,                             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Zm2Cfg<NSRC_>::LDS_BYTES)); \
-            attr_set2 = true;                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL((KERNEL_<NSRC_, ABL_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES, ctx->stream,  \
-                           (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out, partials, D, H, W, \
-                           tilesY, tilesX, zseg);                                                                        \
-    } while (0)
-    if (variant >= 20 && variant < 30 && ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
-        const int abl = variant % 10;
-#define DLV_ZM2_DISPATCH(NSRC_)                                                      \
-    do {                                                                             \
-        if (abl == 1) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 1);                \
-        else if (abl == 2) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 2);           \
-        else if (abl == 3) DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 3);           \
-        else DLV_ZM2_LAUNCH(conv3_zmarch2_kernel, NSRC_, 0);                         \
-    } while (0)
-        if (cin == 32) DLV_ZM2_DISPATCH(1);
-        else DLV_ZM2_DISPATCH(2);
-#undef DLV_ZM2_DISPATCH
-    } else
     if (cin == 32) {
-        if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 1);
-        else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 2);
-        else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 3);
-        else DLV_ZM_LAUNCH(32, 1, 2, false, true, 1, 0);
+        if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1);
+        else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 2);
+        else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 3);
+        else if (variant == 2) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0);
+        else DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0);
     } else if (cin == 64) {
-        if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 1);
-        else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 2);
-        else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 3);
-        else DLV_ZM_LAUNCH(64, 1, 2, false, true, 1, 0);
+        if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 1);
+        else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 2);
+        else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 3);
+        else DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }

@@ -343,7 +343,7 @@ struct ConvTile {
     static constexpr int RV = 32 / TX;       // rows per 32-voxel block
 };
 
-template <int NCB, int TX>
+template <int NCB, int TX, bool WLDS>
 __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict__ in1, int c1_8,
                                                          const uint4* __restrict__ in2, int c2_8,
                                                          const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
     using T = ConvTile<TX>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* slab = reinterpret_cast<uint4*>(smem_raw);
+    uint4* wlds = slab + T::SLAB;  // WLDS: this slab's weights, [cb][tap][k-step][lane]
     const int n = blockIdx.z;
     const int tile = blockIdx.x;
     const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, tz = tile / (tilesX * tilesY);
@@ -397,6 +398,15 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
             }
             slab[i] = v;
         }
+        if (WLDS) {
+            // the slab's weights are fetched cooperatively in one coalesced sweep (deep levels have few
+            // workgroups: per-k-step fragment loads from L2 are latency-bound there)
+            for (int i = threadIdx.x; i < NCB * 27 * 2 * 64; i += 256) {
+                const int l = i & 63, ks = (i >> 6) & 1, r = i >> 7;
+                const int t = r % 27, cb = r / 27;
+                wlds[i] = wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + sl * 2 + ks) * 64 + l];
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz)
@@ -412,7 +422,8 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
                         bf16x8 a[NCB];
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb) {
-                            const uint4 u = wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
+                            const uint4 u = WLDS ? wlds[((cb * 27 + t) * 2 + ks) * 64 + lane]
+                                                 : wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
                             a[cb] = __builtin_bit_cast(bf16x8, u);
                         }
                         bf16x8 b[2];
@@ -634,6 +645,71 @@ __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d k2 s2, row-contiguous form: the 32 MFMA columns are 32 CONSECUTIVE OUTPUT voxels of one
+// output row (input voxel = column >> 1, x-parity = column & 1).  The parity-dependent weights are applied
+// with two MFMAs per k-step on parity-masked copies of the input fragment, and permlane32_swap joins the
+// two half-wave channel quads, so that every store is 16 bytes per lane and 512 contiguous bytes per
+// half-wave (the per-parity form above writes 8-byte halves at a stride of two voxels).
+// ---------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
+                                                           const float* __restrict__ bias, uint4* __restrict__ out,
+                                                           int cout, int D, int H, int W, int segs) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long vox = (long long)D * H * W;
+    const long long item = (long long)blockIdx.x * 4 + wave;  // (z, y, x-segment of 16 input voxels)
+    const long long nitems = (long long)D * H * segs;
+    if (item >= nitems) return;
+    const int sg = (int)(item % segs), y = (int)((item / segs) % H), z = (int)(item / ((long long)segs * H));
+    const int xi = sg * 16 + (col >> 1);
+    const bool ok = xi < W;
+    const bool odd = col & 1;
+    const long long vin = ((long long)z * H + y) * W + (ok ? xi : 0);
+    bf16x8 b0[KP], b1[KP];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        const uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vin];
+        b0[kp] = __builtin_bit_cast(bf16x8, (ok && !odd) ? u : zero4);
+        b1[kp] = __builtin_bit_cast(bf16x8, (ok && odd) ? u : zero4);
+    }
+    const int CB = cout / 32, cout8 = cout / 8;
+    const int OH = 2 * H, OW = 2 * W;
+    const long long ovox = vox * 8;
+    const int ox = 2 * sg * 16 + col;
+    for (int ab = 0; ab < 4; ++ab) {
+        const long long o = ((long long)(2 * z + (ab >> 1)) * OH + (2 * y + (ab & 1))) * OW + ox;
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias[cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                const uint4 w0 = wpk[(((long long)(ab * 2 + 0) * CB + cb) * KP + kp) * 64 + lane];
+                const uint4 w1 = wpk[(((long long)(ab * 2 + 1) * CB + cb) * KP + kp) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), b0[kp], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), b1[kp], acc, 0, 0, 0);
+            }
+            unsigned px[4], py[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                px[g] = pack2(acc[4 * g + 0], acc[4 * g + 1]);
+                py[g] = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+            }
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                // lanes 0-31 end up with all 8 channels of chunk gp, lanes 32-63 with chunk gp+1
+                const auto sx = __builtin_amdgcn_permlane32_swap(px[gp], px[gp + 1], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(py[gp], py[gp + 1], false, false);
+                if (ok) out[((long long)n * cout8 + cb * 4 + gp + h) * ovox + o] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // final: InstanceNorm + Mish of the last block, Conv3d(C5 -> 1, k1), then either plain logits or
 // the blend accumulate of inference/sliding_window_inferer.py:232-251 (acc[window] += logit, un-flipped)
 // ---------------------------------------------------------------------------------------------------
@@ -752,30 +828,37 @@ struct Bf16Net {
         const int TX = tx16 ? 16 : 8, TY = 64 / TX;
         const int tZ = dlv_cdiv(d.D, 4), tY = dlv_cdiv(d.H, TY), tX = dlv_cdiv(d.W, TX);
         const int ntiles = tZ * tY * tX;
-        // cout blocks per workgroup: as many as keeps >= 2 workgroups per CU in flight (the deep levels
-        // have few voxel tiles; there the grid is widened over output channels instead)
-        int ncb = L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1);
+        // cout blocks per workgroup: up to 2 with LDS-staged weights (2 x 54 KB + input slab fit 160 KB), fewer when
+        // that would leave CUs idle (the deep levels have few voxel tiles; the grid is widened over cout instead)
+        int ncb = L.cout >= 64 ? 2 : 1;
         while (ncb > 1 && (long long)B * ntiles * (L.cout / (32 * ncb)) < 512) ncb >>= 1;
         if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
-        const size_t lds = std::max<size_t>((size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16,
-                                            (size_t)4 * ncb * 32 * 2 * 4);
+        const size_t slab_bytes = (size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16;
+        const size_t lds = std::max<size_t>(slab_bytes + (size_t)ncb * 27 * 2 * 64 * 16, (size_t)4 * ncb * 32 * 2 * 4);
         dim3 grid(ntiles, L.cout / (32 * ncb), B);
         const double flops = 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B;
         const double bytes = 2.0 * (double)d.vox() * B * (L.cin + L.cout);
         char name[48];
         snprintf(name, sizeof(name), "conv3_mfma_bf16_c%dx%d", L.cin, L.cout);
         DlvProf pr(ctx, name, flops, bytes);
-#define DLV_CONV_LAUNCH(NCB_, TX_)                                                                                    \
-    hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2, c2 / 8,    \
-                       reinterpret_cast<const uint4*>(L.w_bf16), L.bias, out, partials, L.cout, d.D, d.H, d.W, tY, tX)
+#define DLV_CONV_LAUNCH(NCB_, TX_)                                                                                       \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<NCB_, TX_, true>,                            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_, true>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,    \
+                           c2 / 8, reinterpret_cast<const uint4*>(L.w_bf16), L.bias, out, partials, L.cout, d.D, d.H,    \
+                           d.W, tY, tX);                                                                                 \
+    } while (0)
         if (tx16) {
             if (ncb == 1) DLV_CONV_LAUNCH(1, 16);
-            else if (ncb == 2) DLV_CONV_LAUNCH(2, 16);
-            else DLV_CONV_LAUNCH(4, 16);
+            else DLV_CONV_LAUNCH(2, 16);
         } else {
             if (ncb == 1) DLV_CONV_LAUNCH(1, 8);
-            else if (ncb == 2) DLV_CONV_LAUNCH(2, 8);
-            else DLV_CONV_LAUNCH(4, 8);
+            else DLV_CONV_LAUNCH(2, 8);
         }
 #undef DLV_CONV_LAUNCH
         pr.end();
@@ -799,19 +882,31 @@ struct Bf16Net {
 
     int deconv(int j, const uint4* in, uint4* out, Dims din) {
         const DlvDeconvLayer& L = ctx->deconv[j];
-        dim3 grid(dlv_cdiv(din.vox(), 128), B);
         const uint4* w = reinterpret_cast<const uint4*>(L.w_bf16);
+        const bool rows = !ctx->no_zmarch;
+        const int segs = dlv_cdiv(din.W, 16);
+        dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
         DlvProf pr(ctx, "deconv2_mfma_bf16", 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
                    2.0 * (double)din.vox() * B * (L.cin + 8.0 * L.cout));
+#define DLV_DECONV(KP_)                                                                                                  \
+    do {                                                                                                                 \
+        if (rows)                                                                                                        \
+            hipLaunchKernelGGL(deconv2_rows_kernel<KP_>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
+                               din.D, din.H, din.W, segs);                                                               \
+        else                                                                                                             \
+            hipLaunchKernelGGL(deconv2_mfma_kernel<KP_>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
+                               din.D, din.H, din.W);                                                                     \
+    } while (0)
         switch (L.cin / 16) {
-            case 2: hipLaunchKernelGGL(deconv2_mfma_kernel<2>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
-            case 4: hipLaunchKernelGGL(deconv2_mfma_kernel<4>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
-            case 8: hipLaunchKernelGGL(deconv2_mfma_kernel<8>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
-            case 16: hipLaunchKernelGGL(deconv2_mfma_kernel<16>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W); break;
+            case 2: DLV_DECONV(2); break;
+            case 4: DLV_DECONV(4); break;
+            case 8: DLV_DECONV(8); break;
+            case 16: DLV_DECONV(16); break;
             default: return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: Cin=%d not in {32,64,128,256}", j, L.cin);
         }
+#undef DLV_DECONV
         pr.end();
-        DLV_LAUNCH_CHECK(ctx, "deconv2_mfma_kernel");
+        DLV_LAUNCH_CHECK(ctx, "deconv2 kernel");
         return DLV_OK;
     }
 };

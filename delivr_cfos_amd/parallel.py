@@ -102,26 +102,36 @@ def make_plan(starts: np.ndarray, roi_z: int, Zp: int, world: int) -> ShardPlan:
     return ShardPlan(world, n, win_ranges, z_computed, owned)
 
 
+def _needs_host_staging(t, dist) -> bool:
+    """gloo moves CPU tensors only for point-to-point; RCCL ("nccl") moves HBM directly over xGMI."""
+    try:
+        return bool(t.is_cuda) and dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
 def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None) -> None:
     """acc: (Zp, Yp, Xp) fp32 tensor (full padded extent on every rank; only the computed planes are
     non-zero).  After the call the planes owned by `rank` hold the complete sum.  Contributions are
     added in increasing source-rank order so that the result does not depend on arrival order."""
     import torch
 
+    stage = _needs_host_staging(acc, dist)
     sends = plan.sends(rank)
     recvs = plan.recvs(rank)
     ops, bufs = [], []
     for dst, lo, hi in sends:
-        ops.append(dist.P2POp(dist.isend, acc[lo:hi].contiguous(), dst, group=group))
+        t = acc[lo:hi].contiguous()
+        ops.append(dist.P2POp(dist.isend, t.cpu() if stage else t, dst, group=group))
     for src, lo, hi in recvs:
-        buf = torch.empty_like(acc[lo:hi])
+        buf = torch.empty_like(acc[lo:hi], device="cpu") if stage else torch.empty_like(acc[lo:hi])
         bufs.append((src, lo, hi, buf))
         ops.append(dist.P2POp(dist.irecv, buf, src, group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for src, lo, hi, buf in sorted(bufs, key=lambda t: t[0]):
-        acc[lo:hi] += buf
+        acc[lo:hi] += buf.to(acc.device) if stage else buf
 
 
 def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]] = None, src: int = 0, group=None) -> None:
@@ -145,7 +155,8 @@ def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0,
     """Mask slabs (planes z_owned[r]) -> one (Z, Y, X) tensor on rank `dst` (point-to-point)."""
     import torch
 
-    ops = []
+    stage = _needs_host_staging(slab if slab is not None else out, dist)
+    ops, landed = [], []
     if rank == dst:
         for r in range(plan.world):
             lo, hi = plan.z_owned[r]
@@ -154,14 +165,21 @@ def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0,
                 continue
             if r == dst:
                 out[lo:hi] = slab[: hi - lo]
+            elif stage:
+                buf = torch.empty_like(out[lo:hi], device="cpu")
+                landed.append((lo, hi, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group=group))
             else:
                 ops.append(dist.P2POp(dist.irecv, out[lo:hi], r, group=group))
     else:
-        if slab.numel():
-            ops.append(dist.P2POp(dist.isend, slab.contiguous(), dst, group=group))
+        if slab is not None and slab.numel():
+            t = slab.contiguous()
+            ops.append(dist.P2POp(dist.isend, t.cpu() if stage else t, dst, group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    for lo, hi, buf in landed:
+        out[lo:hi] = buf.to(out.device)
     return out
 
 
