@@ -511,7 +511,8 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         variant = e ? atoi(e) : 0;
     }
     // 16-row tiles (8 waves x 2 rows) for the single-source layers unless a variant asks otherwise
-    const int tyt = (cin == 32 && variant != 2 && !(variant >= 10 && variant < 30)) ? 16 : 8;
+    // 16-row tiles (8 waves x 2 rows) only as A/B variant 3: measured equal/slower than 8 rows x 1 (profiles/README.md)
+    const int tyt = (cin == 32 && variant == 3) ? 16 : 8;
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, ZM_TX);
     // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
     int zseg = ((D + 15) / 16) * 16;
@@ -538,8 +539,8 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1);
         else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 2);
         else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 3);
-        else if (variant == 2) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0);
-        else DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0);
+        else if (variant == 3) DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0);
+        else DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0);
     } else if (cin == 64) {
         if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 1);
         else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 2);

@@ -112,8 +112,7 @@ def test_cli_steps_2_and_3(tmp_path, precision, tta):
     stats = pickle.load(open(os.path.join(post, f"{brain}-stats.pickle"), "rb"))
     ref_stats = orc.cc_stats(lab_ref, n_ref)
     np.testing.assert_array_equal(stats["voxel_counts"][1:], ref_stats["voxel_counts"][1:])
-    csv = [f for f in os.listdir(os.path.join(root, "out")) if f.endswith(".csv")]
-    csv_path = os.path.join(root, "out", csv[0]) if csv else post + f"{vol.shape}_{brain}.csv"
+    csv_path = os.path.join(post, f"{vol.shape}_{brain}.csv")  # path_out ends with '/', so the file sits inside it
     assert os.path.isfile(csv_path), files
     assert open(csv_path).read() == orc.cells_csv_text(ref_stats, n_ref)
 
