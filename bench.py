@@ -234,12 +234,20 @@ def main():
         # (profiles/run_pmc_traffic.sh; FETCH_SIZE doubled as the gfx950 guide prescribes), if available
         try:
             tfile = os.path.join(ROOT, "profiles", f"traffic_r01_{args.workload}.json")
+            scaled = False
+            if not os.path.isfile(tfile):  # PMC passes exist for the 512^3 workload only (25k launches at C3 exceed the
+                tfile = os.path.join(ROOT, "profiles", "traffic_r01_c2.json")  # time limit): same kernels, same batch of 16
+                scaled = True
             if os.path.isfile(tfile) and not args.dense and args.sw_batch == 0:
                 tj = json.load(open(tfile))
                 if name in tj["kernels"]:
-                    roofline["traffic"] = tj["kernels"][name]["traffic_bytes"]
-                    roofline["traffic_source"] = os.path.relpath(tfile, ROOT)
                     roofline["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
+                    t = tj["kernels"][name]["traffic_bytes"]
+                    if scaled and "algorithmic_bytes" in tj["kernels"][name]:
+                        t *= roofline["algorithmic_bytes"] / tj["kernels"][name]["algorithmic_bytes"]
+                    roofline["traffic"] = t
+                    roofline["traffic_source"] = os.path.relpath(tfile, ROOT) + (
+                        " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "")
         except Exception:
             pass
         roofline["lanes"] = 1 if os.environ.get("DLV_ONE_LANE") else 2
