@@ -46,7 +46,7 @@ struct ZmCfg {
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN, int VB, int MINW, int TYT, bool PIN, int DIST, int ABL = 0>
+template <int CIN, int VB, int MINW, int TYT, bool PIN, int DIST, int ABL = 0, bool STAG = false>
 __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -170,11 +170,56 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
         __syncthreads();
     };
 
+    // STAG: the second wave of every SIMD (waves NW/2..NW-1) handles its epilogue one step late, at the start of
+    // the next step, so that on each SIMD one wave's VALU/store work overlaps the other wave's MFMAs
+    const bool late_wave = STAG && (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NT / 2);
+    auto epilogue = [&](f32x16(&acc)[VB], int oz) __attribute__((always_inline)) {
+        const bool emit = !(ABL & 1) && oz >= zs && oz < ze;
+        if (ABL & 1) {
+#pragma unroll
+            for (int v = 0; v < VB; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[v][r]));
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            const int oy = y0 + VB * wave + v, ox = x0 + col;
+            const bool ok = emit && oy < H && ox < W;
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                val[r] = acc[v][r] + bs[r];
+                if (ok) {
+                    ssum[r] += val[r];
+                    ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                }
+            }
+            if (ok) {
+                const long long o = (long long)oz * plane + (long long)oy * W + ox;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                    dst[h] = u;
+                }
+            }
+        }
+    };
+
     // one z step: plane p is in LDS (when 0 <= p < D).  kz=2 -> accA (out[p-1]), kz=1 -> accB (out[p]),
     // kz=0 -> accC (out[p+1], started here).  Then out[p-1] is emitted from accA.
     auto step = [&](int p, f32x16(&accA)[VB], f32x16(&accB)[VB], f32x16(&accC)[VB]) __attribute__((always_inline)) {
         const bool next_needed = !(ABL & 2) && (p + 1 <= ze) && (p + 1 >= 0) && (p + 1 < D);
         if (next_needed) issue_loads(p + 1);
+        if (STAG) {
+            if (late_wave) epilogue(accC, p - 2);  // accC still holds the plane finished one step ago
+            // every wave has now added exactly the planes <= p-2: the only cut at which a statistics chunk is
+            // complete for both wave groups (keeps the partial sums independent of zseg / batch size)
+            const int ozf = p - 2;
+            if (!(ABL & 1) && ozf >= zs && ozf < ze && ((ozf & 15) == 15 || ozf == ze - 1)) flush_stats(ozf >> 4);
+        }
         if (p >= 0 && p < D && p <= ze) {
             // software-pipelined over the 9*KP (ky,kx,ks) groups: the 5 LDS fragment reads of group g+1
             // are issued before the 6 MFMAs of group g (one wave per SIMD: nothing else hides LDS latency)
@@ -211,59 +256,15 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
 #pragma unroll
             for (int v = 0; v < VB; ++v) accC[v] = fzero;
         }
-        // epilogue part 1 (registers only): bias, statistics, bf16 packing of output plane p-1
-        const int oz = p - 1;
-        const bool emit = oz >= zs && oz < ze;
-        uint2 ost[VB][4];
-        bool okv[VB];
-        if (ABL & 1) {  // timing-only build: no epilogue (accumulators kept alive, outputs are garbage)
-#pragma unroll
-            for (int v = 0; v < VB; ++v)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(accA[v][r]));
+        // early waves (and every wave when !STAG) finish output plane p-1 here; late waves did plane p-2 above
+        if (!STAG || !late_wave) epilogue(accA, p - 1);
+        if (!STAG) {
+            const int ozf = p - 1;
+            if (!(ABL & 1) && ozf >= zs && ozf < ze && ((ozf & 15) == 15 || ozf == ze - 1)) flush_stats(ozf >> 4);
         }
-#pragma unroll
-        for (int v = 0; v < VB; ++v) {
-            const int oy = y0 + VB * wave + v, ox = x0 + col;
-            okv[v] = !(ABL & 1) && emit && oy < H && ox < W;
-            float val[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                val[r] = accA[v][r] + bs[r];
-                if (okv[v]) {
-                    ssum[r] += val[r];
-                    ssq[r] = fmaf(val[r], val[r], ssq[r]);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                ost[v][g].x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
-                ost[v][g].y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
-            }
-        }
-        auto store_out = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int v = 0; v < VB; ++v) {
-                if (okv[v]) {
-                    const int oy = y0 + VB * wave + v, ox = x0 + col;
-                    const long long o = (long long)oz * plane + (long long)oy * W + ox;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
-                        dst[h] = ost[v][g];
-                    }
-                }
-            }
-        };
-        if (!LATE) store_out();
-        if (emit && ((oz & 15) == 15 || oz == ze - 1)) flush_stats(oz >> 4);
         __syncthreads();  // every wave is done reading plane p
         if (next_needed) write_plane();
         __syncthreads();
-        // epilogue part 2: the global stores go out AFTER the next plane is staged, so that their
-        // completion latency overlaps the next step's MFMAs instead of sitting in front of the LDS write
-        // (vmcnt counts stores too: waiting for the staged loads would otherwise wait for these stores)
-        if (LATE) store_out();
     };
 
     // prologue: first input plane of the segment (zs-1, or zs when zs == 0)
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
         __syncthreads();
     }
     // steps beyond ze are no-ops (compute, loads and emit are all guarded), so the triple needs no branches
-    for (int p = zs - 1; p <= ze; p += 3) {
+    for (int p = zs - 1; p <= ze + (STAG ? 1 : 0); p += 3) {
         step(p, a0, a1, a2);
         step(p + 1, a1, a2, a0);
         step(p + 2, a2, a0, a1);
@@ -521,31 +522,33 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
     dim3 grid(tilesY * tilesX, nseg, B);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
     // kernel variants (DLV_ZM_VARIANT selects one for A/B timing): VB rows per wave, TYT tile rows -> TYT/VB waves
-#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_)                                                                                  \
+#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_)                                                                                  \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_>,                         \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>,                         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_, TYT_>::LDS_BYTES));  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
                            (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
     if (cin == 32) {
-        if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1);
-        else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 2);
-        else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 3);
-        else if (variant == 3) DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0);
-        else DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0);
+        if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1, false);
+        else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 2, false);
+        else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 3, false);
+        else if (variant == 3) DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0, false);
+        else if (variant == 4) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0, true);
+        else DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0, false);
     } else if (cin == 64) {
-        if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 1);
-        else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 2);
-        else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 3);
-        else DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0);
+        if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 1, false);
+        else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 2, false);
+        else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 3, false);
+        else if (variant == 4) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0, true);
+        else DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0, false);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }

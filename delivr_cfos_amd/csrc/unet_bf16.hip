@@ -828,37 +828,49 @@ struct Bf16Net {
         const int TX = tx16 ? 16 : 8, TY = 64 / TX;
         const int tZ = dlv_cdiv(d.D, 4), tY = dlv_cdiv(d.H, TY), tX = dlv_cdiv(d.W, TX);
         const int ntiles = tZ * tY * tX;
-        // cout blocks per workgroup: up to 2 with LDS-staged weights (2 x 54 KB + input slab fit 160 KB), fewer when
-        // that would leave CUs idle (the deep levels have few voxel tiles; the grid is widened over cout instead)
-        int ncb = L.cout >= 64 ? 2 : 1;
+        // Two weight paths (A/B in profiles/README.md): fragments straight from L2 (levels 2-3: enough workgroups to
+        // hide the latency; up to 4 cout blocks per workgroup) or the slab's weights staged through LDS in one
+        // coalesced sweep (the 8^3 level: few workgroups, per-k-step fragment loads are latency-bound there).
+        const bool wlds = d.vox() <= 1024;
+        int ncb = wlds ? (L.cout >= 64 ? 2 : 1) : (L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1));
         while (ncb > 1 && (long long)B * ntiles * (L.cout / (32 * ncb)) < 512) ncb >>= 1;
         if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
         const size_t slab_bytes = (size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16;
-        const size_t lds = std::max<size_t>(slab_bytes + (size_t)ncb * 27 * 2 * 64 * 16, (size_t)4 * ncb * 32 * 2 * 4);
+        const size_t lds = std::max<size_t>(slab_bytes + (wlds ? (size_t)ncb * 27 * 2 * 64 * 16 : 0), (size_t)4 * ncb * 32 * 2 * 4);
         dim3 grid(ntiles, L.cout / (32 * ncb), B);
         const double flops = 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B;
         const double bytes = 2.0 * (double)d.vox() * B * (L.cin + L.cout);
         char name[48];
         snprintf(name, sizeof(name), "conv3_mfma_bf16_c%dx%d", L.cin, L.cout);
         DlvProf pr(ctx, name, flops, bytes);
-#define DLV_CONV_LAUNCH(NCB_, TX_)                                                                                       \
+#define DLV_CONV_LAUNCH(NCB_, TX_, WLDS_)                                                                                \
     do {                                                                                                                 \
         static bool attr_done = false;                                                                                   \
         if (!attr_done) {                                                                                                \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<NCB_, TX_, true>,                            \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<NCB_, TX_, WLDS_>,                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_done = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_, true>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,    \
+        hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
                            c2 / 8, reinterpret_cast<const uint4*>(L.w_bf16), L.bias, out, partials, L.cout, d.D, d.H,    \
                            d.W, tY, tX);                                                                                 \
     } while (0)
-        if (tx16) {
-            if (ncb == 1) DLV_CONV_LAUNCH(1, 16);
-            else DLV_CONV_LAUNCH(2, 16);
+        if (wlds) {
+            if (tx16) {
+                if (ncb == 1) DLV_CONV_LAUNCH(1, 16, true);
+                else DLV_CONV_LAUNCH(2, 16, true);
+            } else {
+                if (ncb == 1) DLV_CONV_LAUNCH(1, 8, true);
+                else DLV_CONV_LAUNCH(2, 8, true);
+            }
+        } else if (tx16) {
+            if (ncb == 1) DLV_CONV_LAUNCH(1, 16, false);
+            else if (ncb == 2) DLV_CONV_LAUNCH(2, 16, false);
+            else DLV_CONV_LAUNCH(4, 16, false);
         } else {
-            if (ncb == 1) DLV_CONV_LAUNCH(1, 8);
-            else DLV_CONV_LAUNCH(2, 8);
+            if (ncb == 1) DLV_CONV_LAUNCH(1, 8, false);
+            else if (ncb == 2) DLV_CONV_LAUNCH(2, 8, false);
+            else DLV_CONV_LAUNCH(4, 8, false);
         }
 #undef DLV_CONV_LAUNCH
         pr.end();

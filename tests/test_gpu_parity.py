@@ -214,3 +214,28 @@ def test_errors_are_reported_not_crashed(eng):
     with pytest.raises(DelivrHipError):
         fresh.unet_forward(x, "fp32")  # no weights loaded
     fresh.close()
+
+
+@pytest.mark.parametrize("shape,roi,overlap", [((48, 40, 40), (32, 32, 16), 0.25), ((40, 48, 56), (32, 32, 32), 0.5),
+                                               ((32, 32, 48), (32, 32, 16), 0.6)])
+def test_sw_pass_clamped_windows_and_other_overlaps(eng_w, net, shape, roi, overlap):
+    """Volumes that are NOT a multiple of the scan interval: the last window of a dimension is clamped back
+    (MONAI dense_patch_slices), so windows of equal parity may overlap - the colour classes must still be
+    race-free and the sums equal the oracle's."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    vol = synth_volume_np(shape, seed=31, dense=True)
+    vol[:, :, : shape[2] // 3] = 0
+    ref = np.zeros(shape, dtype=np.float32)
+    cref = np.zeros(shape, dtype=np.uint8)
+    info = orc.sliding_window_pass(vol, roi, lambda x: orc.unet_forward(net, x), ref, cref, overlap, None, 1, fp16=False)
+    acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    st = eng_w.sw_infer(eng_w.make_sw_params(shape, roi, overlap, None, 0, "fp32", sw_batch=4), eng_w.to_device(vol), acc, cnt)
+    eng_w.sync()
+    assert st["n_windows"] == info["n_windows"] and st["n_skipped"] == info["n_skipped"]
+    np.testing.assert_array_equal(cnt.cpu().numpy(), cref)
+    assert np.abs(acc.cpu().numpy() - ref).max() < 2e-3
+    np.testing.assert_array_equal(eng_w.window_starts(eng_w.make_sw_params(shape, roi, overlap)), orc.window_list(shape, roi, overlap))
