@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +142,13 @@ def main():
     torch.cuda.synchronize()
     params_all = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch)
     starts = eng.window_starts(params_all)
-    plan = make_plan(starts, roi[0], Z, world)
+    # shards balanced by the windows that actually run the network (a brain fills the central Z-slabs, not the
+    # outer ones); every rank holds the whole volume, so every rank derives the same plan
+    weights = None
+    if world > 1:
+        wmax = eng.window_max(params_all, vol)
+        weights = np.where(wmax > 0, 1.0, 0.02)
+    plan = make_plan(starts, roi[0], Z, world, weights)
     wb, we = plan.win_ranges[rank]
     params = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, win_range=(wb, we))
     if we <= wb:  # a rank without windows still takes part in the exchange
@@ -210,51 +217,66 @@ def main():
     n_active = n_windows - n_skipped
     tile_vox = float(roi[0] * roi[1] * roi[2])
 
-    # ---- roofline of the dominant kernel (rank 0's HIP-event timings over the timed steps) ----------
-    roofline = None
-    kernels = {}
-    if prof:
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    # ---- roofline of the dominant kernel (rank 0's HIP-event timings) -----------------------------------
+    def roofline_of(prof, lanes, steps_covered):
+        if not prof:
+            return None, {}
+        kernels = {}
         for name, e in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
             kernels[name] = {"launches": e["launches"], "total_ms": round(e["total_ms"], 3),
                              "avg_us": round(1e3 * e["total_ms"] / max(e["launches"], 1), 2)}
-        name, e = dom
+        name, e = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         avg_s = 1e-3 * e["total_ms"] / max(e["launches"], 1)
         if e["flops"] > 0 and name.startswith(("conv3_", "deconv2_mfma")):
             ach = e["flops"] / max(e["launches"], 1) / avg_s / 1e12
-            roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                        "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
+            r = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
         else:
             ach = e["bytes"] / max(e["launches"], 1) / avg_s / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                        "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
-        # HBM traffic per launch of that kernel from the committed PMC passes of this same command
-        # (profiles/run_pmc_traffic.sh; FETCH_SIZE doubled as the gfx950 guide prescribes), if available
+            r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
+        # HBM traffic per launch of that kernel from the committed PMC passes (profiles/run_pmc_traffic.sh; FETCH_SIZE
+        # doubled as the gfx950 guide prescribes).  PMC passes exist for the 512^3 workload (25k launches at C3 exceed the
+        # time limit): same kernels, same batch of 16 -> scaled by algorithmic bytes per launch.
         try:
             tfile = os.path.join(ROOT, "profiles", f"traffic_r01_{args.workload}.json")
             scaled = False
-            if not os.path.isfile(tfile):  # PMC passes exist for the 512^3 workload only (25k launches at C3 exceed the
-                tfile = os.path.join(ROOT, "profiles", "traffic_r01_c2.json")  # time limit): same kernels, same batch of 16
+            if not os.path.isfile(tfile):
+                tfile = os.path.join(ROOT, "profiles", "traffic_r01_c2.json")
                 scaled = True
             if os.path.isfile(tfile) and not args.dense and args.sw_batch == 0:
                 tj = json.load(open(tfile))
                 if name in tj["kernels"]:
-                    roofline["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
+                    r["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
                     t = tj["kernels"][name]["traffic_bytes"]
                     if scaled and "algorithmic_bytes" in tj["kernels"][name]:
-                        t *= roofline["algorithmic_bytes"] / tj["kernels"][name]["algorithmic_bytes"]
-                    roofline["traffic"] = t
-                    roofline["traffic_source"] = os.path.relpath(tfile, ROOT) + (
+                        t *= r["algorithmic_bytes"] / tj["kernels"][name]["algorithmic_bytes"]
+                    r["traffic"] = t
+                    r["traffic_source"] = os.path.relpath(tfile, ROOT) + (
                         " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "")
         except Exception:
             pass
-        roofline["lanes"] = 1 if os.environ.get("DLV_ONE_LANE") else 2
-        # whole-forward MFMA fraction as a second figure
+        r["lanes"] = lanes
         net_ms = sum(v["total_ms"] for v in prof.values())
-        roofline["forward_tflops"] = FLOP_PER_PATCH_VOXEL * tile_vox * n_active * args.steps / (1e-3 * net_ms) / 1e12 \
-            if net_ms > 0 and world == 1 else None
+        r["forward_tflops"] = (FLOP_PER_PATCH_VOXEL * tile_vox * n_active * steps_covered / (1e-3 * net_ms) / 1e12
+                               if net_ms > 0 and world == 1 and lanes == 1 else None)
+        return r, kernels
+
+    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else 2
+    roofline, kernels = roofline_of(prof, lanes_used, args.steps)
+    # the timed region runs two overlapping lanes, which stretches every kernel's event-to-event time; one extra,
+    # untimed step on a single lane gives the dominant kernel's own efficiency
+    roofline_isolated = None
+    if prof and lanes_used == 2 and not args.no_isolated and world == 1:
+        eng.set_lanes(1)
+        eng.prof_reset()
+        eng.prof_enable(True)
+        step()
+        fence()
+        prof1 = eng.prof_report()
+        eng.prof_enable(False)
+        eng.set_lanes(2)
+        roofline_isolated, _ = roofline_of(prof1, 1, 1)
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -294,6 +316,7 @@ def main():
             "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
         },
         "roofline": roofline,
+        "roofline_isolated": roofline_isolated,
         "cpu_baseline": cpu,
         "kernels": kernels,
     }

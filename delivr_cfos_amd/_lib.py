@@ -83,6 +83,7 @@ SIGNATURES = {
     "dlv_unet_forward_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dlv_sw_num_windows": (C.c_int, [C.POINTER(SwParams), C.POINTER(C.c_int64)]),
     "dlv_sw_window_starts": (C.c_int, [C.POINTER(SwParams), C.POINTER(C.c_int64), C.c_int64]),
+    "dlv_sw_window_max_dev": (C.c_int, [_P, C.POINTER(SwParams), _P, C.POINTER(C.c_int32), C.c_int64]),
     "dlv_sw_infer_dev": (C.c_int, [_P, C.POINTER(SwParams), _P, _P, _P, C.POINTER(SwStats)]),
     "dlv_finalize_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                    C.c_int, _P, _P]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "dlv_trilinear_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_debug_layer_bf16": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int]),
+    "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
     "dlv_prof_reset": (C.c_int, [_P]),
     "dlv_prof_report": (C.c_int, [_P, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),

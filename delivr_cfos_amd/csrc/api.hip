@@ -360,6 +360,12 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
 }
 
+int dlv_set_lanes(dlv_ctx* ctx, int lanes) {
+    if (!ctx || lanes < 1 || lanes > 2) return DLV_EINVAL;
+    ctx->lanes_wanted = lanes;
+    return DLV_OK;
+}
+
 int dlv_prof_enable(dlv_ctx* ctx, int on) {
     if (!ctx) return DLV_EINVAL;
     if (!on) DLV_TRY(prof_drain(ctx));

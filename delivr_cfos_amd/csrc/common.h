@@ -62,6 +62,7 @@ struct dlv_ctx {
     hipStream_t aux_stream = nullptr;   // second lane: batches alternate between the two so that the
                                         // HBM-bound kernels of one batch overlap the MFMA kernels of the other
     int lane = 0;
+    int lanes_wanted = 2;
     hipEvent_t ev_main = nullptr, ev_aux = nullptr;  // lane joins
     bool own_stream = false;
     std::string err;

@@ -182,6 +182,40 @@ int dlv_sw_window_starts(const dlv_sw_params* p, int64_t* starts, int64_t capaci
     return DLV_OK;
 }
 
+int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, int32_t* wmax, int64_t capacity) {
+    if (!ctx || !p || !vol_dev || !wmax) return DLV_EINVAL;
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    Tiler t;
+    DLV_TRY(build_tiler(ctx, p, t));
+    const int64_t n = t.count();
+    if (capacity < n) return dlv_fail(ctx, DLV_EINVAL, "wmax capacity %lld < %lld windows", (long long)capacity, (long long)n);
+    if (n > (int64_t)1 << 30) return dlv_fail(ctx, DLV_EUNSUP, "too many windows");
+    const int z0 = p->nz > 0 ? p->z0 : 0, nz = p->nz > 0 ? p->nz : p->Zp;
+    std::vector<int> starts((size_t)n * 3);
+    int64_t i = 0;
+    for (int z : t.st[0])
+        for (int y : t.st[1])
+            for (int x : t.st[2]) {
+                if (z < z0 || z + t.roi[0] > z0 + nz) return dlv_fail(ctx, DLV_EINVAL, "window outside the slab");
+                starts[3 * i] = z - z0;
+                starts[3 * i + 1] = y;
+                starts[3 * i + 2] = x;
+                ++i;
+            }
+    int* meta;
+    DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, (size_t)n * 4 * sizeof(int), (void**)&meta));
+    DLV_HIP(ctx, hipMemcpyAsync(meta, starts.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    DLV_HIP(ctx, hipMemsetAsync(meta + n * 3, 0, (size_t)n * sizeof(int), ctx->stream));
+    const long long tile_vox = (long long)t.roi[0] * t.roi[1] * t.roi[2];
+    const int chunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 8 * 4), 1), 64);
+    hipLaunchKernelGGL(window_max_kernel, dim3(chunks, (unsigned)n), dim3(256), 0, ctx->stream, vol_dev, p->Yp, p->Xp, meta,
+                       t.roi[0], t.roi[1], t.roi[2], meta + n * 3);
+    DLV_LAUNCH_CHECK(ctx, "window_max_kernel");
+    DLV_HIP(ctx, hipMemcpyAsync(wmax, meta + n * 3, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+
 int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev, uint8_t* cnt_dev,
                      dlv_sw_stats* stats) {
     if (!ctx || !p || !vol_dev || !acc_dev) return DLV_EINVAL;
@@ -289,7 +323,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     // convolutions of the other.  Windows of one colour class are disjoint, so their blends may run
     // concurrently; the lanes are joined at every class boundary, which keeps the per-voxel summation
     // order (colour by colour) and therefore the bits of the result.
-    const bool two_lanes = p->precision == DLV_PREC_BF16 && ctx->aux_stream != nullptr;
+    const bool two_lanes = p->precision == DLV_PREC_BF16 && ctx->aux_stream != nullptr && ctx->lanes_wanted == 2;
     hipEvent_t ev_main = ctx->ev_main, ev_aux = ctx->ev_aux;
     auto join_lanes = [&]() -> int {
         if (!two_lanes) return DLV_OK;

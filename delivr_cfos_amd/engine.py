@@ -237,6 +237,16 @@ class HipEngine:
             raise DelivrHipError(rc, "dlv_sw_window_starts failed")
         return buf
 
+    def window_max(self, params, vol) -> np.ndarray:
+        """Per-window maximum (int32, reference window order): windows with max <= skip_threshold are background."""
+        n = self.num_windows(params)
+        out = np.zeros(n, dtype=np.int32)
+        self._enter()
+        self._check(self.lib.dlv_sw_window_max_dev(self.ctx, C.byref(params), self._dev(vol, self.torch.uint16, "vol"),
+                                                   out.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        self._leave()
+        return out
+
     def sw_infer(self, params, vol, acc, cnt=None) -> dict:
         """One sliding-window pass; vol uint16 (nz,Yp,Xp), acc fp32 and cnt uint8 (optional) are
         mutated in place (inference/sliding_window_inferer.py:232-251)."""
@@ -340,6 +350,9 @@ class HipEngine:
         return out
 
     # ---- kernel timer ------------------------------------------------------------------------------
+    def set_lanes(self, lanes: int):
+        self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))
+
     def prof_enable(self, on: bool = True):
         self._check(self.lib.dlv_prof_enable(self.ctx, 1 if on else 0))
 

@@ -149,7 +149,8 @@ def run_inference(
 
         Zp = pad[2]
         p_all = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
-        plan = make_plan(eng.window_starts(p_all), int(p_all.roi[0]), Zp, world)
+        wmax = eng.window_max(p_all, dataset)
+        plan = make_plan(eng.window_starts(p_all), int(p_all.roi[0]), Zp, world, np.where(wmax > 0, 1.0, 0.02))
         for flip_dim, repeat in pass_schedule(bool(tta)):
             wb, we = plan.win_ranges[rank]
             if we > wb:

@@ -57,23 +57,33 @@ class ShardPlan:
         return out
 
 
-def make_plan(starts: np.ndarray, roi_z: int, Zp: int, world: int) -> ShardPlan:
-    """starts: (n_windows, 3) window origins in the reference's order (Z slowest).  Windows are
-    split into `world` contiguous ranges of near-equal size, cut only between Z tile-rows where
-    possible so that every seam is one half-tile slab."""
+def make_plan(starts: np.ndarray, roi_z: int, Zp: int, world: int, weights: Optional[np.ndarray] = None) -> ShardPlan:
+    """starts: (n_windows, 3) window origins in the reference's order (Z slowest).  Windows are split into
+    `world` contiguous ranges of near-equal WORK.  Without `weights` every window counts the same and cuts
+    snap to Z tile-row boundaries when there are enough rows (every seam is then one half-tile slab).  With
+    `weights` (e.g. 1 for a window that runs the network, ~0.02 for a background-skipped one) the cuts fall
+    where the cumulative weight is balanced, anywhere in the list: ranks that share a tile row exchange a
+    thicker seam, which is still far cheaper than idling (a brain fills the central slabs, not the outer ones)."""
     n = int(len(starts))
     zs = starts[:, 0]
-    # boundaries of tile rows (indices where z changes)
-    row_edges = [0] + [int(i) for i in np.nonzero(np.diff(zs))[0] + 1] + [n]
     cuts = [0]
-    for r in range(1, world):
-        target = n * r / world
-        # nearest tile-row edge if there are at least `world` rows, else cut anywhere
-        if len(row_edges) - 1 >= world:
-            c = min(row_edges, key=lambda e: abs(e - target))
-        else:
-            c = int(round(target))
-        cuts.append(max(c, cuts[-1]))
+    if weights is None:
+        # boundaries of tile rows (indices where z changes)
+        row_edges = [0] + [int(i) for i in np.nonzero(np.diff(zs))[0] + 1] + [n]
+        for r in range(1, world):
+            target = n * r / world
+            if len(row_edges) - 1 >= world:
+                c = min(row_edges, key=lambda e: abs(e - target))
+            else:
+                c = int(round(target))
+            cuts.append(max(c, cuts[-1]))
+    else:
+        w = np.asarray(weights, dtype=np.float64)
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+        total = cum[-1]
+        for r in range(1, world):
+            c = int(np.searchsorted(cum, total * r / world, side="left")) if total > 0 else int(round(n * r / world))
+            cuts.append(min(max(c, cuts[-1]), n))
     cuts.append(n)
     win_ranges = [(cuts[r], cuts[r + 1]) for r in range(world)]
     z_computed = []

@@ -132,6 +132,11 @@ int dlv_sw_num_windows(const dlv_sw_params* p, int64_t* n_windows);
 /* writes the (z0,y0,x0) start of every window in the reference's order: starts[3*n] */
 int dlv_sw_window_starts(const dlv_sw_params* p, int64_t* starts, int64_t capacity);
 
+/* Per-window maximum of the uint16 volume, in the reference's window order (the quantity the skip test of
+ * sliding_window_inferer.py:198 looks at): wmax[n_windows] on the host.  Lets a multi-rank host balance its
+ * shards by NON-background windows before calling dlv_sw_infer_dev.  Synchronous. */
+int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, int32_t* wmax, int64_t capacity);
+
 /* One pass of sliding_window_inference (inference/sliding_window_inferer.py:161-251) with the
  * volume resident in HBM: gather + cast, per-window background skip, optional flip, U-Net forward,
  * un-flip, acc += logit (fp32; the reference accumulates fp16), cnt += 1.
@@ -192,6 +197,9 @@ typedef struct dlv_prof_entry {
     double flops;        /* algorithmic FLOPs summed over those launches */
     double bytes;        /* algorithmic HBM bytes summed over those launches */
 } dlv_prof_entry;
+/* 1 = run batches back to back on the ctx stream; 2 (default) = alternate consecutive batches between two HIP
+ * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
+int dlv_set_lanes(dlv_ctx* ctx, int lanes);
 int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */

@@ -66,21 +66,25 @@ def test_shard_plan_is_a_partition():
     for shape, roi, world in (((1024, 2048, 2048), (128, 128, 128), 8), ((512, 512, 512), (128, 128, 128), 4),
                               ((64, 64, 32), (32, 32, 16), 2), ((128, 64, 64), (64, 64, 64), 3), ((64, 64, 64), (64, 64, 64), 2)):
         starts = orc.window_list(shape, roi, 0.5)
-        plan = make_plan(starts, roi[0], shape[0], world)
-        assert plan.win_ranges[0][0] == 0 and plan.win_ranges[-1][1] == len(starts)
-        assert all(plan.win_ranges[r][1] == plan.win_ranges[r + 1][0] for r in range(world - 1))
-        assert plan.z_owned[0][0] == 0 and plan.z_owned[-1][1] == shape[0]
-        assert all(plan.z_owned[r][1] == plan.z_owned[r + 1][0] for r in range(world - 1))
-        # every plane a rank computed is either owned by it or sent to exactly one owner
-        for r in range(world):
-            lo, hi = plan.z_computed[r]
-            covered = np.zeros(shape[0], dtype=int)
-            olo, ohi = plan.z_owned[r]
-            covered[max(lo, olo):min(hi, ohi)] += 1
-            for dst, a, b in plan.sends(r):
-                covered[a:b] += 1
-                assert (r, a, b) in plan.recvs(dst)
-            assert np.all(covered[lo:hi] == 1)
+        for weights in (None, np.random.default_rng(world).choice([1.0, 0.02], size=len(starts), p=[0.6, 0.4])):
+            plan = make_plan(starts, roi[0], shape[0], world, weights)
+            if weights is not None and len(starts) >= 4 * world:  # balanced to within ~one window
+                loads = [weights[b:e].sum() for b, e in plan.win_ranges]
+                assert max(loads) - min(loads) <= 2.0, loads
+            assert plan.win_ranges[0][0] == 0 and plan.win_ranges[-1][1] == len(starts)
+            assert all(plan.win_ranges[r][1] == plan.win_ranges[r + 1][0] for r in range(world - 1))
+            assert plan.z_owned[0][0] == 0 and plan.z_owned[-1][1] == shape[0]
+            assert all(plan.z_owned[r][1] == plan.z_owned[r + 1][0] for r in range(world - 1))
+            # every plane a rank computed is either owned by it or sent to exactly one owner
+            for r in range(world):
+                lo, hi = plan.z_computed[r]
+                covered = np.zeros(shape[0], dtype=int)
+                olo, ohi = plan.z_owned[r]
+                covered[max(lo, olo):min(hi, ohi)] += 1
+                for dst, a, b in plan.sends(r):
+                    covered[a:b] += 1
+                    assert (r, a, b) in plan.recvs(dst)
+                assert np.all(covered[lo:hi] == 1)
 
 
 def _gloo_worker(rank, world, port, tmp):
@@ -99,7 +103,8 @@ def _gloo_worker(rank, world, port, tmp):
     vol[:, :, 20:] = 0
     roi = (32, 32, 16)
     starts = orc2.window_list(vol.shape, roi, 0.5)
-    plan = make_plan(starts, roi[0], vol.shape[0], world)
+    wts = np.array([1.0 if vol[z:z + 32, y:y + 32, x:x + 16].max() > 0 else 0.02 for z, y, x in starts])
+    plan = make_plan(starts, roi[0], vol.shape[0], world, wts)
     det = lambda x: (x - 2000.0) / 1000.0  # noqa: E731
     acc = np.zeros(vol.shape, dtype=np.float32)
     wb, we = plan.win_ranges[rank]
