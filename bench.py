@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dense", action="store_true", help="no background: every window runs the network")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--sw-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")
@@ -302,7 +302,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "f32",
+        "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain, windows {roi[0]}^3, overlap 0.5, "

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdelivr_hip.so")
 
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 N_CONV, N_DECONV = 18, 4
 PROF_MAX = 32
 
@@ -93,6 +93,7 @@ SIGNATURES = {
     "dlv_zoom_spline2_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_mask_pad_u16_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_trilinear_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "dlv_debug_set_format": (C.c_int, [_P, C.c_int]),
     "dlv_debug_layer_bf16": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),

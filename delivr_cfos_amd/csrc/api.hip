@@ -132,7 +132,9 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         float* be = (float*)take((size_t)cout[i] * 4);
         // the stem (i == 0) keeps a 4-k-step hi/lo A-fragment pack for the MFMA stem (4 KiB)
         uint16_t* wb = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
+        uint16_t* wh = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
         if (base) {
+            ctx->conv[i].w_f16 = wh;
             ctx->conv[i].cin = cin[i];
             ctx->conv[i].cout = cout[i];
             ctx->conv[i].w_f32 = w;
@@ -147,7 +149,9 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         float* w = (float*)take(nw * 4);
         float* b = (float*)take((size_t)dcout[j] * 4);
         uint16_t* wb = (uint16_t*)take(nw * 2);
+        uint16_t* wh = (uint16_t*)take(nw * 2);
         if (base) {
+            ctx->deconv[j].w_f16 = wh;
             ctx->deconv[j].cin = dcin[j];
             ctx->deconv[j].cout = dcout[j];
             ctx->deconv[j].w_f32 = w;
@@ -356,8 +360,15 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
         return dlv_fail(ctx, DLV_EUNSUP, "patch %dx%dx%d: every dimension must be a multiple of 16", d, h, w);
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     if (precision == DLV_PREC_F32) return dlv_unet_forward_f32(ctx, x_dev, logits_dev, B, d, h, w);
-    if (precision == DLV_PREC_BF16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w);
+    if (precision == DLV_PREC_BF16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 0);
+    if (precision == DLV_PREC_F16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 1);
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
+}
+
+int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
+    if (!ctx || (precision != DLV_PREC_BF16 && precision != DLV_PREC_F16)) return DLV_EINVAL;
+    ctx->debug_f16 = precision == DLV_PREC_F16;
+    return DLV_OK;
 }
 
 int dlv_set_lanes(dlv_ctx* ctx, int lanes) {

@@ -32,12 +32,14 @@ struct DlvConvLayer {
     float* gamma = nullptr;     // (Cout)
     float* beta = nullptr;      // (Cout)
     uint16_t* w_bf16 = nullptr; // MFMA A-operand fragment order (see unet_bf16.hip)
+    uint16_t* w_f16 = nullptr;  // same order, IEEE half
 };
 struct DlvDeconvLayer {
     int cin = 0, cout = 0;
     float* w_f32 = nullptr;     // (Cin,Cout,8)
     float* bias = nullptr;      // (Cout)
     uint16_t* w_bf16 = nullptr; // fragment order, per output parity
+    uint16_t* w_f16 = nullptr;
 };
 
 enum DlvWsSlot {
@@ -79,6 +81,7 @@ struct dlv_ctx {
     void* ws[WS_N_SLOTS] = {nullptr};
     size_t ws_bytes[WS_N_SLOTS] = {0};
     // timing
+    bool debug_f16 = false;  // format used by dlv_debug_layer_bf16
     bool no_zmarch = false;  // test switch: force the generic conv kernel
     bool prof_on = false;
     std::vector<DlvProfSlot> prof_slots;
@@ -124,13 +127,13 @@ static inline int dlv_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 
 // ---- internal engine entry points (defined in the .hip files) ---------------------------------
 int dlv_unet_forward_f32(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
-int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16);
 // bf16 path fused with the tiler: reads the uint16 volume at the given window starts, adds the
 // logits into acc (see sw_infer.hip)
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
-                        int h, int w, int flip_dim, float scale, float* acc);
+                        int h, int w, int flip_dim, float scale, float* acc, int f16);
 int dlv_pack_weights_bf16(dlv_ctx* ctx);
 // z-marching conv for Cout = 32, Cin in {32, 64} (conv_zmarch.hip)
-int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
                             const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts);
 size_t dlv_bf16_pack_bytes(const int features[6]);

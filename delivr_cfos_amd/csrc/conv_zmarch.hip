@@ -19,18 +19,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include "prec16.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ unsigned zm_pack2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
+#define AS_FRAG(x) (x)
 
 constexpr int ZM_TY = 8, ZM_TX = 32, ZM_HY = 10, ZM_HX = 34;
 constexpr int ZM_PLANE = ZM_HY * ZM_HX;  // 340 voxels
@@ -46,7 +39,7 @@ struct ZmCfg {
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + PELEMS) * 16 + 2048;  // + 8x64 floats for the stats flush
 };
 
-template <int CIN, int VB, int MINW, int TYT, bool PIN, int DIST, int ABL = 0, bool STAG = false>
+template <class P, int CIN, int VB, int MINW, int TYT, bool PIN, int DIST, int ABL = 0, bool STAG = false>
 __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const uint4* __restrict__ in1, int c1_8,
                                                            const uint4* __restrict__ in2, int c2_8,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -199,8 +192,8 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 u;
-                    u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
-                    u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+                    u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
                     uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
                     dst[h] = u;
                 }
@@ -243,12 +236,12 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
                 if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < VB; ++v) {
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[cur][v]);
+                    const uint4 bv = AS_FRAG(fb[cur][v]);
                     // accC starts a new output plane: its first MFMA takes a zero C operand
-                    accC[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][0]), bv,
+                    accC[v] = P::mfma(AS_FRAG(fw[cur][0]), bv,
                                                                       g == 0 ? fzero : accC[v], 0, 0, 0);
-                    accB[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), bv, accB[v], 0, 0, 0);
-                    accA[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][2]), bv, accA[v], 0, 0, 0);
+                    accB[v] = P::mfma(AS_FRAG(fw[cur][1]), bv, accB[v], 0, 0, 0);
+                    accA[v] = P::mfma(AS_FRAG(fw[cur][2]), bv, accA[v], 0, 0, 0);
                 }
                 if (PIN) __builtin_amdgcn_sched_barrier(0);
             }
@@ -303,7 +296,7 @@ struct Zm2Cfg {
     static constexpr size_t LDS_BYTES = (size_t)(WELEMS + 2 * PELEMS) * 16 + 2048;
 };
 
-template <int NSRC, int ABL = 0>
+template <class P, int NSRC, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __restrict__ in1, const uint4* __restrict__ in2,
                                                               const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                               uint4* __restrict__ out, float* __restrict__ partials, int D,
@@ -426,11 +419,11 @@ __global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __re
                 const int cur = g & 1;
                 if (g + 1 < NG) load_group(g + 1, fb[cur ^ 1], fw[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[cur]);
-                accC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][0]), bv,
+                const uint4 bv = AS_FRAG(fb[cur]);
+                accC = P::mfma(AS_FRAG(fw[cur][0]), bv,
                                                                (S == 0 && g == 0) ? fzero : accC, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), bv, accB, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][2]), bv, accA, 0, 0, 0);
+                accB = P::mfma(AS_FRAG(fw[cur][1]), bv, accB, 0, 0, 0);
+                accA = P::mfma(AS_FRAG(fw[cur][2]), bv, accA, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if (S == 0) {
@@ -459,8 +452,8 @@ __global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __re
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 u;
-                    u.x = zm_pack2(val[4 * g + 0], val[4 * g + 1]);
-                    u.y = zm_pack2(val[4 * g + 2], val[4 * g + 3]);
+                    u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
                     uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
                     dst[h] = u;
                 }
@@ -504,7 +497,7 @@ __global__ void __launch_bounds__(512, 2) conv3_zmarch2_kernel(const uint4* __re
 }  // namespace
 
 // returns the number of partial-sum rows per sample (columns) or a negative error
-int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
                             const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts) {
     static int variant = -1;
     if (variant < 0) {
@@ -522,19 +515,26 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
     dim3 grid(tilesY * tilesX, nseg, B);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
     // kernel variants (DLV_ZM_VARIANT selects one for A/B timing): VB rows per wave, TYT tile rows -> TYT/VB waves
-#define DLV_ZM_LAUNCH(CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_)                                                                                  \
+#define DLV_ZM_LAUNCH_P(P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_)                                                                                  \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>,                         \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>,                         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_, TYT_>::LDS_BYTES));  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_zmarch_kernel<CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
+        hipLaunchKernelGGL((conv3_zmarch_kernel<P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
                            (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg);                                        \
     } while (0)
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
+#define DLV_ZM_LAUNCH(...) DLV_ZM_LAUNCH_P(PBf16, __VA_ARGS__)
+    // the fp16 format runs the default kernel only (the A/B variants below are bf16)
+    if (f16) {
+        if (cin == 32) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 0, false);
+        else if (cin == 64) DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 0, false);
+        else return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
+    } else
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
     if (cin == 32) {
         if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1, false);
@@ -553,6 +553,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, int cin, const void* in1, int c1, cons
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }
 #undef DLV_ZM_LAUNCH
+#undef DLV_ZM_LAUNCH_P
 #undef DLV_ZM2_LAUNCH
     DLV_LAUNCH_CHECK(ctx, "conv3_zmarch_kernel");
     return DLV_OK;

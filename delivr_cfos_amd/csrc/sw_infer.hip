@@ -220,7 +220,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                      dlv_sw_stats* stats) {
     if (!ctx || !p || !vol_dev || !acc_dev) return DLV_EINVAL;
     if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_sw_infer_dev before dlv_unet_load");
-    if (p->precision != DLV_PREC_F32 && p->precision != DLV_PREC_BF16)
+    if (p->precision != DLV_PREC_F32 && p->precision != DLV_PREC_BF16 && p->precision != DLV_PREC_F16)
         return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", p->precision);
     if (!(p->flip_dim == -1 || (p->flip_dim >= 2 && p->flip_dim <= 4)))
         return dlv_fail(ctx, DLV_EINVAL, "flip_dim must be -1, 2, 3 or 4");
@@ -323,7 +323,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     // convolutions of the other.  Windows of one colour class are disjoint, so their blends may run
     // concurrently; the lanes are joined at every class boundary, which keeps the per-voxel summation
     // order (colour by colour) and therefore the bits of the result.
-    const bool two_lanes = p->precision == DLV_PREC_BF16 && ctx->aux_stream != nullptr && ctx->lanes_wanted == 2;
+    const bool two_lanes = p->precision != DLV_PREC_F32 && ctx->aux_stream != nullptr && ctx->lanes_wanted == 2;
     hipEvent_t ev_main = ctx->ev_main, ev_aux = ctx->ev_aux;
     auto join_lanes = [&]() -> int {
         if (!two_lanes) return DLV_OK;
@@ -340,10 +340,10 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
         for (int b0 = 0; b0 < s.n_active && rc == DLV_OK; b0 += sw_batch) {
             const int B = std::min(sw_batch, s.n_active - b0);
             const int* st_dev = list_dev + (s.off + b0) * 3;
-            if (p->precision == DLV_PREC_BF16) {
+            if (p->precision != DLV_PREC_F32) {
                 ctx->lane = two_lanes ? lane : 0;
                 ctx->stream = ctx->lane ? ctx->aux_stream : ctx->main_stream;
-                rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev);
+                rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, p->precision == DLV_PREC_F16 ? 1 : 0);
                 if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
                                        Xp, 0.0f, rep, acc_dev, cnt_dev);

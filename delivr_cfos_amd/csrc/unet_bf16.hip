@@ -20,20 +20,11 @@
 #include <algorithm>
 
 #include "common.h"
+#include "prec16.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#define AS_FRAG(x) (x)
 
 __device__ __forceinline__ float mish_fast(float y) {
     // y * tanh(softplus(y)) = y * (n^2 + 2n) / (n^2 + 2n + 2), n = e^y; identity above the
@@ -48,6 +39,7 @@ __device__ __forceinline__ float mish_fast(float y) {
 // weight packing (device side, once per dlv_unet_load)
 // ---------------------------------------------------------------------------------------------------
 // conv:   out[((cb*27 + t)*KP + kp)*64 + lane][j] = W[cout = cb*32 + (lane&31)][cin = kp*16 + 8*(lane>>5) + j][t]
+template <class P>
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin) {
     const int KP = cin / 16;
     const long long n = (long long)cout * cin * 27;
@@ -62,12 +54,13 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __rest
         const int co = cb * 32 + (lane & 31);
         const int ci = kp * 16 + 8 * (lane >> 5) + j;
         const float v = w[((long long)co * cin + ci) * 27 + t];
-        out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+        out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
     }
 }
 // stem (Cin = 1, Cout = 32): K = 64 = {hi byte, lo byte} x 32 tap slots (27 used).  The uint16 input is split
 // exactly into x = 256*hi + lo (both exact in bf16), the weights carry the factor 256 for the hi half:
 //   out[(s*64 + lane)*8 + j]: k = 16 s + 8 (lane>>5) + j, part = k>>5, tap = k&31, cout = lane&31
+template <class P>
 __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 64 * 8) return;
@@ -75,10 +68,11 @@ __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __rest
     const int k = 16 * s + 8 * (lane >> 5) + j;
     const int part = k >> 5, tap = k & 31, co = lane & 31;
     float v = 0.f;
-    if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f);
-    out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+    if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f) * P::STEM_SCALE;
+    out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
 }
 // deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
+template <class P>
 __global__ void pack_deconv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cin, int cout) {
     const int KP = cin / 16, CB = cout / 32;
     const long long n = (long long)cin * cout * 8;
@@ -93,7 +87,7 @@ __global__ void pack_deconv_w_kernel(const float* __restrict__ w, uint16_t* __re
         const int co = cb * 32 + (lane & 31);
         const int ci = kp * 16 + 8 * (lane >> 5) + j;
         const float v = w[((long long)ci * cout + co) * 8 + par];
-        out[i] = (uint16_t)(pack2(v, 0.f) & 0xffffu);
+        out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
     }
 }
 
@@ -104,7 +98,7 @@ __global__ void pack_deconv_w_kernel(const float* __restrict__ w, uint16_t* __re
 // ---------------------------------------------------------------------------------------------------
 constexpr int STEM_ZR = 4;  // z-run per thread
 
-template <bool FROM_VOLUME>
+template <class P, bool FROM_VOLUME>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict__ xf, const uint16_t* __restrict__ vol,
                                                         int Yp, int Xp, const int* __restrict__ starts, int flip_dim,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
@@ -166,15 +160,19 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
                         acc[4 * c4 + 3] = fmaf(v, ww.w, acc[4 * c4 + 3]);
                     }
                 }
+        if (P::STEM_SCALE != 1.0f) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] *= P::STEM_SCALE;
+        }
         const long long vox = (long long)D * hw;
         const long long o = (long long)z * hw + p;
 #pragma unroll
         for (int c8 = 0; c8 < 4; ++c8) {
             uint4 u;
-            u.x = pack2(acc[8 * c8 + 0], acc[8 * c8 + 1]);
-            u.y = pack2(acc[8 * c8 + 2], acc[8 * c8 + 3]);
-            u.z = pack2(acc[8 * c8 + 4], acc[8 * c8 + 5]);
-            u.w = pack2(acc[8 * c8 + 6], acc[8 * c8 + 7]);
+            u.x = P::pack2(acc[8 * c8 + 0], acc[8 * c8 + 1]);
+            u.y = P::pack2(acc[8 * c8 + 2], acc[8 * c8 + 3]);
+            u.z = P::pack2(acc[8 * c8 + 4], acc[8 * c8 + 5]);
+            u.w = P::pack2(acc[8 * c8 + 6], acc[8 * c8 + 7]);
             out[((long long)n * 4 + c8) * vox + o] = u;
         }
 #pragma unroll
@@ -214,6 +212,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 constexpr int SM_TZ = 4, SM_TY = 8, SM_TX = 32, SM_HZ = 6, SM_HY = 10, SM_HX = 34;
 
+template <class P>
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
                                                         const int* __restrict__ starts, int flip_dim,
                                                         const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -240,13 +239,13 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
-    bf16x8 a[4];
+    uint4 a[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = __builtin_bit_cast(bf16x8, wpk[s * 64 + lane]);
+    for (int s = 0; s < 4; ++s) a[s] = AS_FRAG(wpk[s * 64 + lane]);
     float bs[16], ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h] * P::STEM_SCALE;
         ssum[r] = ssq[r] = 0.f;
     }
     __syncthreads();
@@ -272,18 +271,18 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
                 gh[e] = (float)(u1 >> 8);
                 gl[e] = (float)(u1 & 255u);
             }
-            hi0[jj] = pack2(fh[0], fh[1]);
-            lo0[jj] = pack2(fl[0], fl[1]);
-            hi1[jj] = pack2(gh[0], gh[1]);
-            lo1[jj] = pack2(gl[0], gl[1]);
+            hi0[jj] = P::pack2(fh[0], fh[1]);
+            lo0[jj] = P::pack2(fl[0], fl[1]);
+            hi1[jj] = P::pack2(gh[0], gh[1]);
+            lo1[jj] = P::pack2(gl[0], gl[1]);
         }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], __builtin_bit_cast(bf16x8, make_uint4(hi0[0], hi0[1], hi0[2], hi0[3])), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], __builtin_bit_cast(bf16x8, make_uint4(hi1[0], hi1[1], hi1[2], hi1[3])), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], __builtin_bit_cast(bf16x8, make_uint4(lo0[0], lo0[1], lo0[2], lo0[3])), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], __builtin_bit_cast(bf16x8, make_uint4(lo1[0], lo1[1], lo1[2], lo1[3])), acc, 0, 0, 0);
+        acc = P::mfma(a[0], AS_FRAG(make_uint4(hi0[0], hi0[1], hi0[2], hi0[3])), acc, 0, 0, 0);
+        acc = P::mfma(a[1], AS_FRAG(make_uint4(hi1[0], hi1[1], hi1[2], hi1[3])), acc, 0, 0, 0);
+        acc = P::mfma(a[2], AS_FRAG(make_uint4(lo0[0], lo0[1], lo0[2], lo0[3])), acc, 0, 0, 0);
+        acc = P::mfma(a[3], AS_FRAG(make_uint4(lo1[0], lo1[1], lo1[2], lo1[3])), acc, 0, 0, 0);
         const int oy = y0 + row, ox = x0 + col;
         const bool ok = oz < D && oy < H && ox < W;
         float val[16];
@@ -300,8 +299,8 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 u;
-                u.x = pack2(val[4 * g + 0], val[4 * g + 1]);
-                u.y = pack2(val[4 * g + 2], val[4 * g + 3]);
+                u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
+                u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
                 uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
                 dst[h] = u;
             }
@@ -343,7 +342,7 @@ struct ConvTile {
     static constexpr int RV = 32 / TX;       // rows per 32-voxel block
 };
 
-template <int NCB, int TX, bool WLDS>
+template <class P, int NCB, int TX, bool WLDS>
 __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict__ in1, int c1_8,
                                                          const uint4* __restrict__ in2, int c2_8,
                                                          const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -419,24 +418,24 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const int kp = sl * 2 + ks;
-                        bf16x8 a[NCB];
+                        uint4 a[NCB];
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb) {
                             const uint4 u = WLDS ? wlds[((cb * 27 + t) * 2 + ks) * 64 + lane]
                                                  : wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
-                            a[cb] = __builtin_bit_cast(bf16x8, u);
+                            a[cb] = AS_FRAG(u);
                         }
-                        bf16x8 b[2];
+                        uint4 b[2];
 #pragma unroll
                         for (int v = 0; v < 2; ++v) {
                             const uint4 u = slab[lbase[v] + toff + ks * 2 * T::HZ * T::HY * T::HX];
-                            b[v] = __builtin_bit_cast(bf16x8, u);
+                            b[v] = AS_FRAG(u);
                         }
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                             for (int v = 0; v < 2; ++v)
-                                acc[cb][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[v], acc[cb][v], 0, 0, 0);
+                                acc[cb][v] = P::mfma(a[cb], b[v], acc[cb][v], 0, 0, 0);
                     }
                 }
     }
@@ -472,8 +471,8 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 u;
-                    u.x = pack2(val[4 * g + 0], val[4 * g + 1]);
-                    u.y = pack2(val[4 * g + 2], val[4 * g + 3]);
+                    u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
                     uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * cout8 + (cbg0 + cb) * 4 + g) * vox + o);
                     dst[h] = u;
                 }
@@ -535,22 +534,23 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // InstanceNorm apply + Mish (+ MaxPool3d(2) into a second tensor), in place on the raw bf16 tensor
 // ---------------------------------------------------------------------------------------------------
+template <class P>
 __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const float* sh, float* mx) {
-    float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+    float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         v[k] = mish_fast(fmaf(v[k], sc[k], sh[k]));
         if (mx) mx[k] = fmaxf(mx[k], v[k]);
     }
     uint4 r;
-    r.x = pack2(v[0], v[1]);
-    r.y = pack2(v[2], v[3]);
-    r.z = pack2(v[4], v[5]);
-    r.w = pack2(v[6], v[7]);
+    r.x = P::pack2(v[0], v[1]);
+    r.y = P::pack2(v[2], v[3]);
+    r.z = P::pack2(v[4], v[5]);
+    r.w = P::pack2(v[6], v[7]);
     return r;
 }
 
-template <bool POOL>
+template <class P, bool POOL>
 __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C,
                                                         int D, int H, int W, uint4* __restrict__ pooled) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
     uint4* p = x + ((long long)n * (C / 8) + c8) * vox;
     if (!POOL) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256)
-            p[i] = norm_mish8(p[i], sc, sh, nullptr);
+            p[i] = norm_mish8<P>(p[i], sc, sh, nullptr);
     } else {
         const int d2 = D / 2, h2 = H / 2, w2 = W / 2;
         const long long pv = (long long)d2 * h2 * w2;
@@ -580,14 +580,14 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const long long o = ((long long)(2 * zz + a) * H + (2 * yy + b)) * W + 2 * xx;
-                    p[o] = norm_mish8(p[o], sc, sh, mx);
-                    p[o + 1] = norm_mish8(p[o + 1], sc, sh, mx);
+                    p[o] = norm_mish8<P>(p[o], sc, sh, mx);
+                    p[o + 1] = norm_mish8<P>(p[o + 1], sc, sh, mx);
                 }
             uint4 r;
-            r.x = pack2(mx[0], mx[1]);
-            r.y = pack2(mx[2], mx[3]);
-            r.z = pack2(mx[4], mx[5]);
-            r.w = pack2(mx[6], mx[7]);
+            r.x = P::pack2(mx[0], mx[1]);
+            r.y = P::pack2(mx[2], mx[3]);
+            r.z = P::pack2(mx[4], mx[5]);
+            r.w = P::pack2(mx[6], mx[7]);
             q[i] = r;
         }
     }
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
 // ConvTranspose3d k2 s2 on MFMA: for each of the 8 output parities a (Cin x Cout) channel GEMM
 //   wave: 32 consecutive input voxels (B fragments straight from HBM, no LDS), all parities/couts
 // ---------------------------------------------------------------------------------------------------
-template <int KP>  // Cin / 16
+template <class P, int KP>  // Cin / 16
 __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
                                                            const float* __restrict__ bias, uint4* __restrict__ out,
                                                            int cout, int D, int H, int W) {
@@ -608,12 +608,12 @@ __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restri
     const long long v = ((long long)blockIdx.x * 4 + wave) * 32 + col;
     const bool ok = v < vox;
     const long long vc = ok ? v : 0;
-    bf16x8 b[KP];
+    uint4 b[KP];
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
         uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vc];
         if (!ok) u = make_uint4(0, 0, 0, 0);
-        b[kp] = __builtin_bit_cast(bf16x8, u);
+        b[kp] = AS_FRAG(u);
     }
     const int x = (int)(vc % W), y = (int)((vc / W) % H), z = (int)(vc / ((long long)W * H));
     const int CB = cout / 32, cout8 = cout / 8;
@@ -628,14 +628,14 @@ __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restri
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp) {
                 const uint4 u = wpk[(((long long)par * CB + cb) * KP + kp) * 64 + lane];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u), b[kp], acc, 0, 0, 0);
+                acc = P::mfma(AS_FRAG(u), b[kp], acc, 0, 0, 0);
             }
             if (ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 u;
-                    u.x = pack2(acc[4 * g + 0], acc[4 * g + 1]);
-                    u.y = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+                    u.x = P::pack2(acc[4 * g + 0], acc[4 * g + 1]);
+                    u.y = P::pack2(acc[4 * g + 2], acc[4 * g + 3]);
                     uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * cout8 + cb * 4 + g) * ovox + o);
                     dst[h] = u;
                 }
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restri
 // two half-wave channel quads, so that every store is 16 bytes per lane and 512 contiguous bytes per
 // half-wave (the per-parity form above writes 8-byte halves at a stride of two voxels).
 // ---------------------------------------------------------------------------------------------------
-template <int KP>
+template <class P, int KP>
 __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
                                                            const float* __restrict__ bias, uint4* __restrict__ out,
                                                            int cout, int D, int H, int W, int segs) {
@@ -667,13 +667,13 @@ __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restri
     const bool ok = xi < W;
     const bool odd = col & 1;
     const long long vin = ((long long)z * H + y) * W + (ok ? xi : 0);
-    bf16x8 b0[KP], b1[KP];
+    uint4 b0[KP], b1[KP];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
         const uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vin];
-        b0[kp] = __builtin_bit_cast(bf16x8, (ok && !odd) ? u : zero4);
-        b1[kp] = __builtin_bit_cast(bf16x8, (ok && odd) ? u : zero4);
+        b0[kp] = AS_FRAG((ok && !odd) ? u : zero4);
+        b1[kp] = AS_FRAG((ok && odd) ? u : zero4);
     }
     const int CB = cout / 32, cout8 = cout / 8;
     const int OH = 2 * H, OW = 2 * W;
@@ -689,14 +689,14 @@ __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restri
             for (int kp = 0; kp < KP; ++kp) {
                 const uint4 w0 = wpk[(((long long)(ab * 2 + 0) * CB + cb) * KP + kp) * 64 + lane];
                 const uint4 w1 = wpk[(((long long)(ab * 2 + 1) * CB + cb) * KP + kp) * 64 + lane];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), b0[kp], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), b1[kp], acc, 0, 0, 0);
+                acc = P::mfma(AS_FRAG(w0), b0[kp], acc, 0, 0, 0);
+                acc = P::mfma(AS_FRAG(w1), b1[kp], acc, 0, 0, 0);
             }
             unsigned px[4], py[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                px[g] = pack2(acc[4 * g + 0], acc[4 * g + 1]);
-                py[g] = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+                px[g] = P::pack2(acc[4 * g + 0], acc[4 * g + 1]);
+                py[g] = P::pack2(acc[4 * g + 2], acc[4 * g + 3]);
             }
 #pragma unroll
             for (int gp = 0; gp < 4; gp += 2) {
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restri
 // final: InstanceNorm + Mish of the last block, Conv3d(C5 -> 1, k1), then either plain logits or
 // the blend accumulate of inference/sliding_window_inferer.py:232-251 (acc[window] += logit, un-flipped)
 // ---------------------------------------------------------------------------------------------------
-template <bool BLEND>
+template <class P, bool BLEND>
 __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict__ x, const float2* __restrict__ ss,
                                                          const float* __restrict__ wf, const float* __restrict__ bf,
                                                          float* __restrict__ logits, const int* __restrict__ starts,
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
 #pragma unroll
         for (int c8 = 0; c8 < 4; ++c8) {
             const uint4 u = x[((long long)n * 4 + c8) * vox + i];
-            const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+            const float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
 #pragma unroll
             for (int k = 0; k < 8; ++k) a = fmaf(mish_fast(fmaf(v[k], sc[8 * c8 + k], sh[8 * c8 + k])), ww[8 * c8 + k], a);
         }
@@ -760,6 +760,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
 // ---------------------------------------------------------------------------------------------------
 // debug / test conversions: fp32 NCDHW <-> bf16 chunk-planar
 // ---------------------------------------------------------------------------------------------------
+template <class P>
 __global__ void f32_to_cp_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C, long long vox) {
     const int c8 = blockIdx.y, n = blockIdx.z;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
@@ -767,18 +768,19 @@ __global__ void f32_to_cp_kernel(const float* __restrict__ in, uint4* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = in[((long long)n * C + c8 * 8 + k) * vox + i];
         uint4 r;
-        r.x = pack2(v[0], v[1]);
-        r.y = pack2(v[2], v[3]);
-        r.z = pack2(v[4], v[5]);
-        r.w = pack2(v[6], v[7]);
+        r.x = P::pack2(v[0], v[1]);
+        r.y = P::pack2(v[2], v[3]);
+        r.z = P::pack2(v[4], v[5]);
+        r.w = P::pack2(v[6], v[7]);
         out[((long long)n * (C / 8) + c8) * vox + i] = r;
     }
 }
+template <class P>
 __global__ void cp_to_f32_kernel(const uint4* __restrict__ in, float* __restrict__ out, int C, long long vox) {
     const int c8 = blockIdx.y, n = blockIdx.z;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
         const uint4 u = in[((long long)n * (C / 8) + c8) * vox + i];
-        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+        const float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[((long long)n * C + c8 * 8 + k) * vox + i] = v[k];
     }
@@ -792,7 +794,13 @@ struct Dims {
     long long vox() const { return (long long)D * H * W; }
 };
 
-struct Bf16Net {
+template <class P>
+const uint16_t* wpack(const DlvConvLayer& L) { return P::IS_F16 ? L.w_f16 : L.w_bf16; }
+template <class P>
+const uint16_t* wpack(const DlvDeconvLayer& L) { return P::IS_F16 ? L.w_f16 : L.w_bf16; }
+
+template <class P>
+struct Net16 {
     dlv_ctx* ctx;
     int B;
     float* partials;
@@ -803,8 +811,10 @@ struct Bf16Net {
 
     int stats(int nparts, int li, Dims d) {
         const DlvConvLayer& L = ctx->conv[li];
+        // the fp16 format stores the raw stem output scaled by 2^-8: eps scales with its square (same normalised value)
+        const float eps = li == 0 ? 1e-5f * P::STEM_SCALE * P::STEM_SCALE : 1e-5f;
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(B * L.cout), dim3(64), 0, ctx->stream, partials, nparts, L.cout,
-                           1.0 / (double)d.vox(), 1e-5f, L.gamma, L.beta, ss);
+                           1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss);
         DLV_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
         return DLV_OK;
     }
@@ -816,10 +826,10 @@ struct Bf16Net {
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
         if (L.cout == 32 && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
             char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zmarch_bf16_c%dx32", L.cin);
+            snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx32", P::IS_F16 ? "f16" : "bf16", L.cin);
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * 32 * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + 32));
             int np = 0;
-            DLV_TRY(dlv_conv3_zmarch_launch(ctx, L.cin, in1, c1, in2, c2, L.w_bf16, L.bias, out, partials, B, d.D, d.H, d.W, &np));
+            DLV_TRY(dlv_conv3_zmarch_launch(ctx, P::IS_F16, L.cin, in1, c1, in2, c2, wpack<P>(L), L.bias, out, partials, B, d.D, d.H, d.W, &np));
             zp.end();
             if ((size_t)B * np * 64 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
             return stats(np, li, d);
@@ -841,18 +851,18 @@ struct Bf16Net {
         const double flops = 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B;
         const double bytes = 2.0 * (double)d.vox() * B * (L.cin + L.cout);
         char name[48];
-        snprintf(name, sizeof(name), "conv3_mfma_bf16_c%dx%d", L.cin, L.cout);
+        snprintf(name, sizeof(name), "conv3_mfma_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
         DlvProf pr(ctx, name, flops, bytes);
 #define DLV_CONV_LAUNCH(NCB_, TX_, WLDS_)                                                                                \
     do {                                                                                                                 \
         static bool attr_done = false;                                                                                   \
         if (!attr_done) {                                                                                                \
-            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<NCB_, TX_, WLDS_>,                           \
+            DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<P, NCB_, TX_, WLDS_>,                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_done = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3_mfma_kernel<NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
-                           c2 / 8, reinterpret_cast<const uint4*>(L.w_bf16), L.bias, out, partials, L.cout, d.D, d.H,    \
+        hipLaunchKernelGGL((conv3_mfma_kernel<P, NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
+                           c2 / 8, reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, out, partials, L.cout, d.D, d.H,    \
                            d.W, tY, tX);                                                                                 \
     } while (0)
         if (wlds) {
@@ -884,9 +894,9 @@ struct Bf16Net {
         DlvProf pr(ctx, pooled ? "norm_mish_pool_bf16" : "norm_mish_bf16", 0.0,
                    (double)d.vox() * B * C * 2 * 2 + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
         if (pooled)
-            hipLaunchKernelGGL(norm_mish_kernel<true>, grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+            hipLaunchKernelGGL((norm_mish_kernel<P, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
         else
-            hipLaunchKernelGGL(norm_mish_kernel<false>, grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+            hipLaunchKernelGGL((norm_mish_kernel<P, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "norm_mish_kernel");
         return DLV_OK;
@@ -894,7 +904,7 @@ struct Bf16Net {
 
     int deconv(int j, const uint4* in, uint4* out, Dims din) {
         const DlvDeconvLayer& L = ctx->deconv[j];
-        const uint4* w = reinterpret_cast<const uint4*>(L.w_bf16);
+        const uint4* w = reinterpret_cast<const uint4*>(wpack<P>(L));
         const bool rows = !ctx->no_zmarch;
         const int segs = dlv_cdiv(din.W, 16);
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
@@ -903,10 +913,10 @@ struct Bf16Net {
 #define DLV_DECONV(KP_)                                                                                                  \
     do {                                                                                                                 \
         if (rows)                                                                                                        \
-            hipLaunchKernelGGL(deconv2_rows_kernel<KP_>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
+            hipLaunchKernelGGL((deconv2_rows_kernel<P, KP_>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
                                din.D, din.H, din.W, segs);                                                               \
         else                                                                                                             \
-            hipLaunchKernelGGL(deconv2_mfma_kernel<KP_>, grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
+            hipLaunchKernelGGL((deconv2_mfma_kernel<P, KP_>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
                                din.D, din.H, din.W);                                                                     \
     } while (0)
         switch (L.cin / 16) {
@@ -925,7 +935,8 @@ struct Bf16Net {
 
 // the whole forward; the stem reads either xf (fp32 patches) or the uint16 volume windows, the final
 // layer writes either logits or blends into acc
-int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int flip_dim,
+template <class P>
+int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int flip_dim,
                  float scale, float* logits, float* acc, int B, int d, int h, int w) {
     const int* f = ctx->features;
     if (f[0] != 32 || f[5] != 32)
@@ -947,7 +958,7 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
     const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
     char* sbase;
     DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_STATS_B : WS_STATS, pfloats * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
-    Bf16Net net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
+    Net16<P> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
     auto buf = [&](int l, int k) { return (uint4*)(base + offs[l][k]); };
     enum { A = 0, Bf = 1, S = 2, U = 3 };
 
@@ -963,13 +974,13 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
             grid = dim3(tZ * tY * tX, 1, B);
             nblk = grid.x;
             if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
-            hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim,
-                               reinterpret_cast<const uint4*>(L.w_bf16), L.bias, buf(0, A), net.partials, d, h, w, tY, tX);
+            hipLaunchKernelGGL(stem_mfma_kernel<P>, grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim,
+                               reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, buf(0, A), net.partials, d, h, w, tY, tX);
         } else if (vol)
-            hipLaunchKernelGGL(stem_conv_kernel<true>, grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
+            hipLaunchKernelGGL((stem_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
                                flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
         else
-            hipLaunchKernelGGL(stem_conv_kernel<false>, grid, dim3(256), 0, ctx->stream, xf, nullptr, 0, 0, nullptr, -1,
+            hipLaunchKernelGGL((stem_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, xf, nullptr, 0, 0, nullptr, -1,
                                L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "stem_conv_kernel");
@@ -1001,10 +1012,10 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
         if (acc)
-            hipLaunchKernelGGL(final_conv_kernel<true>, grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+            hipLaunchKernelGGL((final_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
                                ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w);
         else
-            hipLaunchKernelGGL(final_conv_kernel<false>, grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+            hipLaunchKernelGGL((final_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
                                ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "final_conv_kernel");
@@ -1012,42 +1023,29 @@ int forward_bf16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int
     return DLV_OK;
 }
 
-}  // namespace
-
-int dlv_pack_weights_bf16(dlv_ctx* ctx) {
-    hipLaunchKernelGGL(pack_stem_w_kernel, dim3(8), dim3(256), 0, ctx->stream, ctx->conv[0].w_f32, ctx->conv[0].w_bf16);
+template <class P>
+int pack_weights_16(dlv_ctx* ctx) {
+    auto dst = [](auto& L) { return const_cast<uint16_t*>(wpack<P>(L)); };
+    hipLaunchKernelGGL(pack_stem_w_kernel<P>, dim3(8), dim3(256), 0, ctx->stream, ctx->conv[0].w_f32, dst(ctx->conv[0]));
     DLV_LAUNCH_CHECK(ctx, "pack_stem_w_kernel");
     for (int i = 1; i < DLV_N_CONV; ++i) {
         const DlvConvLayer& L = ctx->conv[i];
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: %d->%d not multiples of 32", i, L.cin, L.cout);
-        hipLaunchKernelGGL(pack_conv_w_kernel, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, L.w_bf16, L.cout, L.cin);
+        hipLaunchKernelGGL(pack_conv_w_kernel<P>, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->conv[i]), L.cout, L.cin);
         DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
     }
     for (int j = 0; j < DLV_N_DECONV; ++j) {
         const DlvDeconvLayer& L = ctx->deconv[j];
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: %d->%d not multiples of 32", j, L.cin, L.cout);
-        hipLaunchKernelGGL(pack_deconv_w_kernel, dim3(64), dim3(256), 0, ctx->stream, L.w_f32, L.w_bf16, L.cin, L.cout);
+        hipLaunchKernelGGL(pack_deconv_w_kernel<P>, dim3(64), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->deconv[j]), L.cin, L.cout);
         DLV_LAUNCH_CHECK(ctx, "pack_deconv_w_kernel");
     }
     return DLV_OK;
 }
 
-int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w) {
-    return forward_bf16(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
-}
-
-int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d, int h,
-                        int w, int flip_dim, float scale, float* acc) {
-    return forward_bf16(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
-}
-
-// test hook: one conv block (raw conv + InstanceNorm + Mish) or one deconv of the bf16 path on fp32
-// NCDHW tensors (converted on the device)
-extern "C" int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
-                                    int c2, float* out_dev, int B, int D, int H, int W) {
-    if (!ctx || !in1_dev || !out_dev) return DLV_EINVAL;
-    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "no weights");
-    DLV_HIP(ctx, hipSetDevice(ctx->device));
+template <class P>
+int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev, int c2,
+                   float* out_dev, int B, int D, int H, int W) {
     const long long vox = (long long)D * H * W;
     if (kind == 0) {
         if (index < 1 || index >= DLV_N_CONV) return dlv_fail(ctx, DLV_EINVAL, "conv index must be 1..17");
@@ -1062,13 +1060,13 @@ extern "C" int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const flo
         DLV_TRY(dlv_ws_get(ctx, WS_STATS, pf * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
         uint4 *i1 = (uint4*)base, *i2 = (uint4*)(base + ((b1 + 255) & ~(size_t)255)),
               *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255) + ((b2 + 255) & ~(size_t)255));
-        Bf16Net net{ctx, B, (float*)sbase, pf, (float2*)(sbase + ((pf * 4 + 255) & ~(size_t)255))};
+        Net16<P> net{ctx, B, (float*)sbase, pf, (float2*)(sbase + ((pf * 4 + 255) & ~(size_t)255))};
         const int g = net.grid1d(vox);
-        hipLaunchKernelGGL(f32_to_cp_kernel, dim3(g, c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
-        if (c2) hipLaunchKernelGGL(f32_to_cp_kernel, dim3(g, c2 / 8, B), dim3(256), 0, ctx->stream, in2_dev, i2, c2, vox);
+        hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
+        if (c2) hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c2 / 8, B), dim3(256), 0, ctx->stream, in2_dev, i2, c2, vox);
         DLV_TRY(net.conv(index, i1, c1, c2 ? i2 : nullptr, c2, o, Dims{D, H, W}));
         DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr));
-        hipLaunchKernelGGL(cp_to_f32_kernel, dim3(g, L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev, L.cout, vox);
+        hipLaunchKernelGGL(cp_to_f32_kernel<P>, dim3(g, L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev, L.cout, vox);
         DLV_LAUNCH_CHECK(ctx, "debug conv");
         return DLV_OK;
     }
@@ -1080,13 +1078,42 @@ extern "C" int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const flo
         char* base;
         DLV_TRY(dlv_ws_get(ctx, WS_BF16_ACT, b1 + bo + 1024, (void**)&base));
         uint4 *i1 = (uint4*)base, *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255));
-        Bf16Net net{ctx, B, nullptr, 0, nullptr};
-        hipLaunchKernelGGL(f32_to_cp_kernel, dim3(net.grid1d(vox), c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
+        Net16<P> net{ctx, B, nullptr, 0, nullptr};
+        hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(net.grid1d(vox), c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
         DLV_TRY(net.deconv(index, i1, o, Dims{D, H, W}));
-        hipLaunchKernelGGL(cp_to_f32_kernel, dim3(net.grid1d(vox * 8), L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev,
+        hipLaunchKernelGGL(cp_to_f32_kernel<P>, dim3(net.grid1d(vox * 8), L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev,
                            L.cout, vox * 8);
         DLV_LAUNCH_CHECK(ctx, "debug deconv");
         return DLV_OK;
     }
     return dlv_fail(ctx, DLV_EINVAL, "kind must be 0 (conv block) or 1 (deconv)");
+}
+
+}  // namespace
+
+int dlv_pack_weights_bf16(dlv_ctx* ctx) {
+    DLV_TRY(pack_weights_16<PBf16>(ctx));
+    return pack_weights_16<PF16>(ctx);
+}
+
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16) {
+    if (f16) return forward_16<PF16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
+    return forward_16<PBf16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
+}
+
+int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d, int h,
+                        int w, int flip_dim, float scale, float* acc, int f16) {
+    if (f16) return forward_16<PF16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
+    return forward_16<PBf16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
+}
+
+// test hook: one conv block (raw conv + InstanceNorm + Mish) or one deconv of the 16-bit path on fp32
+// NCDHW tensors (converted on the device); precision DLV_PREC_BF16 or DLV_PREC_F16
+extern "C" int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
+                                    int c2, float* out_dev, int B, int D, int H, int W) {
+    if (!ctx || !in1_dev || !out_dev) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "no weights");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->debug_f16) return debug_layer_16<PF16>(ctx, kind, index, in1_dev, c1, in2_dev, c2, out_dev, B, D, H, W);
+    return debug_layer_16<PBf16>(ctx, kind, index, in1_dev, c1, in2_dev, c2, out_dev, B, D, H, W);
 }

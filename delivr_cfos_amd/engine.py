@@ -12,9 +12,9 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32, DelivrHipError
+from ._lib import PREC_BF16, PREC_F16, PREC_F32, DelivrHipError
 
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
 
 # checkpoint keys of the 18 conv blocks in forward order (include/delivr_hip.h)
 CONV_BLOCKS = (
@@ -182,7 +182,7 @@ class HipEngine:
         self._leave()
         return out
 
-    def debug_layer_bf16(self, kind: int, index: int, in1, in2=None):
+    def debug_layer_bf16(self, kind: int, index: int, in1, in2=None, precision: str = "bf16"):
         """test hook (dlv_debug_layer_bf16): one conv block / deconv of the bf16 path on fp32 tensors."""
         torch = self.torch
         B, c1, D, H, W = in1.shape
@@ -197,6 +197,7 @@ class HipEngine:
         else:
             dco = [self.features[4] // 2, self.features[3] // 2, self.features[2] // 2, self.features[1]]
             out = torch.empty((B, dco[index], 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=self.device)
+        self._check(self.lib.dlv_debug_set_format(self.ctx, PRECISIONS[precision]))
         self._enter()
         self._check(self.lib.dlv_debug_layer_bf16(
             self.ctx, kind, index, self._dev(in1, torch.float32, "in1"), int(c1),

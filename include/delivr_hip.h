@@ -42,6 +42,7 @@ extern "C" {
 /* compute precision of the U-Net forward */
 #define DLV_PREC_F32 0  /* fp32 VALU kernels, NCDHW: parity mode (matches torch fp32 to ~1e-5) */
 #define DLV_PREC_BF16 1 /* bf16 MFMA implicit-GEMM kernels, fp32 accumulate + fp32 norm stats */
+#define DLV_PREC_F16 2  /* same kernels on IEEE-half operands (11 significant bits, same MFMA rate) */
 
 #define DLV_N_CONV 18
 #define DLV_N_DECONV 4
@@ -209,6 +210,8 @@ int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_
  * that tests/ can compare each kernel with the oracle in isolation.  kind 0: conv block `index`
  * (1..17: Conv3d k3 + InstanceNorm + Mish) on the channel concatenation [in1 (c1), in2 (c2, may be
  * 0)] -> out (B,Cout,D,H,W); kind 1: ConvTranspose3d `index` (0..3) -> out (B,Cout,2D,2H,2W). */
+/* selects the 16-bit format dlv_debug_layer_bf16 runs in (DLV_PREC_BF16 default, DLV_PREC_F16) */
+int dlv_debug_set_format(dlv_ctx* ctx, int precision);
 int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
                          int c2, float* out_dev, int B, int D, int H, int W);
 

@@ -193,3 +193,67 @@ def test_sw_pass_fast_kernels_vs_generic_and_fp32(net):
         rel = float(np.sqrt(np.mean((a - ref)[live] ** 2)) / ref[live].std())
         print(tag, "rel rms vs fp32:", rel)
         assert rel < 5e-2, (tag, rel)
+
+
+# ---------------------------------------------------------------------------------------------------
+# IEEE-half variant of the same kernels (precision="fp16"): 11 significant bits instead of 8
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("li,c1,c2,D,H,W", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[5], CONV_CASES[8], CONV_CASES[11]])
+def test_conv_block_fp16(eng, net, li, c1, c2, D, H, W):
+    """Same check as test_conv_block_bf16 on fp16-rounded inputs/weights: errors shrink by the 3 extra mantissa bits."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(li * 100 + D)
+    x1 = torch.randn((2, c1, D, H, W), generator=g).half().float()
+    x2 = torch.randn((2, c2, D, H, W), generator=g).half().float() if c2 else None
+    blk = _conv_block(net, li)
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    with torch.no_grad():
+        raw = F.conv3d(xin, blk.conv.weight.half().float(), blk.conv.bias, padding=1)
+        ref = F.mish(F.instance_norm(raw, weight=blk.adn.N.weight, bias=blk.adn.N.bias, eps=1e-5))
+    out = eng.debug_layer_bf16(0, li, x1.cuda(), None if x2 is None else x2.cuda(), precision="fp16").cpu()
+    err = (out - ref).abs()
+    assert err.max() < 0.01, float(err.max())
+    assert err.mean() < 1e-3, float(err.mean())
+
+
+def test_forward_fp16_vs_oracle(eng, golden_dir):
+    """fp16 whole forward vs the torch-fp32 oracle: relative RMS <= 1e-2 (measured ~1e-3), sign agreement >= 0.999."""
+    import os
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "orc_unet.npz"))
+    for xk, lk in (("x32", "logits32"), ("x_odd", "logits_odd")):
+        x = torch.from_numpy(g[xk].astype(np.float32))[None, None].cuda()
+        out = eng.unet_forward(x, "fp16").cpu().numpy()[0, 0]
+        ref = g[lk]
+        rel = float(np.sqrt(np.mean((out - ref) ** 2)) / ref.std())
+        agree = float(((out >= 0) == (ref >= 0)).mean())
+        print(f"fp16 {xk}: rel rms {rel:.5f} sign agreement {agree:.5f}")
+        assert rel < 1e-2, rel
+        assert agree > 0.999, agree
+
+
+def test_sw_pass_fp16_matches_fp32_engine(eng, golden_dir):
+    """fused fp16 path (MFMA stem with the 2^-8 output scale, z-march convs) vs the fp32 engine on a 16x32x48-window pass."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+
+    vol = synth_volume_np((32, 64, 96), seed=11, dense=True)
+    vol[:, :, 40:] = 0
+    vol[0, 0, 0] = 65535  # the largest uint16 through the scaled stem
+    roi = (16, 32, 48)
+    v = eng.to_device(vol)
+    res = {}
+    for prec in ("fp32", "fp16"):
+        acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+        st = eng.sw_infer(eng.make_sw_params(vol.shape, roi, 0.5, 2, 0, prec), v, acc)
+        eng.sync()
+        res[prec] = (acc.cpu().numpy(), st)
+    assert res["fp32"][1] == res["fp16"][1]
+    a32, a16 = res["fp32"][0], res["fp16"][0]
+    live = a32 > -500
+    assert np.isfinite(a16).all()
+    rel = float(np.sqrt(np.mean((a16 - a32)[live] ** 2)) / a32[live].std())
+    assert rel < 1e-2, rel
