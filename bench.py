@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W   # N ranks, RCCL over xGMI
 
 One "step" = ONE sliding-window pass (no TTA) over the whole volume, volume resident in HBM as
-uint16: tiler -> per-window background skip -> U-Net forward (bf16 MFMA) -> fp32 overlap blend ->
+uint16: tiler -> per-window background skip -> U-Net forward (16-bit MFMA operands, fp32 accumulate) -> fp32 overlap blend ->
 (N>1: seam exchange) -> threshold + L1-30 eroded re-mask -> uint8 mask (N>1: gathered on rank 0).
 That is BASELINE.json's metric ("voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @
 1/2/4/8 GPU"); the volume and its window list are the same at every N, so scaling is "strong".
@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dense", action="store_true", help="no background: every window runs the network")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="fp16 (default): IEEE-half MFMA operands, mask IoU 0.9997 vs the fp32 path; bf16: 2.7 %% faster, IoU 0.998")
     ap.add_argument("--sw-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")

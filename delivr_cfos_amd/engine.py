@@ -207,7 +207,7 @@ class HipEngine:
         return out
 
     # ---- sliding window ----------------------------------------------------------------------------
-    def make_sw_params(self, padded_shape, roi, overlap=0.5, flip_dim=None, skip_threshold=0, precision="bf16",
+    def make_sw_params(self, padded_shape, roi, overlap=0.5, flip_dim=None, skip_threshold=0, precision="fp16",
                        sw_batch=0, win_range=None, slab=None, repeat=1) -> _lib.SwParams:
         p = _lib.SwParams()
         p.Zp, p.Yp, p.Xp = (int(v) for v in padded_shape)

@@ -62,7 +62,7 @@ def run_inference(
     precision: Optional[str] = None,
     state_dict=None,
 ):
-    """Same parameters as the reference (:113-129) plus ``precision`` ("bf16" default / "fp32",
+    """Same parameters as the reference (:113-129) plus ``precision`` ("fp16" default / "bf16" / "fp32",
     also settings["mi355x"]["precision"]) and ``state_dict`` (use instead of reading
     ``model_weights``).  Returns "<abs output_folder>/<comment>"."""
     import torch
@@ -73,7 +73,7 @@ def run_inference(
         crop_size = (wd["window_dim_0"], wd["window_dim_1"], wd["window_dim_2"])
         if precision is None:
             precision = settings.get("mi355x", {}).get("precision")
-    precision = precision or "bf16"
+    precision = precision or "fp16"
     crop_size = tuple(int(c) for c in crop_size)
     print("using crop size:  ", crop_size)
     if not torch.cuda.is_available():

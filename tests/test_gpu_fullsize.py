@@ -130,3 +130,33 @@ def test_resamplers_fullsize_properties(setup):
     padded = eng.mask_pad_u16(vol, up, (512, 512, 640))
     assert torch.equal(padded[:, :, :512].to(torch.int32), vol.to(torch.int32) * up.to(torch.int32))
     assert int(padded[:, :, 512:].to(torch.int32).abs().sum()) == 0
+
+
+def test_mask_iou_vs_fp32_path_256cube():
+    """north_star tolerance: mask IoU >= 0.999 against the fp32 path (itself within 2e-4 of the torch-fp32 oracle,
+    test_unet_fp32_matches_oracle_golden) - met by the default fp16 format; bf16 (8 significant bits) reaches 0.998 with the
+    seeded RANDOM weights that stand in for the absent checkpoint (logit std 0.39, no margin around 0)."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.weights import random_state_dict
+
+    shape, roi = (256, 256, 256), (128, 128, 128)
+    eng = HipEngine(0)
+    eng.load_state_dict({"state_dict": random_state_dict(0)})
+    vol = synth_volume_torch(shape, 1, eng.device)
+    masks = {}
+    for prec in ("fp32", "fp16", "bf16"):
+        acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        eng.sw_infer(eng.make_sw_params(shape, roi, 0.5, None, 0, prec), vol, acc)
+        masks[prec] = eng.finalize(acc, None, vol, shape, 0.5, 30, 0).bool()
+    eng.sync()
+
+    def iou(a, b):
+        return float((a & b).sum()) / max(float((a | b).sum()), 1.0)
+
+    i16, ib = iou(masks["fp16"], masks["fp32"]), iou(masks["bf16"], masks["fp32"])
+    print(f"mask IoU vs fp32 path: fp16 {i16:.5f}  bf16 {ib:.5f}  (foreground {float(masks['fp32'].float().mean()):.3f})")
+    assert i16 >= 0.999, i16
+    assert ib >= 0.995, ib
+    eng.close()
