@@ -247,11 +247,12 @@ def main():
                 scaled = True
             if os.path.isfile(tfile) and not args.dense and args.sw_batch == 0:
                 tj = json.load(open(tfile))
-                if name in tj["kernels"]:
+                tname = name.replace("_f16_", "_bf16_")  # the PMC passes ran the bf16 build: same bytes per launch
+                if tname in tj["kernels"]:
                     r["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
-                    t = tj["kernels"][name]["traffic_bytes"]
-                    if scaled and "algorithmic_bytes" in tj["kernels"][name]:
-                        t *= r["algorithmic_bytes"] / tj["kernels"][name]["algorithmic_bytes"]
+                    t = tj["kernels"][tname]["traffic_bytes"]
+                    if scaled and "algorithmic_bytes" in tj["kernels"][tname]:
+                        t *= r["algorithmic_bytes"] / tj["kernels"][tname]["algorithmic_bytes"]
                     r["traffic"] = t
                     r["traffic_source"] = os.path.relpath(tfile, ROOT) + (
                         " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "")
@@ -307,7 +308,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain, windows {roi[0]}^3, overlap 0.5, "
-                        f"1 pass (no TTA), seeded random BasicUNet(32,32,64,128,256,32) weights"
+                        f"1 pass (no TTA), seeded random BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
                         + (", dense (no background)" if args.dense else ", ellipsoid brain (background skipped)"),
             "volume_zyx": [Z, Y, X], "roi": list(roi), "overlap": 0.5,
             "windows": n_windows, "windows_skipped": n_skipped,
