@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time CCL-26 + statistics and the resamplers on this volume (configs 4/5)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
     args = ap.parse_args()
 
@@ -126,6 +127,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.hostlogic import arrayterator_zblock
     from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, finalize_owned, gather_slabs, make_plan
     from delivr_cfos_amd.synth import synth_volume_torch
     from delivr_cfos_amd.weights import random_state_dict
@@ -280,6 +282,37 @@ def main():
         eng.set_lanes(2)
         roofline_isolated, _ = roofline_of(prof1, 1, 1)
 
+    # ---- optional: the stages either side of the pass (BASELINE configs 4 and 5), timed separately ----------
+    extras = None
+    if args.extras and world == 1:
+        def timed(fn, reps=2):
+            fn()
+            eng.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = fn()
+            eng.sync()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / reps, out
+
+        extras = {}
+        mask = slab.contiguous()
+        ms, (labels, ncomp) = timed(lambda: eng.ccl26(mask))
+        extras["ccl26_ms"] = ms
+        extras["components"] = ncomp
+        ms, _ = timed(lambda: eng.cc_stats(labels, ncomp), reps=1)
+        extras["cc_stats_ms"] = ms
+        del labels
+        ms, ds = timed(lambda: eng.block_mean_u16(vol, (4, 15, 15)))
+        extras["block_mean_4x15x15_ms"] = ms
+        small = (ds.to(torch.int32) > 0).to(torch.uint8)
+        ms, _ = timed(lambda: eng.zoom_spline2_u8(small, shape), reps=1)
+        extras["zoom_spline2_to_full_ms"] = ms
+        ms, _ = timed(lambda: eng.finalize(acc, None, vol, shape, 0.5, 30, arrayterator_zblock(shape)), reps=2)
+        extras["finalize_ms"] = ms
+        extras["voxels"] = vox
+
     cpu = None
     if not args.no_cpu_baseline:
         try:
@@ -321,6 +354,7 @@ def main():
         "roofline_isolated": roofline_isolated,
         "cpu_baseline": cpu,
         "kernels": kernels,
+        "extras": extras,
     }
     print(json.dumps(out))
     if world > 1:
