@@ -180,31 +180,106 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const uint8_t* __restr
 }
 
 // ---- statistics -------------------------------------------------------------------------------------
-// per label: count, sum z/y/x (u64), bbox min/max (u32).  Background (label 0) is reduced per wave.
+// per label: count, sum z/y/x (u64), bbox min/max (u32).  Contributions are aggregated before they reach memory:
+// each thread folds the runs of equal labels inside its 8 consecutive x voxels, then the lanes of a wave that hold
+// the same label are reduced with shuffles and ONE lane issues the atomics (a mask made of one giant component
+// would otherwise serialise hundreds of millions of atomics on a single address).  Background (label 0) is not
+// accumulated here: its row is derived from the totals on the host, its bounding box by a per-wave reduction.
+constexpr int SPT = 8;  // voxels per thread (one x-run inside a row)
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const u32 lo = __shfl((u32)v, src, 64), hi = __shfl((u32)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
 __global__ void __launch_bounds__(256) cc_stats_kernel(const u32* __restrict__ labels, int Z, int Y, int X,
                                                        u32* __restrict__ counts, u64* __restrict__ sums,
                                                        u32* __restrict__ bbmin, u32* __restrict__ bbmax) {
-    const u64 n = (u64)Z * Y * X;
+    const int segs = (X + SPT - 1) / SPT;
+    const u64 nitems = (u64)Z * Y * segs;
+    const int lane = threadIdx.x & 63;
     u32 bmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, bmax[3] = {0, 0, 0};
     bool any_bg = false;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u32 l = labels[i];
-        const u32 x = (u32)(i % X), y = (u32)((i / X) % Y), z = (u32)(i / ((u64)X * Y));
-        if (l) {
-            atomicAdd(counts + l, 1u);
-            atomicAdd(sums + 3 * (u64)l, (u64)z);
-            atomicAdd(sums + 3 * (u64)l + 1, (u64)y);
-            atomicAdd(sums + 3 * (u64)l + 2, (u64)x);
-            atomicMin(bbmin + 3 * (u64)l, z);
-            atomicMin(bbmin + 3 * (u64)l + 1, y);
-            atomicMin(bbmin + 3 * (u64)l + 2, x);
-            atomicMax(bbmax + 3 * (u64)l, z);
-            atomicMax(bbmax + 3 * (u64)l + 1, y);
-            atomicMax(bbmax + 3 * (u64)l + 2, x);
+    // wave-uniform trip count so that the shuffles below are convergent
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 first = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 rounds = (nitems + stride - 1) / stride;
+    for (u64 rd = 0; rd < rounds; ++rd) {
+        const u64 it = first + rd * stride;
+        const bool in_range = it < nitems;
+        u32 l[SPT];
+        u32 z = 0, y = 0, x0 = 0;
+        if (in_range) {
+            const u32 sg = (u32)(it % segs);
+            y = (u32)((it / segs) % Y);
+            z = (u32)(it / ((u64)segs * Y));
+            x0 = sg * SPT;
+            const u64 base = ((u64)z * Y + y) * X + x0;
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) l[k] = (x0 + k < (u32)X) ? labels[base + k] : 0xffffffffu;  // pad = "no voxel"
         } else {
-            any_bg = true;
-            bmin[0] = min(bmin[0], z); bmin[1] = min(bmin[1], y); bmin[2] = min(bmin[2], x);
-            bmax[0] = max(bmax[0], z); bmax[1] = max(bmax[1], y); bmax[2] = max(bmax[2], x);
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) l[k] = 0xffffffffu;
+        }
+        // background bookkeeping
+#pragma unroll
+        for (int k = 0; k < SPT; ++k)
+            if (l[k] == 0) {
+                any_bg = true;
+                bmin[0] = min(bmin[0], z); bmax[0] = max(bmax[0], z);
+                bmin[1] = min(bmin[1], y); bmax[1] = max(bmax[1], y);
+                bmin[2] = min(bmin[2], x0 + k); bmax[2] = max(bmax[2], x0 + k);
+            }
+        // runs of equal foreground labels inside the thread's voxels, one run per pass of the loop below
+        int k = 0;
+        while (true) {
+            // next run of this lane (if any)
+            while (k < SPT && (l[k] == 0 || l[k] == 0xffffffffu)) ++k;
+            const bool have = k < SPT;
+            if (!__any(have)) break;
+            u32 lab = 0, cnt = 0, sx = 0, mnx = 0xffffffffu, mxx = 0;
+            if (have) {
+                lab = l[k];
+                while (k < SPT && l[k] == lab) {
+                    ++cnt;
+                    sx += x0 + k;
+                    mnx = min(mnx, x0 + k);
+                    mxx = max(mxx, x0 + k);
+                    ++k;
+                }
+            }
+            // lanes holding the same label are combined; one leader per distinct label issues the atomics
+            bool pending = have;
+            while (true) {
+                const unsigned long long m = __ballot(pending);
+                if (!m) break;
+                const int leader = __ffsll((long long)m) - 1;
+                const u32 L = __shfl(lab, leader, 64);
+                const bool mine = pending && lab == L;
+                u32 c = mine ? cnt : 0;
+                u64 vz = mine ? (u64)z * cnt : 0, vy = mine ? (u64)y * cnt : 0, vx = mine ? (u64)sx : 0;
+                u32 z0 = mine ? z : 0xffffffffu, z1 = mine ? z : 0, y0 = mine ? y : 0xffffffffu, y1 = mine ? y : 0;
+                u32 xa = mine ? mnx : 0xffffffffu, xb = mine ? mxx : 0;
+                for (int o = 32; o > 0; o >>= 1) {
+                    c += __shfl_xor(c, o, 64);
+                    vz += shfl64(vz, lane ^ o);
+                    vy += shfl64(vy, lane ^ o);
+                    vx += shfl64(vx, lane ^ o);
+                    z0 = min(z0, __shfl_xor(z0, o, 64)); z1 = max(z1, __shfl_xor(z1, o, 64));
+                    y0 = min(y0, __shfl_xor(y0, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+                    xa = min(xa, __shfl_xor(xa, o, 64)); xb = max(xb, __shfl_xor(xb, o, 64));
+                }
+                if (lane == leader) {
+                    atomicAdd(counts + L, c);
+                    atomicAdd(sums + 3 * (u64)L, vz);
+                    atomicAdd(sums + 3 * (u64)L + 1, vy);
+                    atomicAdd(sums + 3 * (u64)L + 2, vx);
+                    atomicMin(bbmin + 3 * (u64)L, z0); atomicMax(bbmax + 3 * (u64)L, z1);
+                    atomicMin(bbmin + 3 * (u64)L + 1, y0); atomicMax(bbmax + 3 * (u64)L + 1, y1);
+                    atomicMin(bbmin + 3 * (u64)L + 2, xa); atomicMax(bbmax + 3 * (u64)L + 2, xb);
+                }
+                pending = pending && !mine;
+            }
         }
     }
     if (__any(any_bg)) {
@@ -212,10 +287,10 @@ __global__ void __launch_bounds__(256) cc_stats_kernel(const u32* __restrict__ l
         for (int k = 0; k < 3; ++k) {
             u32 lo = bmin[k], hi = bmax[k];
             for (int o = 32; o > 0; o >>= 1) {
-                lo = min(lo, __shfl_down(lo, o, 64));
-                hi = max(hi, __shfl_down(hi, o, 64));
+                lo = min(lo, __shfl_xor(lo, o, 64));
+                hi = max(hi, __shfl_xor(hi, o, 64));
             }
-            if ((threadIdx.x & 63) == 0) {
+            if (lane == 0) {
                 atomicMin(bbmin + k, lo);
                 atomicMax(bbmax + k, hi);
             }
@@ -285,7 +360,8 @@ int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int
     u32* bbmin = (u32*)(ws + off_min);
     u32* bbmax = (u32*)(ws + off_max);
     u64* sums = (u64*)(ws + off_sum);
-    const int gs = (int)std::min<u64>((nvox + 255) / 256, (u64)256 * 32);
+    const u64 nitems = (u64)Z * Y * ((X + SPT - 1) / SPT);
+    const int gs = (int)std::min<u64>((nitems + 255) / 256, (u64)256 * 32);
     DlvProf pr(ctx, "cc_stats", 0.0, (double)nvox * 4);
     hipLaunchKernelGGL(cc_stats_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_dev, Z, Y, X, counts, sums, bbmin, bbmax);
     pr.end();
