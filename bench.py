@@ -266,12 +266,12 @@ def main():
                                if net_ms > 0 and world == 1 and lanes == 1 else None)
         return r, kernels
 
-    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else 2
+    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else int(os.environ.get("DLV_LANES", "4"))
     roofline, kernels = roofline_of(prof, lanes_used, args.steps)
     # the timed region runs two overlapping lanes, which stretches every kernel's event-to-event time; one extra,
     # untimed step on a single lane gives the dominant kernel's own efficiency
     roofline_isolated = None
-    if prof and lanes_used == 2 and not args.no_isolated and world == 1:
+    if prof and lanes_used > 1 and not args.no_isolated and world == 1:
         eng.set_lanes(1)
         eng.prof_reset()
         eng.prof_enable(True)
@@ -279,7 +279,7 @@ def main():
         fence()
         prof1 = eng.prof_report()
         eng.prof_enable(False)
-        eng.set_lanes(2)
+        eng.set_lanes(lanes_used)
         roofline_isolated, _ = roofline_of(prof1, 1, 1)
 
     # ---- optional: the stages either side of the pass (BASELINE configs 4 and 5), timed separately ----------

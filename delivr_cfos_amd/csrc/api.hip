@@ -1,5 +1,6 @@
 // api.hip - context, memory helpers, weight loading and the in-library kernel timer of
 // libdelivr_hip.so (C ABI declared in include/delivr_hip.h).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -19,7 +20,8 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
             DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
-            if (ctx->aux_stream) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+            for (int k = 0; k < 3; ++k)
+                if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
             DLV_HIP(ctx, hipFree(ctx->ws[slot]));
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
@@ -76,7 +78,8 @@ void DlvProf::end() {
 static int prof_drain(dlv_ctx* ctx) {
     if (ctx->prof_pending.empty()) return DLV_OK;
     DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
-    if (ctx->aux_stream) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    for (int k = 0; k < 3; ++k)
+        if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
     for (auto& p : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -222,13 +225,20 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         ctx->own_stream = true;
     }
     ctx->main_stream = ctx->stream;
-    if (!getenv("DLV_ONE_LANE") && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess)
-        ctx->aux_stream = nullptr;
-    if (ctx->aux_stream && (hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) {
-        (void)hipStreamDestroy(ctx->aux_stream);
-        ctx->aux_stream = nullptr;
+    if (!getenv("DLV_ONE_LANE")) {
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < DLV_MAX_LANES && ok; ++k) ok = hipEventCreateWithFlags(&ctx->ev_lane[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (int k = 0; k < 3; ++k)
+                if (ctx->aux[k]) {
+                    (void)hipStreamDestroy(ctx->aux[k]);
+                    ctx->aux[k] = nullptr;
+                }
+        }
+        ctx->aux_stream = ctx->aux[0];
     }
+    if (const char* e = getenv("DLV_LANES")) ctx->lanes_wanted = std::max(1, std::min(DLV_MAX_LANES, atoi(e)));
     *out = ctx;
     return DLV_OK;
 }
@@ -245,12 +255,13 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
     for (int i = 0; i < WS_N_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->blob) (void)hipFree(ctx->blob);
-    if (ctx->aux_stream) {
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamDestroy(ctx->aux_stream);
-        if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
-        if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
-    }
+    for (int k = 0; k < 3; ++k)
+        if (ctx->aux[k]) {
+            (void)hipStreamSynchronize(ctx->aux[k]);
+            (void)hipStreamDestroy(ctx->aux[k]);
+        }
+    for (int k = 0; k < DLV_MAX_LANES; ++k)
+        if (ctx->ev_lane[k]) (void)hipEventDestroy(ctx->ev_lane[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->main_stream);
     delete ctx;
     return DLV_OK;
@@ -372,7 +383,7 @@ int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
 }
 
 int dlv_set_lanes(dlv_ctx* ctx, int lanes) {
-    if (!ctx || lanes < 1 || lanes > 2) return DLV_EINVAL;
+    if (!ctx || lanes < 1 || lanes > DLV_MAX_LANES) return DLV_EINVAL;
     ctx->lanes_wanted = lanes;
     return DLV_OK;
 }

@@ -13,6 +13,7 @@
 #include "../../include/delivr_hip.h"
 
 #define DLV_WAVE 64
+#define DLV_MAX_LANES 4
 
 struct DlvProfSlot {
     char name[48];
@@ -52,8 +53,12 @@ enum DlvWsSlot {
     WS_ERODE,         // distance maps
     WS_CCL,           // CCL scratch
     WS_MISC,
-    WS_BF16_ACT_B,    // second pipeline lane (aux stream)
-    WS_STATS_B,
+    WS_LANE_ACT0,     // extra pipeline lanes (aux streams): activations, then stats, DLV_MAX_LANES-1 each
+    WS_LANE_ACT1,
+    WS_LANE_ACT2,
+    WS_LANE_STATS0,
+    WS_LANE_STATS1,
+    WS_LANE_STATS2,
     WS_N_SLOTS
 };
 
@@ -61,10 +66,12 @@ struct dlv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream the NEXT launch goes to (main or aux lane)
     hipStream_t main_stream = nullptr;  // the ctx stream proper
-    hipStream_t aux_stream = nullptr;   // second lane: batches alternate between the two so that the
-                                        // HBM-bound kernels of one batch overlap the MFMA kernels of the other
+    hipStream_t aux_stream = nullptr;   // lane 1 (kept as a named alias of aux[0])
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // extra lanes: batches rotate over the lanes so that the
+                                        // HBM-bound kernels of one batch overlap the MFMA kernels of another
+    hipEvent_t ev_lane[4] = {nullptr, nullptr, nullptr, nullptr};
     int lane = 0;
-    int lanes_wanted = 2;
+    int lanes_wanted = 4;
     hipEvent_t ev_main = nullptr, ev_aux = nullptr;  // lane joins
     bool own_stream = false;
     std::string err;

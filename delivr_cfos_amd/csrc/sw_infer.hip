@@ -323,14 +323,15 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     // convolutions of the other.  Windows of one colour class are disjoint, so their blends may run
     // concurrently; the lanes are joined at every class boundary, which keeps the per-voxel summation
     // order (colour by colour) and therefore the bits of the result.
-    const bool two_lanes = p->precision != DLV_PREC_F32 && ctx->aux_stream != nullptr && ctx->lanes_wanted == 2;
-    hipEvent_t ev_main = ctx->ev_main, ev_aux = ctx->ev_aux;
+    const int nlanes = (p->precision != DLV_PREC_F32 && ctx->aux[0] != nullptr) ? std::max(1, std::min(ctx->lanes_wanted, DLV_MAX_LANES)) : 1;
+    const bool two_lanes = nlanes > 1;
+    auto lane_stream = [&](int l) { return l == 0 ? ctx->main_stream : ctx->aux[l - 1]; };
     auto join_lanes = [&]() -> int {
         if (!two_lanes) return DLV_OK;
-        DLV_HIP(ctx, hipEventRecord(ev_main, ctx->main_stream));
-        DLV_HIP(ctx, hipEventRecord(ev_aux, ctx->aux_stream));
-        DLV_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ev_main, 0));
-        DLV_HIP(ctx, hipStreamWaitEvent(ctx->main_stream, ev_aux, 0));
+        for (int l = 0; l < nlanes; ++l) DLV_HIP(ctx, hipEventRecord(ctx->ev_lane[l], lane_stream(l)));
+        for (int l = 0; l < nlanes; ++l)
+            for (int m = 0; m < nlanes; ++m)
+                if (m != l) DLV_HIP(ctx, hipStreamWaitEvent(lane_stream(l), ctx->ev_lane[m], 0));
         return DLV_OK;
     };
     int rc = join_lanes();  // the aux lane starts after everything queued on the main stream so far
@@ -342,14 +343,14 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
             const int* st_dev = list_dev + (s.off + b0) * 3;
             if (p->precision != DLV_PREC_F32) {
                 ctx->lane = two_lanes ? lane : 0;
-                ctx->stream = ctx->lane ? ctx->aux_stream : ctx->main_stream;
+                ctx->stream = lane_stream(ctx->lane);
                 rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, p->precision == DLV_PREC_F16 ? 1 : 0);
                 if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
                                        Xp, 0.0f, rep, acc_dev, cnt_dev);
                     if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel(count) failed");
                 }
-                lane ^= 1;
+                lane = (lane + 1) % nlanes;
             } else {
                 float *tin, *tout;
                 rc = dlv_ws_get(ctx, WS_TILE_IN, (size_t)sw_batch * tile_vox * 4, (void**)&tin);

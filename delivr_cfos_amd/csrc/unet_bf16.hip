@@ -952,12 +952,12 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
             off = (off + 255) & ~(size_t)255;
         }
     char* base;
-    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_BF16_ACT_B : WS_BF16_ACT, off, (void**)&base));
+    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_ACT0 + (ctx->lane - 1) : WS_BF16_ACT, off, (void**)&base));
     // partial sums: the level-0 convs have the most tiles (256 voxels each); the stem has fewer blocks
     const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
     const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
     char* sbase;
-    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_STATS_B : WS_STATS, pfloats * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
+    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
     Net16<P> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
     auto buf = [&](int l, int k) { return (uint4*)(base + offs[l][k]); };
     enum { A = 0, Bf = 1, S = 2, U = 3 };
