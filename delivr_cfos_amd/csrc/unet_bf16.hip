@@ -212,12 +212,16 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 constexpr int SM_TZ = 4, SM_TY = 8, SM_TX = 32, SM_HZ = 6, SM_HY = 10, SM_HX = 34;
 
-template <class P>
+// MODE 0: store raw + statistics; MODE 1: statistics only (first pass of the two-pass stem); MODE 2: recompute,
+// apply InstanceNorm scale/shift + Mish and store the ACTIVATED tensor (no raw tensor, no separate norm pass:
+// the K = 64 MFMA work is cheap next to 268 MB of avoided traffic per 128^3 window)
+template <class P, int MODE>
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
                                                         const int* __restrict__ starts, int flip_dim,
                                                         const uint4* __restrict__ wpk, const float* __restrict__ bias,
-                                                        uint4* __restrict__ out, float* __restrict__ partials, int D, int H,
-                                                        int W, int tilesY, int tilesX) {
+                                                        uint4* __restrict__ out, float* __restrict__ partials,
+                                                        const float2* __restrict__ ss, int D, int H, int W, int tilesY,
+                                                        int tilesX) {
     __shared__ unsigned short tile_u16[SM_HZ * SM_HY * SM_HX + 2];
     __shared__ float red[4 * 64];
     const int n = blockIdx.z;
@@ -247,6 +251,15 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
     for (int r = 0; r < 16; ++r) {
         bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h] * P::STEM_SCALE;
         ssum[r] = ssq[r] = 0.f;
+    }
+    float nsc[16], nsh[16];
+    if (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 v = ss[n * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+            nsc[r] = v.x;
+            nsh[r] = v.y;
+        }
     }
     __syncthreads();
     const long long vox = (long long)D * H * W;
@@ -289,12 +302,13 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             val[r] = acc[r] + bs[r];
-            if (ok) {
+            if (MODE != 2 && ok) {
                 ssum[r] += val[r];
                 ssq[r] = fmaf(val[r], val[r], ssq[r]);
             }
+            if (MODE == 2) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
         }
-        if (ok) {
+        if (MODE != 1 && ok) {
             const long long o = ((long long)oz * H + oy) * W + ox;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -306,6 +320,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
             }
         }
     }
+    if (MODE == 2) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float sa = ssum[r], sb = ssq[r];
@@ -966,6 +981,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     {
         dim3 grid(dlv_cdiv((long long)h * w, 256), dlv_cdiv(d, STEM_ZR), B);
         int nblk = grid.x * grid.y;
+        bool two_pass_stem = false;
         if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
         const DlvConvLayer& L = ctx->conv[0];
         DlvProf pr(ctx, (vol && !ctx->no_zmarch) ? "stem_mfma_u16" : "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
@@ -974,8 +990,14 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
             grid = dim3(tZ * tY * tX, 1, B);
             nblk = grid.x;
             if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
-            hipLaunchKernelGGL(stem_mfma_kernel<P>, grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim,
-                               reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, buf(0, A), net.partials, d, h, w, tY, tX);
+            const uint4* wst = reinterpret_cast<const uint4*>(wpack<P>(L));
+            hipLaunchKernelGGL((stem_mfma_kernel<P, 1>), grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim, wst,
+                               L.bias, buf(0, A), net.partials, (const float2*)nullptr, d, h, w, tY, tX);
+            DLV_LAUNCH_CHECK(ctx, "stem_mfma_kernel<1>");
+            DLV_TRY(net.stats(nblk, 0, dm[0]));
+            hipLaunchKernelGGL((stem_mfma_kernel<P, 2>), grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim, wst,
+                               L.bias, buf(0, A), net.partials, (const float2*)net.ss, d, h, w, tY, tX);
+            two_pass_stem = true;
         } else if (vol)
             hipLaunchKernelGGL((stem_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
                                flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
@@ -984,8 +1006,10 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
                                L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "stem_conv_kernel");
-        DLV_TRY(net.stats(nblk, 0, dm[0]));
-        DLV_TRY(net.norm_mish(buf(0, A), 32, dm[0], nullptr));
+        if (!two_pass_stem) {
+            DLV_TRY(net.stats(nblk, 0, dm[0]));
+            DLV_TRY(net.norm_mish(buf(0, A), 32, dm[0], nullptr));
+        }
     }
     DLV_TRY(net.conv(1, buf(0, A), 32, nullptr, 0, buf(0, S), dm[0]));
     DLV_TRY(net.norm_mish(buf(0, S), 32, dm[0], buf(1, A)));
