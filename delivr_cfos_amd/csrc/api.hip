@@ -210,6 +210,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     dlv_ctx* ctx = new (std::nothrow) dlv_ctx();
     if (!ctx) return DLV_ENOMEM;
     ctx->device = device_id;
+    if (const char* e = getenv("DLV_ZM_VARIANT")) ctx->zm_variant = atoi(e);
     ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
@@ -225,6 +226,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         ctx->own_stream = true;
     }
     ctx->main_stream = ctx->stream;
+    if (hipMalloc(&ctx->zero_page, 256) == hipSuccess) (void)hipMemset(ctx->zero_page, 0, 256);
     if (!getenv("DLV_ONE_LANE")) {
         bool ok = true;
         for (int k = 0; k < 3 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
@@ -255,6 +257,7 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
     for (int i = 0; i < WS_N_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->blob) (void)hipFree(ctx->blob);
+    if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     for (int k = 0; k < 3; ++k)
         if (ctx->aux[k]) {
             (void)hipStreamSynchronize(ctx->aux[k]);
@@ -374,6 +377,18 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
     if (precision == DLV_PREC_BF16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 0);
     if (precision == DLV_PREC_F16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 1);
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
+}
+
+int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant) {
+    if (!ctx) return DLV_EINVAL;
+    ctx->zm_variant = variant;
+    return DLV_OK;
+}
+
+int dlv_debug_stamps(dlv_ctx* ctx, void* buf_dev) {
+    if (!ctx) return DLV_EINVAL;
+    ctx->stamp_buf = buf_dev;
+    return DLV_OK;
 }
 
 int dlv_debug_set_format(dlv_ctx* ctx, int precision) {

@@ -78,6 +78,9 @@ struct dlv_ctx {
     // weights
     bool weights_loaded = false;
     int features[6] = {0, 0, 0, 0, 0, 0};
+    int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
+    void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
+    void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads
     void* blob = nullptr;  // one allocation holding every packed parameter
     size_t blob_bytes = 0;
     DlvConvLayer conv[DLV_N_CONV];
@@ -144,3 +147,20 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx);
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
                             const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts);
 size_t dlv_bf16_pack_bytes(const int features[6]);
+#if defined(__HIPCC__)
+// Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU
+// instructions, no LDS permute): the total is valid in lanes 16-31 resp. 48-63 - read it from lane 31 / 63.
+__device__ __forceinline__ float dlv_half_sum32(float v) {
+#define DLV_DPP_ADD(ctrl, rmask)                                                                                      \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
+    DLV_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    DLV_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    DLV_DPP_ADD(0x141, 0xf);  // row_half_mirror
+    DLV_DPP_ADD(0x140, 0xf);  // row_mirror: every lane holds its row's (16 lanes) total
+    DLV_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3: they now hold the 32-lane totals
+#undef DLV_DPP_ADD
+    return v;
+}
+#endif
+
+

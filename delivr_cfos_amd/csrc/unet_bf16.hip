@@ -324,12 +324,9 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float sa = ssum[r], sb = ssq[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            sa += __shfl_xor(sa, o, 64);
-            sb += __shfl_xor(sb, o, 64);
-        }
-        if (col == 0) {
+        sa = dlv_half_sum32(sa);  // DPP adds; totals valid in lanes 16-31 / 48-63
+        sb = dlv_half_sum32(sb);
+        if (col == 31) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
             red[(wave * 32 + co) * 2] = sa;
             red[(wave * 32 + co) * 2 + 1] = sb;
@@ -497,12 +494,9 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float a = s[r], b = q[r];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-            }
-            if (col == 0) {
+            a = dlv_half_sum32(a);  // DPP adds; totals valid in lanes 16-31 / 48-63
+            b = dlv_half_sum32(b);
+            if (col == 31) {
                 const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 red[(wave * NCB * 32 + co) * 2] = a;
                 red[(wave * NCB * 32 + co) * 2 + 1] = b;

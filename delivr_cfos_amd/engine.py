@@ -182,6 +182,10 @@ class HipEngine:
         self._leave()
         return out
 
+    def set_zm_variant(self, variant: int) -> None:
+        """A/B and diagnostic builds of the z-march conv (dlv_debug_set_zm_variant); 0 = default."""
+        self._check(self.lib.dlv_debug_set_zm_variant(self.ctx, int(variant)))
+
     def debug_layer_bf16(self, kind: int, index: int, in1, in2=None, precision: str = "bf16"):
         """test hook (dlv_debug_layer_bf16): one conv block / deconv of the bf16 path on fp32 tensors."""
         torch = self.torch

@@ -210,6 +210,14 @@ int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_
  * that tests/ can compare each kernel with the oracle in isolation.  kind 0: conv block `index`
  * (1..17: Conv3d k3 + InstanceNorm + Mish) on the channel concatenation [in1 (c1), in2 (c2, may be
  * 0)] -> out (B,Cout,D,H,W); kind 1: ConvTranspose3d `index` (0..3) -> out (B,Cout,2D,2H,2W). */
+/* selects a build variant of the z-marching 3x3x3 conv (same as the DLV_ZM_VARIANT environment variable read at
+ * dlv_ctx_create): 0 default; 3/4/6 tile, stagger and streaming-store variants; 20/24 double-buffered half-planes with
+ * register / LDS-DMA staging; 40 software-pipelined step; 11-13, 30, 41-45 timing-only or stamped diagnostic builds
+ * (profiles/README.md).  No reference counterpart. */
+int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant);
+/* diagnostic: buffer (caller-owned, HBM, >= tiles*8*(D+4)*64 bytes, zeroed) that the stamped build of the z-march
+ * conv (DLV_ZM_VARIANT=30) fills with s_memtime stamps of window 0; NULL switches it off.  No reference counterpart. */
+int dlv_debug_stamps(dlv_ctx* ctx, void* buf_dev);
 /* selects the 16-bit format dlv_debug_layer_bf16 runs in (DLV_PREC_BF16 default, DLV_PREC_F16) */
 int dlv_debug_set_format(dlv_ctx* ctx, int precision);
 int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,

@@ -257,3 +257,39 @@ def test_sw_pass_fp16_matches_fp32_engine(eng, golden_dir):
     assert np.isfinite(a16).all()
     rel = float(np.sqrt(np.mean((a16 - a32)[live] ** 2)) / a32[live].std())
     assert rel < 1e-2, rel
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in builds of the z-march conv (dlv_debug_set_zm_variant): same torch reference, same tolerance
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [6, 20, 24, 40])
+@pytest.mark.parametrize("li,c1,c2,prec", [(1, 32, 0, "fp16"), (16, 32, 32, "fp16"), (1, 32, 0, "bf16"), (16, 32, 32, "bf16")])
+def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
+    """Streaming-store (6), double-buffered half-plane (20), LDS-DMA (24) and software-pipelined (40) builds of the
+    32->32 / 64->32 conv block on a 40x24x64 window (3 z chunks of 16, an in-plane tile grid of 3x2, ragged z tail):
+    against conv3d+InstanceNorm+Mish in fp32 on the same 16-bit-rounded operands.  Variant 40 drops the conv bias
+    (InstanceNorm cancels it) and takes the statistics on the rounded values: same tolerance."""
+    import torch
+    import torch.nn.functional as F
+
+    D, H, W = 40, 24, 64
+    g = torch.Generator().manual_seed(li * 7 + variant)
+    rnd = (lambda t: t.half().float()) if prec == "fp16" else _bf
+    x1 = rnd(torch.randn((3, c1, D, H, W), generator=g))
+    x2 = rnd(torch.randn((3, c2, D, H, W), generator=g)) if c2 else None
+    blk = _conv_block(net, li)
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    with torch.no_grad():
+        raw = F.conv3d(xin, rnd(blk.conv.weight), blk.conv.bias, padding=1)
+        ref = F.mish(F.instance_norm(raw, weight=blk.adn.N.weight, bias=blk.adn.N.bias, eps=1e-5))
+    try:
+        eng.set_zm_variant(variant)
+        out = eng.debug_layer_bf16(0, li, x1.cuda(), None if x2 is None else x2.cuda(), precision=prec).cpu()
+    finally:
+        eng.set_zm_variant(0)
+    base = eng.debug_layer_bf16(0, li, x1.cuda(), None if x2 is None else x2.cuda(), precision=prec).cpu()
+    err = (out - ref).abs()
+    tol_max, tol_mean = (0.01, 1e-3) if prec == "fp16" else (0.06, 6e-3)
+    assert err.max() < tol_max, float(err.max())
+    assert err.mean() < tol_mean, float(err.mean())
+    assert (out - base).abs().max() < tol_max
