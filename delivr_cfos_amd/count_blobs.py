@@ -41,10 +41,44 @@ def _label_dtype(n: int):
     return np.uint16 if n < 2**16 else np.uint32
 
 
+def _even_slabs(Z: int, world: int):
+    cuts = [(Z * r) // world for r in range(world + 1)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _count_blobs_sharded(eng, bin_img, dist):
+    """One process per GPU: every rank labels a Z-slab of the mask, seams are merged (parallel.ccl_sharded); rank 0
+    receives the label slabs and the merged statistics.  Returns (labels ndarray | None, N, stats | None)."""
+    import torch
+    from .parallel import ShardPlan, ccl_sharded, gather_slabs
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    Z, Y, X = bin_img.shape
+    slabs = _even_slabs(Z, world)
+    lo, hi = slabs[rank]
+    slab = eng.to_device(np.ascontiguousarray(bin_img[lo:hi])) if hi > lo else None
+    labels, N, stats = ccl_sharded(eng, slab, slabs, rank, dist, (Z, Y, X))
+    plan = ShardPlan(world, 0, [(0, 0)] * world, slabs, slabs)
+    # label slabs travel HBM -> HBM (RCCL p2p over xGMI; 17 GB of labels for a 1024x2048x2048 volume fit rank 0's HBM)
+    full = torch.empty((Z, Y, X), dtype=torch.int32, device=eng.device) if rank == 0 else None
+    gather_slabs(labels, plan, rank, dist, out=full)
+    if rank != 0:
+        return None, N, None
+    return full.cpu().numpy().view(np.uint32), N, stats
+
+
 def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max_size=-1, engine=None):
     """Same positional parameters as the reference.  ``engine``: a HipEngine to reuse (one is
-    created on device 0 otherwise)."""
+    created on device 0 otherwise).  Under torch.distributed (one process per GPU) the labelling is sharded over the
+    ranks along z; rank 0 writes the files, every rank returns N."""
     from .engine import HipEngine
+
+    try:
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except ImportError:  # pragma: no cover
+        dist, sharded = None, False
+    rank = dist.get_rank() if sharded else 0
 
     path_out = settings["postprocessing"]["output_location"]
     if not os.path.exists(path_out):
@@ -56,8 +90,24 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
     shape = tuple(int(v) for v in stack_shape[2:])
     bin_img = np.memmap(brain_path, dtype=np.uint8, mode="r", shape=shape, offset=128)
     own = engine is None
-    eng = engine or HipEngine(0)
+    eng = engine or HipEngine(int(os.environ.get("LOCAL_RANK", 0)) if sharded else 0)
     labels_dev = None
+    if sharded and not load_cached_brain(settings, brain):
+        try:
+            labels, N, stats = _count_blobs_sharded(eng, bin_img, dist)
+        finally:
+            if own:
+                eng.close()
+        if rank == 0:
+            np.save(os.path.join(path_out, f"{brain}-{N}-cc3d.npy"), labels.astype(_label_dtype(N), copy=False))
+            with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
+                pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
+            with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
+                fh.write(cells_csv_text(stats, N))
+            end = datetime.datetime.now()
+            print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
+        dist.barrier()
+        return N
     try:
         cached = load_cached_brain(settings, brain)
         if not cached:

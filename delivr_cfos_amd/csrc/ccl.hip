@@ -10,6 +10,8 @@
 // compression, then a raster-order renumbering of the roots by a two-level prefix sum.  Integer
 // work only: results are bit-exact and independent of scheduling.
 #include "common.h"
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -298,6 +300,69 @@ __global__ void __launch_bounds__(256) cc_stats_kernel(const u32* __restrict__ l
     }
 }
 
+
+// ---- multi-GPU seam merge: slabs are labelled independently; these kernels supply the pairs of
+// labels that touch across a slab boundary and apply the global renumbering --------------------------------------
+// a = labels of the last plane of the upper slab, b = labels of the first plane of the slab below it.  Every
+// 26-adjacency across the seam is one of the 9 (dy,dx) neighbours in b of a voxel in a.  Emits (a,b) when the
+// pair differs from the one the same voxel produced for the previous neighbour (cheap local dedupe; the host
+// makes the list unique).  pairs == nullptr: count only.
+__global__ void __launch_bounds__(256) seam_pairs_kernel(const u32* __restrict__ a, const u32* __restrict__ b, int Y, int X,
+                                                         u32* __restrict__ pairs, u64 cap, u64* __restrict__ count) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)Y * X) return;
+    const u32 la = a[t];
+    if (!la) return;
+    const int x = (int)(t % X), y = (int)(t / X);
+    u32 prev = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)Y) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)X) continue;
+            const u32 lb = b[(u64)yy * X + xx];
+            if (!lb || lb == prev) continue;
+            prev = lb;
+            const u64 slot = atomicAdd(count, 1ull);
+            if (pairs && slot < cap) {
+                pairs[2 * slot] = la;
+                pairs[2 * slot + 1] = lb;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) relabel_lut_kernel(u32* __restrict__ labels, u64 n, const u32* __restrict__ lut) {
+    // 4 labels per thread (16-byte accesses); background (0) maps to lut[0] = 0 without a table read
+    const u64 n4 = n / 4;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (u64)gridDim.x * blockDim.x) {
+        uint4 v = reinterpret_cast<uint4*>(labels)[i];
+        if (v.x | v.y | v.z | v.w) {
+            v.x = v.x ? lut[v.x] : 0u;
+            v.y = v.y ? lut[v.y] : 0u;
+            v.z = v.z ? lut[v.z] : 0u;
+            v.w = v.w ? lut[v.w] : 0u;
+            reinterpret_cast<uint4*>(labels)[i] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const u64 i = n4 * 4 + threadIdx.x;
+        const u32 l = labels[i];
+        if (l) labels[i] = lut[l];
+    }
+}
+
+// shared by dlv_cc_stats_dev / dlv_cc_stats_raw_dev: raw per-label accumulators copied to the host
+struct StatsRaw {
+    std::vector<char> host;
+    size_t off_min, off_max, off_sum, rows;
+    const u32* counts() const { return (const u32*)host.data(); }
+    const u32* bbmin() const { return (const u32*)(host.data() + off_min); }
+    const u32* bbmax() const { return (const u32*)(host.data() + off_max); }
+    const u64* sums() const { return (const u64*)(host.data() + off_sum); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -340,39 +405,47 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     return DLV_OK;
 }
 
-int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* voxel_counts,
-                     uint16_t* bounding_boxes, double* centroids) {
-    if (!ctx || !labels_dev || !voxel_counts || !bounding_boxes || !centroids) return DLV_EINVAL;
+static int cc_stats_raw(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, StatsRaw& r) {
     if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty volume");
-    if (Z > 65536 || Y > 65536 || X > 65536) return dlv_fail(ctx, DLV_EUNSUP, "bounding boxes are uint16");
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     const u64 nvox = (u64)Z * Y * X;
     const size_t rows = (size_t)n + 1;
     // [counts u32 rows | bbmin u32 3*rows | bbmax u32 3*rows | pad | sums u64 3*rows]
-    const size_t off_min = rows * 4, off_max = off_min + rows * 12;
-    const size_t off_sum = (off_max + rows * 12 + 7) & ~(size_t)7;
-    const size_t bytes = off_sum + rows * 24;
+    r.rows = rows;
+    r.off_min = rows * 4;
+    r.off_max = r.off_min + rows * 12;
+    r.off_sum = (r.off_max + rows * 12 + 7) & ~(size_t)7;
+    const size_t bytes = r.off_sum + rows * 24;
     char* ws;
     DLV_TRY(dlv_ws_get(ctx, WS_MISC, bytes, (void**)&ws));
     DLV_HIP(ctx, hipMemsetAsync(ws, 0, bytes, ctx->stream));
-    DLV_HIP(ctx, hipMemsetAsync(ws + off_min, 0xff, rows * 12, ctx->stream));
+    DLV_HIP(ctx, hipMemsetAsync(ws + r.off_min, 0xff, rows * 12, ctx->stream));
     u32* counts = (u32*)ws;
-    u32* bbmin = (u32*)(ws + off_min);
-    u32* bbmax = (u32*)(ws + off_max);
-    u64* sums = (u64*)(ws + off_sum);
+    u32* bbmin = (u32*)(ws + r.off_min);
+    u32* bbmax = (u32*)(ws + r.off_max);
+    u64* sums = (u64*)(ws + r.off_sum);
     const u64 nitems = (u64)Z * Y * ((X + SPT - 1) / SPT);
     const int gs = (int)std::min<u64>((nitems + 255) / 256, (u64)256 * 32);
     DlvProf pr(ctx, "cc_stats", 0.0, (double)nvox * 4);
     hipLaunchKernelGGL(cc_stats_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_dev, Z, Y, X, counts, sums, bbmin, bbmax);
     pr.end();
     DLV_LAUNCH_CHECK(ctx, "cc_stats_kernel");
-    std::vector<char> host(bytes);
-    DLV_HIP(ctx, hipMemcpyAsync(host.data(), ws, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    r.host.resize(bytes);
+    DLV_HIP(ctx, hipMemcpyAsync(r.host.data(), ws, bytes, hipMemcpyDeviceToHost, ctx->stream));
     DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const u32* hc = (const u32*)host.data();
-    const u32* hmin = (const u32*)(host.data() + off_min);
-    const u32* hmax = (const u32*)(host.data() + off_max);
-    const u64* hs = (const u64*)(host.data() + off_sum);
+    return DLV_OK;
+}
+
+int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* voxel_counts,
+                     uint16_t* bounding_boxes, double* centroids) {
+    if (!ctx || !labels_dev || !voxel_counts || !bounding_boxes || !centroids) return DLV_EINVAL;
+    if (Z > 65536 || Y > 65536 || X > 65536) return dlv_fail(ctx, DLV_EUNSUP, "bounding boxes are uint16");
+    StatsRaw r;
+    DLV_TRY(cc_stats_raw(ctx, labels_dev, Z, Y, X, n, r));
+    const u64 nvox = (u64)Z * Y * X;
+    const size_t rows = r.rows;
+    const u32 *hc = r.counts(), *hmin = r.bbmin(), *hmax = r.bbmax();
+    const u64* hs = r.sums();
     u64 fg = 0, fs[3] = {0, 0, 0};
     for (size_t l = 1; l < rows; ++l) {
         voxel_counts[l] = hc[l];
@@ -394,6 +467,47 @@ int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int
         bounding_boxes[2 * k] = bgc ? (uint16_t)hmin[k] : 0;
         bounding_boxes[2 * k + 1] = bgc ? (uint16_t)hmax[k] : 0;
     }
+    return DLV_OK;
+}
+
+int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* counts,
+                         uint32_t* bbmin, uint32_t* bbmax, uint64_t* sums) {
+    if (!ctx || !labels_dev || !counts || !bbmin || !bbmax || !sums) return DLV_EINVAL;
+    StatsRaw r;
+    DLV_TRY(cc_stats_raw(ctx, labels_dev, Z, Y, X, n, r));
+    memcpy(counts, r.counts(), r.rows * 4);
+    memcpy(bbmin, r.bbmin(), r.rows * 12);
+    memcpy(bbmax, r.bbmax(), r.rows * 12);
+    memcpy(sums, r.sums(), r.rows * 24);
+    return DLV_OK;
+}
+
+int dlv_seam_pairs_dev(dlv_ctx* ctx, const uint32_t* plane_a_dev, const uint32_t* plane_b_dev, int Y, int X,
+                       uint32_t* pairs_dev, uint64_t cap, uint64_t* count_out) {
+    if (!ctx || !plane_a_dev || !plane_b_dev || !count_out) return DLV_EINVAL;
+    if (Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty plane");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    u64* cnt;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, 8, (void**)&cnt));
+    DLV_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    const u64 n = (u64)Y * X;
+    hipLaunchKernelGGL(seam_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, plane_a_dev,
+                       plane_b_dev, Y, X, pairs_dev, pairs_dev ? cap : 0, cnt);
+    DLV_LAUNCH_CHECK(ctx, "seam_pairs_kernel");
+    DLV_HIP(ctx, hipMemcpyAsync(count_out, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+
+int dlv_relabel_u32_dev(dlv_ctx* ctx, uint32_t* labels_dev, uint64_t nvox, const uint32_t* lut_dev, uint64_t lut_len) {
+    if (!ctx || !labels_dev || !lut_dev) return DLV_EINVAL;
+    if (lut_len == 0) return dlv_fail(ctx, DLV_EINVAL, "empty lookup table");
+    if (nvox == 0) return DLV_OK;
+    if ((uintptr_t)labels_dev & 15) return dlv_fail(ctx, DLV_EINVAL, "labels must be 16-byte aligned");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const int gs = (int)std::min<u64>((nvox / 4 + 255) / 256 + 1, (u64)256 * 32);
+    hipLaunchKernelGGL(relabel_lut_kernel, dim3(gs), dim3(256), 0, ctx->stream, labels_dev, (u64)nvox, lut_dev);
+    DLV_LAUNCH_CHECK(ctx, "relabel_lut_kernel");
     return DLV_OK;
 }
 

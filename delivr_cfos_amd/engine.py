@@ -307,6 +307,50 @@ class HipEngine:
         self._leave()
         return {"voxel_counts": counts, "bounding_boxes": bbox, "centroids": cent}
 
+    def cc_stats_raw(self, labels, n: int) -> dict:
+        """Accumulators behind cc_stats (dlv_cc_stats_raw_dev): counts u32, bbmin/bbmax u32 (n+1,3), sums u64 (n+1,3)."""
+        Z, Y, X = (int(v) for v in labels.shape)
+        counts = np.zeros(n + 1, dtype=np.uint32)
+        bbmin = np.zeros((n + 1, 3), dtype=np.uint32)
+        bbmax = np.zeros((n + 1, 3), dtype=np.uint32)
+        sums = np.zeros((n + 1, 3), dtype=np.uint64)
+        self._enter()
+        self._check(self.lib.dlv_cc_stats_raw_dev(self.ctx, C.c_void_p(labels.data_ptr()), Z, Y, X, n,
+                                                  counts.ctypes.data_as(C.c_void_p), bbmin.ctypes.data_as(C.c_void_p),
+                                                  bbmax.ctypes.data_as(C.c_void_p), sums.ctypes.data_as(C.c_void_p)))
+        self._leave()
+        return {"counts": counts, "bbmin": bbmin, "bbmax": bbmax, "sums": sums}
+
+    def seam_pairs(self, plane_a, plane_b) -> np.ndarray:
+        """Unique (label in plane_a, label in plane_b) pairs that are 26-adjacent across a slab seam; (k,2) uint32,
+        sorted (dlv_seam_pairs_dev: count pass, then emit pass)."""
+        torch = self.torch
+        Y, X = (int(v) for v in plane_a.shape)
+        a = self._dev(plane_a, torch.int32, "plane_a")
+        b = self._dev(plane_b, torch.int32, "plane_b")
+        cnt = C.c_uint64()
+        self._enter()
+        self._check(self.lib.dlv_seam_pairs_dev(self.ctx, a, b, Y, X, None, 0, C.byref(cnt)))
+        k = int(cnt.value)
+        if k == 0:
+            self._leave()
+            return np.zeros((0, 2), dtype=np.uint32)
+        pairs = torch.empty((k, 2), dtype=torch.int32, device=self.device)
+        self._check(self.lib.dlv_seam_pairs_dev(self.ctx, a, b, Y, X, C.c_void_p(pairs.data_ptr()), k, C.byref(cnt)))
+        self._leave()
+        assert int(cnt.value) == k
+        return np.unique(pairs.cpu().numpy().view(np.uint32), axis=0)
+
+    def relabel(self, labels, lut: np.ndarray) -> None:
+        """labels[i] = lut[labels[i]] in place (dlv_relabel_u32_dev); lut: uint32 (n_local+1,), lut[0] = 0."""
+        torch = self.torch
+        lut_dev = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.uint32).view(np.int32)).to(self.device)
+        self._enter()
+        self._check(self.lib.dlv_relabel_u32_dev(self.ctx, C.c_void_p(labels.data_ptr()), int(labels.numel()),
+                                                 C.c_void_p(lut_dev.data_ptr()), int(lut_dev.numel())))
+        self._leave()
+        self.sync()
+
     # ---- resamplers --------------------------------------------------------------------------------
     def block_mean_u16(self, vol, factors):
         torch = self.torch

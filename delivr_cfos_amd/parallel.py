@@ -11,6 +11,14 @@ re-broadcast and gather through GPU 0) with:
   * each rank finalizes the planes it owns; mask slabs are gathered to rank 0 on request.
 No all-reduce is needed on this path.
 
+Connected components over the sharded mask: every rank labels the planes it owns, the ranks
+exchange ONE boundary plane of provisional labels per seam, the (label, label) pairs that touch across a seam are
+united in a small host-side union-find over (rank, local label) nodes, and every rank renumbers its slab with a
+lookup table.  Because local labels are numbered in raster order and slabs are ordered along z, "component with
+the smallest (rank, local label) member first" IS the raster order of the components' first voxels - the merged
+labels equal the single-volume labelling bit for bit, for any number of shards (tests/test_host_cpu.py with gloo,
+tests/test_gpu_pipeline.py on the device).
+
 The plan is pure integer arithmetic (testable without a GPU); the exchange works on any
 torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
@@ -212,3 +220,164 @@ def finalize_owned(engine, plan: ShardPlan, rank: int, acc, cnt, vol, stack_shap
                           threshold, erode_iters, nb, want_prob=want_prob)
     mask, prob = res if want_prob else (res, None)
     return mask[lo - blo: hi - blo], (None if prob is None else prob[lo - blo: hi - blo]), (lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# connected components over Z-slabs
+# ---------------------------------------------------------------------------------------------------------------
+def merge_components(counts: Sequence[int], seam_pairs: Sequence[Tuple[int, int, np.ndarray]]):
+    """counts[r] = number of local components of slab r (slabs in z order; 0 for an empty slab).
+    seam_pairs: (r_upper, r_lower, pairs (k,2)) - local labels of r_upper / r_lower that touch across their seam.
+    Returns (luts, N): luts[r] uint32 (counts[r]+1,) maps a local label to the global one (luts[r][0] = 0);
+    global labels 1..N are numbered by the smallest (slab, local label) member of each component."""
+    counts = [int(c) for c in counts]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)   # node id = offs[r] + local label - 1
+    total = int(offs[-1])
+    roots = np.arange(total, dtype=np.int64)
+    # only the components that touch a seam take part in the union-find (a few thousand of up to millions)
+    edges = []
+    for ra, rb, pairs in seam_pairs:
+        pr = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        if len(pr):
+            edges.append(np.stack([offs[ra] + pr[:, 0] - 1, offs[rb] + pr[:, 1] - 1], axis=1))
+    if edges:
+        e = np.unique(np.concatenate(edges), axis=0)
+        nodes, inv = np.unique(e.ravel(), return_inverse=True)       # nodes ascending: compact index order = id order
+        inv = inv.reshape(-1, 2)
+        parent = list(range(len(nodes)))
+
+        def find(i):
+            root = i
+            while parent[root] != root:
+                root = parent[root]
+            while parent[i] != root:
+                parent[i], i = root, parent[i]
+            return root
+
+        for a, b in inv.tolist():
+            a, b = find(a), find(b)
+            if a != b:
+                if a < b:
+                    parent[b] = a
+                else:
+                    parent[a] = b
+        roots[nodes] = nodes[np.array([find(i) for i in range(len(nodes))], dtype=np.int64)]
+    # the root is the minimum node id of its component (unions always keep the smaller id)
+    is_root = roots == np.arange(total)
+    rank_of_root = np.cumsum(is_root)            # 1-based raster rank of each root
+    glob = rank_of_root[roots].astype(np.uint32)
+    luts = []
+    for r, c in enumerate(counts):
+        lut = np.zeros(c + 1, dtype=np.uint32)
+        lut[1:] = glob[offs[r]: offs[r] + c]
+        luts.append(lut)
+    return luts, int(is_root.sum())
+
+
+def merge_stats(luts, raws, z_offsets, shape, n_total: int) -> dict:
+    """Per-slab raw statistics (engine.cc_stats_raw; None for an empty slab) -> the cc3d.statistics layout of the
+    whole volume (count_blobs.py:85): voxel_counts uint32, bounding_boxes uint16 (N+1,6) inclusive, centroids float64."""
+    Z, Y, X = (int(v) for v in shape)
+    rows = n_total + 1
+    counts = np.zeros(rows, dtype=np.uint64)
+    sums = np.zeros((rows, 3), dtype=np.uint64)
+    bbmin = np.full((rows, 3), np.iinfo(np.uint32).max, dtype=np.uint64)
+    bbmax = np.zeros((rows, 3), dtype=np.uint64)
+    for lut, raw, z0 in zip(luts, raws, z_offsets):
+        if raw is None:
+            continue
+        c = raw["counts"].astype(np.uint64)
+        present = c > 0
+        present[0] = False
+        g = lut.astype(np.int64)
+        idx = g[present]
+        np.add.at(counts, idx, c[present])
+        s = raw["sums"].astype(np.uint64).copy()
+        s[:, 0] += c * np.uint64(z0)                      # slab-local z -> volume z
+        np.add.at(sums, idx, s[present])
+        lo = raw["bbmin"].astype(np.uint64).copy()
+        hi = raw["bbmax"].astype(np.uint64).copy()
+        lo[:, 0] += np.uint64(z0)
+        hi[:, 0] += np.uint64(z0)
+        np.minimum.at(bbmin, idx, lo[present])
+        np.maximum.at(bbmax, idx, hi[present])
+        # background box of this slab (row 0 of the raw arrays is valid when the slab has any background voxel)
+        if raw["bbmin"][0, 0] != np.iinfo(np.uint32).max:
+            bbmin[0] = np.minimum(bbmin[0], lo[0])
+            bbmax[0] = np.maximum(bbmax[0], hi[0])
+    nvox = Z * Y * X
+    fg = int(counts[1:].sum())
+    bgc = nvox - fg
+    counts[0] = bgc
+    dims = (Z, Y, X)
+    fs = sums[1:].sum(axis=0)
+    cent = np.full((rows, 3), np.nan, dtype=np.float64)
+    nz = counts[1:] > 0
+    cent[1:][nz] = sums[1:][nz].astype(np.float64) / counts[1:][nz].astype(np.float64)[:, None]
+    bbox = np.zeros((rows, 6), dtype=np.uint16)
+    bbox[1:, 0::2] = bbmin[1:].astype(np.uint16)
+    bbox[1:, 1::2] = bbmax[1:].astype(np.uint16)
+    for k in range(3):
+        allk = (nvox // dims[k]) * (dims[k] * (dims[k] - 1) // 2)
+        if bgc:
+            cent[0, k] = float(allk - int(fs[k])) / float(bgc)
+            bbox[0, 2 * k], bbox[0, 2 * k + 1] = int(bbmin[0, k]), int(bbmax[0, k])
+    return {"voxel_counts": counts.astype(np.uint32), "bounding_boxes": bbox, "centroids": cent}
+
+
+def slab_ranges(plan: ShardPlan, Z: int) -> List[Tuple[int, int]]:
+    """Planes [lo, hi) of the UNPADDED volume each rank owns (the padded tail belongs to nobody)."""
+    return [(min(lo, Z), min(hi, Z)) for lo, hi in plan.z_owned]
+
+
+def ccl_sharded(engine, mask_slab, slabs: Sequence[Tuple[int, int]], rank: int, dist, shape, want_stats: bool = True,
+                group=None):
+    """26-connectivity labelling of a mask whose Z-slabs live on different ranks.
+    mask_slab: uint8 (hi-lo, Y, X) in HBM, the planes slabs[rank] of the volume (None / empty for a rank without planes).
+    Returns (labels_slab int32 tensor (uint32 payload) or None, N, stats or None): labels are the GLOBAL ones, identical
+    to a single-volume cc3d.connected_components; stats (rank 0 only, when want_stats) in cc3d.statistics layout."""
+    import torch
+
+    world = len(slabs)
+    live = [r for r in range(world) if slabs[r][1] > slabs[r][0]]
+    mine = rank in live
+    labels, n_local = (engine.ccl26(mask_slab) if mine else (None, 0))
+    # one boundary plane per seam: the lower slab sends its first plane of provisional labels to the upper one
+    pairs = np.zeros((0, 2), dtype=np.uint32)
+    if mine and len(live) > 1:
+        k = live.index(rank)
+        upper = live[k - 1] if k > 0 else None
+        lower = live[k + 1] if k + 1 < len(live) else None
+        stage = _needs_host_staging(labels, dist)
+        ops, recv_buf = [], None
+        if upper is not None:
+            t = labels[0].contiguous()
+            ops.append(dist.P2POp(dist.isend, t.cpu() if stage else t, upper, group=group))
+        if lower is not None:
+            recv_buf = torch.empty_like(labels[0], device="cpu") if stage else torch.empty_like(labels[0])
+            ops.append(dist.P2POp(dist.irecv, recv_buf, lower, group=group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if lower is not None:
+            pairs = engine.seam_pairs(labels[-1], recv_buf.to(labels.device) if stage else recv_buf)
+    # tiny all-gather: component counts and seam pairs of every rank; every rank runs the same merge
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (int(n_local), pairs), group=group)
+    counts = [g[0] for g in gathered]
+    seams = []
+    for k, r in enumerate(live[:-1]):
+        if len(gathered[r][1]):
+            seams.append((r, live[k + 1], gathered[r][1]))
+    luts, n_total = merge_components(counts, seams)
+    raw = None
+    if mine:
+        if want_stats:
+            raw = engine.cc_stats_raw(labels, n_local)   # on the local labels: the table maps the rows afterwards
+        engine.relabel(labels, luts[rank])
+    stats = None
+    if want_stats:
+        raws = [None] * world
+        dist.gather_object(raw, raws if rank == 0 else None, dst=0, group=group)
+        if rank == 0:
+            stats = merge_stats(luts, raws, [s[0] for s in slabs], shape, n_total)
+    return labels, n_total, stats

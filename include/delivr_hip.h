@@ -170,6 +170,23 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
 int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n,
                      uint32_t* voxel_counts, uint16_t* bounding_boxes, double* centroids);
 
+/* Multi-GPU CCL (one process per GPU, every rank labels its own Z-slab with dlv_ccl26_dev): the pieces of the seam
+ * merge that run on the device.  The reference has no counterpart - cc3d labels the whole volume on one core
+ * (count_blobs.py:61); the contract is that the merged result is identical to that single-volume labelling.
+ *  dlv_seam_pairs_dev: plane_a = labels of the LAST plane of a slab, plane_b = labels of the FIRST plane of the slab
+ *    below it (both (Y,X) uint32).  Writes every (label_a, label_b) pair that is 26-adjacent across the seam (with
+ *    repeats) to pairs_dev (cap pairs of 2 x uint32) and the number of pairs found to *count_out; pairs_dev == NULL
+ *    counts only.  Synchronous.
+ *  dlv_relabel_u32_dev: labels[i] = lut[labels[i]] for labels[i] != 0 (lut_len = n_local + 1, lut[0] unused).
+ *  dlv_cc_stats_raw_dev: the accumulators behind dlv_cc_stats_dev, host arrays of n+1 rows: counts uint32, bbmin /
+ *    bbmax uint32 (n+1,3) in z,y,x (0xffffffff / 0 for an absent label), coordinate sums uint64 (n+1,3); row 0
+ *    (background) carries its bounding box only.  Synchronous. */
+int dlv_seam_pairs_dev(dlv_ctx* ctx, const uint32_t* plane_a_dev, const uint32_t* plane_b_dev, int Y, int X,
+                       uint32_t* pairs_dev, uint64_t cap, uint64_t* count_out);
+int dlv_relabel_u32_dev(dlv_ctx* ctx, uint32_t* labels_dev, uint64_t nvox, const uint32_t* lut_dev, uint64_t lut_len);
+int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* counts,
+                         uint32_t* bbmin, uint32_t* bbmax, uint64_t* sums);
+
 /* ---- resamplers (the steps either side of the path) ----------------------------------------- */
 /* transform.downscale_local_mean(chunk,(fz,fy,fx)).astype(uint16) (downsample_and_mask.py:44):
  * out (ceil(Z/fz),ceil(Y/fy),ceil(X/fx)) = floor(sum over zero-padded block / (fz*fy*fx)). */

@@ -141,3 +141,140 @@ def test_default_config_window_96_96_64():
     rel16 = float(np.sqrt(np.mean((accs["fp16"] - accs["fp32"]) ** 2)) / accs["fp32"].std())
     assert rel16 < 1e-2, rel16
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-rank connected components: one process per rank, all on device 0 (gloo rendezvous), real HIP kernels
+# ---------------------------------------------------------------------------------------------------
+def _ccl_volume():
+    rng = np.random.default_rng(11)
+    m = (rng.random((90, 70, 130)) < 0.08).astype(np.uint8)
+    m[5:80, 33, 64] = 1            # a column through every seam
+    m[40:50, :, 100:] = 0
+    m[:, 60:, :] |= (rng.random((90, 10, 130)) < 0.5).astype(np.uint8)   # a dense band: large merged components
+    return m
+
+
+class _ThreadDist:
+    """The torch.distributed calls ccl_sharded makes, between THREADS of this process (one HipEngine per thread, all on
+    device 0).  A GPU-initialised process must not start other programs on this pool, so the ranks cannot be processes
+    here; the process-per-rank path itself runs over gloo in tests/test_host_cpu.py."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+        self.bar = threading.Barrier(world)
+        self.box = [None] * world
+        self.local = threading.local()
+
+    # -- per-thread rank --
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def get_backend(self):
+        return "threads"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def batch_isend_irecv(self, ops):
+        me = self.local.rank
+        for o in ops:
+            if o.op == "isend":
+                self.q[(me, o.peer)].put(o.tensor.clone())
+        for o in ops:
+            if o.op == "irecv":
+                o.tensor.copy_(self.q[(o.peer, me)].get(timeout=120))
+        return [self._Done() for _ in ops]
+
+    def all_gather_object(self, out, obj, group=None):
+        self.box[self.local.rank] = obj
+        self.bar.wait()
+        for i in range(self.world):
+            out[i] = self.box[i]
+        self.bar.wait()
+
+    def gather_object(self, obj, out, dst=0, group=None):
+        self.box[self.local.rank] = obj
+        self.bar.wait()
+        if self.local.rank == dst:
+            for i in range(self.world):
+                out[i] = self.box[i]
+        self.bar.wait()
+
+
+def _run_sharded_ccl(cuts, m):
+    import threading
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.parallel import ccl_sharded
+
+    world = len(cuts) - 1
+    slabs = [(cuts[r], cuts[r + 1]) for r in range(world)]
+    fake = _ThreadDist(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            fake.bind(rank)
+            torch.cuda.set_device(0)
+            eng = HipEngine(0)
+            lo, hi = slabs[rank]
+            slab = torch.from_numpy(m[lo:hi].copy()).cuda() if hi > lo else None
+            labels, n, stats = ccl_sharded(eng, slab, slabs, rank, fake, m.shape)
+            results[rank] = (None if labels is None else labels.cpu().numpy(), n, stats)
+            eng.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                fake.bar.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cuts", [(0, 44, 90), (0, 30, 30, 90), (0, 1, 47, 90)])
+def test_sharded_ccl_on_device_equals_single_volume(tmp_path, cuts):
+    """dlv_ccl26_dev per slab + dlv_seam_pairs_dev + host union + dlv_relabel_u32_dev + dlv_cc_stats_raw_dev ==
+    one dlv_ccl26_dev / dlv_cc_stats_dev over the whole volume == the oracle, bit for bit."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from oracle import delivr_oracle as orc
+
+    world = len(cuts) - 1
+    res = _run_sharded_ccl(cuts, _ccl_volume())
+    m = _ccl_volume()
+    eng = HipEngine(0)
+    lab, n = eng.ccl26(torch.from_numpy(m).cuda())
+    single = lab.cpu().numpy()
+    st1 = eng.cc_stats(lab, n)
+    eng.close()
+    ref, n_ref = orc.ccl26(m)
+    assert n == n_ref
+    np.testing.assert_array_equal(single.view(np.uint32), ref)
+    out = np.zeros(m.shape, dtype=np.int32)
+    for r in range(world):
+        if cuts[r + 1] > cuts[r]:
+            out[cuts[r]:cuts[r + 1]] = res[r][0]
+        assert res[r][1] == n
+    np.testing.assert_array_equal(out, single)
+    st = res[0][2]
+    for k in ("voxel_counts", "bounding_boxes", "centroids"):
+        np.testing.assert_array_equal(st[k], st1[k])
