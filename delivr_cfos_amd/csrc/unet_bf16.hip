@@ -66,10 +66,18 @@ __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 64 * 8) return;
     const int j = i & 7, lane = (i >> 3) & 63, s = i >> 9;
-    const int k = 16 * s + 8 * (lane >> 5) + j;
-    const int part = k >> 5, tap = k & 31, co = lane & 31;
+    const int co = lane & 31;
     float v = 0.f;
-    if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f) * P::STEM_SCALE;
+    if (P::IS_F16) {
+        // k-step s, lane half h: taps 8s + 4h + (j >> 1), low byte (j even) then high byte (j odd) of the same tap -
+        // the order in which stem_mfma_kernel builds its operand (one v_perm_b32 per tap)
+        const int tap = 8 * s + 4 * (lane >> 5) + (j >> 1);
+        if (tap < 27) v = w[co * 27 + tap] * ((j & 1) ? 256.f : 1.f) * P::STEM_SCALE;
+    } else {
+        const int k = 16 * s + 8 * (lane >> 5) + j;
+        const int part = k >> 5, tap = k & 31;
+        if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f) * P::STEM_SCALE;
+    }
     out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
 }
 // deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
@@ -265,10 +273,35 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
     __syncthreads();
     const long long vox = (long long)D * H * W;
     const int oz = z0 + wave;
+    // fp16: per-lane LDS byte addresses of this lane's 16 taps (k-step s, slot q: tap 8s + 4h + q), row 0; the row
+    // loop is unrolled so that the row offset is an immediate of the ds_read
+    unsigned short const* tap_ptr[16];
+    if (P::IS_F16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = 8 * (i >> 2) + 4 * h + (i & 3);
+            const int tt = t < 27 ? t : 0;  // padding slots: any finite value (their weights are 0)
+            tap_ptr[i] = tile_u16 + (wave * SM_HY * SM_HX + col) + ((tt / 9) * SM_HY + (tt / 3) % 3) * SM_HX + tt % 3;
+        }
+    }
+#pragma unroll
     for (int row = 0; row < SM_TY; ++row) {
+        unsigned hi0[4], lo0[4], hi1[4], lo1[4];
+        if (P::IS_F16) {
+            // x = 256*hi + lo.  (0x6400 | byte) is the fp16 number 1024 + byte: one v_perm_b32 puts both bytes of a tap
+            // into the two halves of a register, one v_pk_add_f16 subtracts the 1024s - exact, 2 VALU ops per tap
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned u = tap_ptr[i][row * SM_HX];
+                const unsigned m = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
+                const unsigned v = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, m) - k1024);
+                (i < 4 ? hi0 : i < 8 ? hi1 : i < 12 ? lo0 : lo1)[i & 3] = v;  // k-steps 0..3 in MFMA order below
+            }
+        } else {
         // taps of this lane: slots 8h..8h+7 (k-steps 0 and 2) and 16+8h..16+8h+7 (k-steps 1 and 3)
         const int base = (wave * SM_HY + row) * SM_HX + col;
-        unsigned hi0[4], lo0[4], hi1[4], lo1[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             float fh[2], fl[2], gh[2], gl[2];
@@ -290,6 +323,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
             hi1[jj] = P::pack2(gh[0], gh[1]);
             lo1[jj] = P::pack2(gl[0], gl[1]);
         }
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -301,13 +335,17 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
         const bool ok = oz < D && oy < H && ox < W;
         float val[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            val[r] = acc[r] + bs[r];
-            if (MODE != 2 && ok) {
+        for (int r = 0; r < 16; ++r) val[r] = acc[r] + bs[r];
+        if (MODE != 2 && ok) {  // one exec-masked block (per-element selects cost two v_cndmask per value)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 ssum[r] += val[r];
                 ssq[r] = fmaf(val[r], val[r], ssq[r]);
             }
-            if (MODE == 2) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
         }
         if (MODE != 1 && ok) {
             const long long o = ((long long)oz * H + oy) * W + ox;
