@@ -88,11 +88,26 @@ def main(argv=None) -> int:
             stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
             count_blobs(settings, path_in, i, brain, stack_shape, settings["postprocessing"]["min_size"],
                         settings["postprocessing"]["max_size"])
-    for k in ("ATLAS_ALIGNMENT", "REGION_ASSIGNMENT", "VISUALIZATION"):
+    for k in ("ATLAS_ALIGNMENT", "REGION_ASSIGNMENT"):
         if flags.get(k):
             step_no += 1
             print(f"HOOK:{step_no}:{len(steps)}:0:0")
             print(f"{k}: wraps external binaries / table work - not part of the accelerated path, skipped")
+    if flags.get("VISUALIZATION"):
+        # reference __main__.py:210-221; needs the cells_<brain>.csv written by the (external) region assignment step
+        step_no += 1
+        from .blob_highlighter import blob_highlighter
+
+        print("Visualization")
+        brains = sorted(os.listdir(settings["visualization"]["input_prediction_location"]))
+        for i, brain in enumerate(brains):
+            print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
+            csv_dir = settings["visualization"]["input_csv_location"]
+            if not os.path.isdir(csv_dir) or not any("cells_" + brain in x for x in os.listdir(csv_dir)):
+                print(f"VISUALIZATION: no cells_{brain}*.csv under {csv_dir} (region assignment did not run) - skipped")
+                continue
+            stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
+            blob_highlighter(settings, [brain, ""], stack_shape)
     return 0
 
 

@@ -1,0 +1,110 @@
+// paint.hip - stats-driven blob painting: the loop of blob_highlighter.py:108-125 / :150-158
+//     for cc_id in cell_csv['connected_component_id']:
+//         bb = pad_bb(stats['bounding_boxes'][cc_id]);  IMG[bb] = bin_img[bb] * value(cc_id)
+// paints every cell's padded bounding box in CSV order, so a voxel ends up with the value of the LAST listed cell
+// whose box contains it (boxes of neighbouring blobs overlap; the reference's comment calls this "might accidentally
+// re-color other blobs close by") - times bin_img.  Restated order-free: owner[v] = max{ i+1 : box_i contains v },
+// built with atomicMax by one wave per box (boxes are tiny: a cell is 10-40 voxels), then IMG[v] = bin[v] * value[owner[v]-1].
+// Integer only; identical to the sequential loop for any box list (tests/test_gpu_parity.py, tests/golden/ref_paint.npz).
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+constexpr long long PAINT_BIG = 1 << 16;  // boxes above this volume get a launch of their own
+
+__device__ __forceinline__ void paint_box(const uint8_t* __restrict__ bin, u32* __restrict__ owner, int Y, int X,
+                                          const int* __restrict__ b, u32 tag, long long first, long long step) {
+    const int z0 = b[0], y0 = b[2], x0 = b[4];
+    const long long dy = b[3] - b[2], dx = b[5] - b[4];
+    const long long vol = (long long)(b[1] - b[0]) * dy * dx;
+    for (long long i = first; i < vol; i += step) {
+        const int x = x0 + (int)(i % dx);
+        const int y = y0 + (int)((i / dx) % dy);
+        const int z = z0 + (int)(i / (dx * dy));
+        const u64 v = ((u64)z * Y + y) * X + x;
+        if (bin[v]) atomicMax(owner + v, tag);
+    }
+}
+
+// one wave per box; boxes of PAINT_BIG voxels or more are left to paint_big_kernel
+__global__ void __launch_bounds__(256) paint_small_kernel(const uint8_t* __restrict__ bin, u32* __restrict__ owner, int Y,
+                                                          int X, const int* __restrict__ boxes, long long n) {
+    const int lane = threadIdx.x & 63;
+    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
+        const int* b = boxes + 6 * i;
+        const long long vol = (long long)(b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
+        if (vol <= 0 || vol >= PAINT_BIG) continue;
+        paint_box(bin, owner, Y, X, b, (u32)(i + 1), lane, 64);
+    }
+}
+
+__global__ void __launch_bounds__(256) paint_big_kernel(const uint8_t* __restrict__ bin, u32* __restrict__ owner, int Y,
+                                                        int X, const int* __restrict__ boxes, long long i) {
+    paint_box(bin, owner, Y, X, boxes + 6 * i, (u32)(i + 1), (long long)blockIdx.x * blockDim.x + threadIdx.x,
+              (long long)gridDim.x * blockDim.x);
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) paint_apply_kernel(const u32* __restrict__ owner, const uint8_t* __restrict__ bin,
+                                                          u64 n, const T* __restrict__ values, T* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 o = owner[i];
+        // numpy: bin (uint8, or .astype(uint16)) * value, stored into a T array -> wraps modulo 2^bits like T arithmetic
+        out[i] = o ? (T)((T)bin[i] * values[o - 1]) : (T)0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlv_paint_owner_dev(dlv_ctx* ctx, const uint8_t* bin_dev, int Z, int Y, int X, const int32_t* boxes_dev,
+                        const int32_t* boxes_host, uint64_t n_boxes, uint32_t* owner_dev) {
+    if (!ctx || !bin_dev || !owner_dev || (n_boxes && (!boxes_dev || !boxes_host))) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty volume");
+    if (n_boxes >= 0xffffffffull) return dlv_fail(ctx, DLV_EUNSUP, "more than 2^32-2 boxes");
+    for (uint64_t i = 0; i < n_boxes; ++i) {
+        const int32_t* b = boxes_host + 6 * i;
+        if (b[0] < 0 || b[2] < 0 || b[4] < 0 || b[1] > Z || b[3] > Y || b[5] > X)
+            return dlv_fail(ctx, DLV_EINVAL, "box %llu leaves the volume", (unsigned long long)i);
+    }
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 nvox = (u64)Z * Y * X;
+    DLV_HIP(ctx, hipMemsetAsync(owner_dev, 0, nvox * 4, ctx->stream));
+    if (!n_boxes) return DLV_OK;
+    const int gs = (int)std::min<u64>((n_boxes + 3) / 4, (u64)256 * 64);
+    hipLaunchKernelGGL(paint_small_kernel, dim3(gs), dim3(256), 0, ctx->stream, bin_dev, owner_dev, Y, X, boxes_dev,
+                       (long long)n_boxes);
+    DLV_LAUNCH_CHECK(ctx, "paint_small_kernel");
+    for (uint64_t i = 0; i < n_boxes; ++i) {
+        const int32_t* b = boxes_host + 6 * i;
+        const long long vol = (long long)(b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
+        if (vol < PAINT_BIG) continue;
+        const int gb = (int)std::min<long long>((vol + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(paint_big_kernel, dim3(gb), dim3(256), 0, ctx->stream, bin_dev, owner_dev, Y, X, boxes_dev, (long long)i);
+        DLV_LAUNCH_CHECK(ctx, "paint_big_kernel");
+    }
+    return DLV_OK;
+}
+
+int dlv_paint_apply_dev(dlv_ctx* ctx, const uint32_t* owner_dev, const uint8_t* bin_dev, uint64_t nvox,
+                        const void* values_dev, int elem_bytes, void* out_dev) {
+    if (!ctx || !owner_dev || !bin_dev || !values_dev || !out_dev) return DLV_EINVAL;
+    if (elem_bytes != 1 && elem_bytes != 2) return dlv_fail(ctx, DLV_EUNSUP, "values must be uint8 or uint16");
+    if (!nvox) return DLV_OK;
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const int gs = (int)std::min<u64>((nvox + 255) / 256, (u64)256 * 32);
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL(paint_apply_kernel<uint8_t>, dim3(gs), dim3(256), 0, ctx->stream, owner_dev, bin_dev, (u64)nvox,
+                           (const uint8_t*)values_dev, (uint8_t*)out_dev);
+    else
+        hipLaunchKernelGGL(paint_apply_kernel<uint16_t>, dim3(gs), dim3(256), 0, ctx->stream, owner_dev, bin_dev, (u64)nvox,
+                           (const uint16_t*)values_dev, (uint16_t*)out_dev);
+    DLV_LAUNCH_CHECK(ctx, "paint_apply_kernel");
+    return DLV_OK;
+}
+
+}  // extern "C"

@@ -351,6 +351,38 @@ class HipEngine:
         self._leave()
         self.sync()
 
+    # ---- blob painting -----------------------------------------------------------------------------
+    def paint_boxes(self, bin_img, boxes: np.ndarray, values):
+        """blob_highlighter.py:108-125 / :150-158 on the device.  bin_img: uint8 (Z,Y,X) in HBM; boxes (n,6) int32
+        half-open slices in painting order; values: list of (n,) uint8 / uint16 arrays (one image per array).
+        Returns the list of painted images (HBM tensors)."""
+        torch = self.torch
+        Z, Y, X = (int(v) for v in bin_img.shape)
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 6)
+        n = int(boxes.shape[0])
+        owner = torch.empty((Z, Y, X), dtype=torch.int32, device=self.device)
+        boxes_dev = torch.from_numpy(boxes).to(self.device) if n else None
+        self._enter()
+        self._check(self.lib.dlv_paint_owner_dev(
+            self.ctx, self._dev(bin_img, torch.uint8, "bin_img"), Z, Y, X,
+            C.c_void_p(boxes_dev.data_ptr()) if n else None, boxes.ctypes.data_as(C.c_void_p) if n else None, n,
+            C.c_void_p(owner.data_ptr())))
+        outs = []
+        for val in values:
+            val = np.ascontiguousarray(val)
+            if val.dtype not in (np.uint8, np.uint16) or val.shape != (n,):
+                raise TypeError("values: (n_boxes,) uint8 or uint16 arrays")
+            tdt = torch.uint8 if val.dtype == np.uint8 else torch.uint16
+            vdev = torch.from_numpy(val if n else np.zeros(1, val.dtype)).to(self.device)
+            out = torch.empty((Z, Y, X), dtype=tdt, device=self.device)
+            self._check(self.lib.dlv_paint_apply_dev(self.ctx, C.c_void_p(owner.data_ptr()), C.c_void_p(bin_img.data_ptr()),
+                                                     Z * Y * X, C.c_void_p(vdev.data_ptr()), val.dtype.itemsize,
+                                                     C.c_void_p(out.data_ptr())))
+            outs.append(out)
+        self._leave()
+        self.sync()
+        return outs
+
     # ---- resamplers --------------------------------------------------------------------------------
     def block_mean_u16(self, vol, factors):
         torch = self.torch

@@ -67,3 +67,19 @@ def downsample_ratios(steps: dict) -> Tuple[int, int, int]:
     return (round(steps["downsample_um_z"] / steps["original_um_z"]),
             round(steps["downsample_um_y"] / steps["original_um_y"]),
             round(steps["downsample_um_x"] / steps["original_um_x"]))
+
+
+def padded_boxes(bounding_boxes: np.ndarray, cc_ids, shape_zyx, times: int = 1) -> np.ndarray:
+    """Half-open slices the reference paints for the listed cells (blob_highlighter.py:18-23, :112-113): the inclusive
+    cc3d box with every upper end moved up by one, `times` times, each time only while it is still below the axis
+    length (pad_bb mutates the statistics in place, so the region-id loop - which runs after the RGB loop - sees boxes
+    that were already padded once: times=2).  Returns (n,6) int32 [z0,z1,y0,y1,x0,x1]."""
+    bb = np.asarray(bounding_boxes)[np.asarray(cc_ids, dtype=np.int64)].astype(np.int64)
+    dims = np.asarray(shape_zyx, dtype=np.int64)
+    out = np.empty((len(bb), 6), dtype=np.int64)
+    out[:, 0::2] = bb[:, 0::2]
+    hi = bb[:, 1::2].copy()
+    for _ in range(times):
+        hi = np.where(hi < dims[None, :], hi + 1, hi)
+    out[:, 1::2] = hi
+    return out.astype(np.int32)

@@ -187,6 +187,19 @@ int dlv_relabel_u32_dev(dlv_ctx* ctx, uint32_t* labels_dev, uint64_t nvox, const
 int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* counts,
                          uint32_t* bbmin, uint32_t* bbmax, uint64_t* sums);
 
+/* ---- blob painting (visualisation step) ------------------------------------------ */
+/* The colouring loops of blob_highlighter.py:108-125 (RGB) and :150-158 (region id): cells are visited in CSV order
+ * and IMG[box] = bin_img[box] * value is assigned over each cell's padded bounding box, so the last listed box that
+ * contains a voxel wins.  dlv_paint_owner_dev computes that winner for every voxel: owner (Z,Y,X) uint32 = 1 + index
+ * of the last box containing the voxel, 0 = none / background.  boxes (n,6) int32 = z0,z1,y0,y1,x0,x1 HALF-OPEN, i.e.
+ * exactly the slices the reference takes after pad_bb (blob_highlighter.py:18-23); the same list is passed on the host
+ * (bounds check, launch plan) and in HBM.  dlv_paint_apply_dev: out[v] = bin[v] * values[owner[v]-1] (0 where owner is
+ * 0) in uint8 (elem_bytes 1: the R/G/B images) or uint16 (elem_bytes 2: region ids), numpy's wrap-around included. */
+int dlv_paint_owner_dev(dlv_ctx* ctx, const uint8_t* bin_dev, int Z, int Y, int X, const int32_t* boxes_dev,
+                        const int32_t* boxes_host, uint64_t n_boxes, uint32_t* owner_dev);
+int dlv_paint_apply_dev(dlv_ctx* ctx, const uint32_t* owner_dev, const uint8_t* bin_dev, uint64_t nvox,
+                        const void* values_dev, int elem_bytes, void* out_dev);
+
 /* ---- resamplers (the steps either side of the path) ----------------------------------------- */
 /* transform.downscale_local_mean(chunk,(fz,fy,fx)).astype(uint16) (downsample_and_mask.py:44):
  * out (ceil(Z/fz),ceil(Y/fy),ceil(X/fx)) = floor(sum over zero-padded block / (fz*fy*fx)). */

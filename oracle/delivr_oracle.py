@@ -458,3 +458,26 @@ def scale_coords(coords_zyx: np.ndarray, original_shape: Sequence[int], down_sha
     divided by the factor going down and multiplied going up."""
     f = np.asarray(original_shape, dtype=np.float64) / np.asarray(down_shape, dtype=np.float64)
     return np.asarray(coords_zyx, dtype=np.float64) / f
+
+
+def pad_bb(bb: np.ndarray, stack_shape: Sequence[int]) -> np.ndarray:
+    """blob_highlighter.py:18-23: IN PLACE (+1 on the inclusive upper ends unless already at the shape)."""
+    if bb[1] < stack_shape[2]:
+        bb[1] += 1
+    if bb[3] < stack_shape[3]:
+        bb[3] += 1
+    if bb[5] < stack_shape[4]:
+        bb[5] += 1
+    return bb
+
+
+def paint_blobs(bin_img: np.ndarray, bounding_boxes: np.ndarray, cc_ids: Sequence[int], values: np.ndarray,
+                stack_shape: Sequence[int], dtype) -> np.ndarray:
+    """The colouring loop of blob_highlighter.py:108-125 (dtype uint8) / :150-158 (uint16), sequentially:
+    bounding_boxes is the cc3d.statistics array and IS MUTATED by pad_bb exactly like the reference's stats."""
+    out = np.zeros(bin_img.shape, dtype=dtype)
+    for cc_id, val in zip(cc_ids, values):
+        bb = pad_bb(bounding_boxes[cc_id], stack_shape)
+        sl = (slice(int(bb[0]), int(bb[1])), slice(int(bb[2]), int(bb[3])), slice(int(bb[4]), int(bb[5])))
+        out[sl] = (bin_img[sl].astype(np.int64) * int(val)).astype(dtype)
+    return out

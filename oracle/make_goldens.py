@@ -339,7 +339,103 @@ def golden_swc():
     print("ref_swc.npz", out["single_name"], len(str(out["single_text"])), "bytes;", len(out["chunk_names"]), "chunks")
 
 
-if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "swc":
+def golden_paint():
+    """R/G/B and region-id images painted by the reference's own blob_highlighter (blob_highlighter.py:38-169),
+    imported under stubs (cc3d, cv2, tifffile, skimage, filehandling, matplotlib absent; tifffile.imwrite captured),
+    for a small volume with touching / nested bounding boxes, 'bgr' rows and non-listed blobs."""
+    import importlib.util
+    import pickle
+
+    import pandas as pd
+
+    captured = {}
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    saved = {k: sys.modules.get(k) for k in ("cc3d", "cv2", "tifffile", "filehandling", "skimage", "skimage.morphology",
+                                             "skimage.draw", "skimage.io", "inference", "inference.inference",
+                                             "matplotlib", "matplotlib.pyplot", "blob_depthmap")}
+    stub("cc3d")
+    stub("cv2")
+    stub("tifffile", imwrite=lambda path, arr, **kw: captured.__setitem__(os.path.basename(path), np.array(arr)))
+    stub("filehandling", read_nifti=None, write_nifti=None)
+    sk = stub("skimage")
+    sk.morphology = stub("skimage.morphology", binary_dilation=None)
+    sk.draw = stub("skimage.draw", ellipsoid=None)
+    sk.io = stub("skimage.io")
+    inf_pkg = stub("inference")
+    inf_pkg.inference = stub("inference.inference", create_empty_memmap=None)
+    mpl = stub("matplotlib")
+    mpl.pyplot = stub("matplotlib.pyplot")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_harness.REFERENCE_ROOT, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    load("blob_depthmap")
+    bh = load("blob_highlighter")
+
+    rng = np.random.default_rng(21)
+    Z, Y, X = 14, 20, 26
+    m = np.zeros((Z, Y, X), dtype=np.uint8)
+    for _ in range(16):
+        z, y, x = rng.integers(1, Z - 3), rng.integers(1, Y - 4), rng.integers(1, X - 4)
+        m[z:z + rng.integers(1, 3), y:y + rng.integers(1, 4), x:x + rng.integers(1, 4)] = 1
+    m[5, 2:18, 3] = 1          # a long thin blob whose box swallows neighbours
+    m[13, 19, 25] = 1          # a voxel in the far corner (pad_bb stops at the border)
+    labels, n = orc.ccl26(m)
+    stats = orc.cc_stats(labels, n)
+    ids = list(range(1, n + 1))
+    order = [int(v) for v in rng.permutation(ids)]
+    order = order[:-2]                                 # two blobs are not listed (ids must be unique: the reference's
+                                                       # second loop has no try/except around a duplicated id's broadcast error)
+    acr = ["bgr" if i % 7 == 3 else "CTX" for i in range(len(order))]
+    df = pd.DataFrame({"connected_component_id": order, "acronym": acr,
+                       "red": rng.integers(0, 256, len(order)), "green": rng.integers(0, 256, len(order)),
+                       "blue": rng.integers(0, 256, len(order)), "graph_order": rng.integers(1, 1300, len(order))})
+    brain = "brainA"
+    with tempfile.TemporaryDirectory() as td:
+        d_bin = os.path.join(td, "bin") + "/"
+        d_csv = os.path.join(td, "csv") + "/"
+        d_out = os.path.join(td, "out")
+        d_cache = os.path.join(td, "cache")
+        d_post = os.path.join(td, "post")
+        for d in (os.path.join(d_bin, brain, "binary_segmentations"), d_csv, d_out, d_cache, d_post):
+            os.makedirs(d, exist_ok=True)
+        np.save(os.path.join(d_bin, brain, "binary_segmentations", "binaries.npy"), m)
+        df.to_csv(os.path.join(d_csv, f"cells_{brain}.csv"))
+        with open(os.path.join(d_post, f"{brain}-stats.pickle"), "wb") as fh:
+            pickle.dump({k: v.copy() for k, v in stats.items()}, fh)
+        settings = {"visualization": {"input_prediction_location": d_bin, "input_csv_location": d_csv, "output_location": d_out,
+                                      "cache_location": d_cache, "no_atlas_depthmap": False, "region_id_rgb": True,
+                                      "region_id_grayvalues": True},
+                    "postprocessing": {"output_location": d_post}, "FLAGS": {"LOAD_ALL_RAM": True}}
+        bh.blob_highlighter(settings, (brain, ""), (1, 1, Z, Y, X))
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    rgb = np.stack([np.stack([captured[f"{brain}rgb_C0{c}_z{str(z).zfill(4)}.tif"] for z in range(Z)]) for c in range(3)])
+    rid = np.stack([captured[f"region_id_{str(z).zfill(4)}.tif"] for z in range(Z)])
+    np.savez_compressed(os.path.join(GOLD, "ref_paint.npz"), mask=m, bounding_boxes=stats["bounding_boxes"],
+                        cc_id=np.array(order), acronym=np.array(acr), red=df["red"].to_numpy(), green=df["green"].to_numpy(),
+                        blue=df["blue"].to_numpy(), graph_order=df["graph_order"].to_numpy(), rgb=rgb, region_id=rid,
+                        tiff_names=np.array(sorted(captured)))
+    print("ref_paint.npz", rgb.shape, rid.shape, "painted voxels", int((rgb.sum(0) > 0).sum()), "of", int(m.sum()))
+
+
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "paint":
+    golden_paint()
+elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "swc":
     golden_swc()
 elif __name__ == "__main__":
     main()

@@ -239,3 +239,55 @@ def test_sw_pass_clamped_windows_and_other_overlaps(eng_w, net, shape, roi, over
     np.testing.assert_array_equal(cnt.cpu().numpy(), cref)
     assert np.abs(acc.cpu().numpy() - ref).max() < 2e-3
     np.testing.assert_array_equal(eng_w.window_starts(eng_w.make_sw_params(shape, roi, overlap)), orc.window_list(shape, roi, overlap))
+
+
+# ---------------------------------------------------------------------------------------------------
+# blob painting (blob_highlighter.py:108-125, :150-158)
+# ---------------------------------------------------------------------------------------------------
+def test_paint_matches_reference_golden(eng, golden_dir):
+    import torch
+    from delivr_cfos_amd.hostlogic import padded_boxes
+
+    g = np.load(os.path.join(golden_dir, "ref_paint.npz"))
+    m = g["mask"]
+    keep = g["acronym"] != "bgr"
+    ids = g["cc_id"][keep]
+    bin_dev = torch.from_numpy(m).cuda()
+    r, gr, b = eng.paint_boxes(bin_dev, padded_boxes(g["bounding_boxes"], ids, m.shape, 1),
+                                  [g[k][keep].astype(np.uint8) for k in ("red", "green", "blue")])
+    for c, img in enumerate((r, gr, b)):
+        np.testing.assert_array_equal(img.cpu().numpy(), g["rgb"][c])
+    (rid,) = eng.paint_boxes(bin_dev, padded_boxes(g["bounding_boxes"], ids, m.shape, 2), [g["graph_order"][keep].astype(np.uint16)])
+    np.testing.assert_array_equal(rid.cpu().numpy(), g["region_id"])
+
+
+def test_paint_random_boxes_vs_sequential_loop(eng):
+    """Overlapping boxes in random order, a whole-volume box (own launch, > 65536 voxels) in the middle of the list,
+    empty boxes, values that wrap in uint8 (bin_img holds 1s and 2s): bit-exact against the sequential loop."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    Z, Y, X = 40, 64, 96
+    m = (rng.random((Z, Y, X)) < 0.3).astype(np.uint8) * rng.integers(1, 3, (Z, Y, X)).astype(np.uint8)
+    n = 400
+    lo = np.stack([rng.integers(0, Z, n), rng.integers(0, Y, n), rng.integers(0, X, n)], 1)
+    ext = np.stack([rng.integers(0, 9, n), rng.integers(0, 12, n), rng.integers(0, 14, n)], 1)
+    hi = np.minimum(lo + ext, [Z, Y, X])
+    boxes = np.empty((n, 6), np.int32)
+    boxes[:, 0::2], boxes[:, 1::2] = lo, hi
+    boxes[200] = [0, Z, 0, Y, 0, X]
+    v8 = rng.integers(0, 256, n).astype(np.uint8)
+    v16 = rng.integers(0, 65536, n).astype(np.uint16)
+    want8 = np.zeros(m.shape, np.uint8)
+    want16 = np.zeros(m.shape, np.uint16)
+    for b, a8, a16 in zip(boxes, v8, v16):
+        sl = (slice(b[0], b[1]), slice(b[2], b[3]), slice(b[4], b[5]))
+        want8[sl] = (m[sl].astype(np.int64) * int(a8)).astype(np.uint8)
+        want16[sl] = (m[sl].astype(np.uint16) * a16)
+    o8, o16 = eng.paint_boxes(torch.from_numpy(m).cuda(), boxes, [v8, v16])
+    np.testing.assert_array_equal(o8.cpu().numpy(), want8)
+    np.testing.assert_array_equal(o16.cpu().numpy(), want16)
+    with pytest.raises(RuntimeError):
+        bad = boxes.copy()
+        bad[3, 1] = Z + 1
+        eng.paint_boxes(torch.from_numpy(m).cuda(), bad, [v8])

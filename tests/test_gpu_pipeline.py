@@ -278,3 +278,46 @@ def test_sharded_ccl_on_device_equals_single_volume(tmp_path, cuts):
     st = res[0][2]
     for k in ("voxel_counts", "bounding_boxes", "centroids"):
         np.testing.assert_array_equal(st[k], st1[k])
+
+
+def test_blob_highlighter_writes_the_reference_planes(tmp_path, golden_dir):
+    """File-level mirror of the visualisation step on the reference's own fixture: same plane file names as the
+    reference wrote (tests/golden/ref_paint.npz: tiff_names), pixels identical after decoding."""
+    from delivr_cfos_amd.blob_highlighter import blob_highlighter
+    from delivr_cfos_amd.downsample.downsample_and_mask import read_tiff_plane
+
+    g = np.load(os.path.join(golden_dir, "ref_paint.npz"))
+    m = g["mask"]
+    Z, Y, X = m.shape
+    brain = "brainA"
+    d_bin, d_csv, d_out, d_post = (str(tmp_path / k) for k in ("bin", "csv", "out", "post"))
+    os.makedirs(os.path.join(d_bin, brain, "binary_segmentations"))
+    for d in (d_csv, d_out, d_post):
+        os.makedirs(d)
+    np.save(os.path.join(d_bin, brain, "binary_segmentations", "binaries.npy"), m)
+    with open(os.path.join(d_csv, f"cells_{brain}.csv"), "w") as fh:
+        fh.write(",connected_component_id,acronym,red,green,blue,graph_order\n")
+        for i in range(len(g["cc_id"])):
+            fh.write(f"{i},{g['cc_id'][i]},{g['acronym'][i]},{g['red'][i]},{g['green'][i]},{g['blue'][i]},{g['graph_order'][i]}\n")
+    with open(os.path.join(d_post, f"{brain}-stats.pickle"), "wb") as fh:
+        pickle.dump({"bounding_boxes": g["bounding_boxes"].copy()}, fh)
+    settings = {"visualization": {"input_prediction_location": d_bin + "/", "input_csv_location": d_csv + "/",
+                                  "output_location": d_out, "cache_location": str(tmp_path / "cache"),
+                                  "no_atlas_depthmap": False, "region_id_rgb": True, "region_id_grayvalues": True},
+                "postprocessing": {"output_location": d_post}, "FLAGS": {"LOAD_ALL_RAM": True}}
+    blob_highlighter(settings, [brain, ""], (1, 1, Z, Y, X))
+    written = sorted(os.listdir(os.path.join(d_out, brain + "_rgb_tiffs")) +
+                     os.listdir(os.path.join(d_out, brain, brain + "_region_id_tiffs")))
+    assert written == sorted(str(s) for s in g["tiff_names"])
+    for c in range(3):
+        for z in range(Z):
+            p = read_tiff_plane(os.path.join(d_out, brain + "_rgb_tiffs", f"{brain}rgb_C0{c}_z{z:04d}.tif"))
+            np.testing.assert_array_equal(p, g["rgb"][c, z])
+    for z in range(Z):
+        p = read_tiff_plane(os.path.join(d_out, brain, brain + "_region_id_tiffs", f"region_id_{z:04d}.tif"))
+        np.testing.assert_array_equal(p, g["region_id"][z])
+    # without the cached statistics the boxes come from CCL-26 + statistics on the device: same planes
+    os.remove(os.path.join(d_post, f"{brain}-stats.pickle"))
+    blob_highlighter(settings, [brain, ""], (1, 1, Z, Y, X))
+    p = read_tiff_plane(os.path.join(d_out, brain, brain + "_region_id_tiffs", "region_id_0005.tif"))
+    np.testing.assert_array_equal(p, g["region_id"][5])

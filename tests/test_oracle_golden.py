@@ -134,3 +134,34 @@ def test_arrayterator_block_rule():
         axis, nb = orc.zblock_planes(shape, buf)
         if axis == "z":
             assert blocks[0] == (min(nb, shape[0]),) + shape[1:]
+
+
+def test_paint_restatement_and_box_logic_match_reference_blob_highlighter(golden_dir):
+    """The R/G/B and region-id images the reference's blob_highlighter wrote (captured under stubs by
+    oracle/make_goldens.py::golden_paint) == the oracle's sequential loop == painting hostlogic.padded_boxes in order
+    (the second loop sees boxes that pad_bb already moved once)."""
+    from delivr_cfos_amd.hostlogic import padded_boxes
+
+    g = np.load(os.path.join(golden_dir, "ref_paint.npz"))
+    m = g["mask"]
+    Z, Y, X = m.shape
+    keep = g["acronym"] != "bgr"
+    ids = g["cc_id"][keep]
+    bb = None
+    for c, key in enumerate(("red", "green", "blue")):
+        bb = g["bounding_boxes"].copy()
+        img = orc.paint_blobs(m, bb, ids, g[key][keep], (1, 1, Z, Y, X), np.uint8)
+        np.testing.assert_array_equal(img, g["rgb"][c])
+    rid = orc.paint_blobs(m, bb, ids, g["graph_order"][keep], (1, 1, Z, Y, X), np.uint16)   # bb: padded once already
+    np.testing.assert_array_equal(rid, g["region_id"])
+
+    def paint(boxes, vals, dt):
+        out = np.zeros(m.shape, dt)
+        for b, v in zip(boxes, vals):
+            sl = (slice(b[0], b[1]), slice(b[2], b[3]), slice(b[4], b[5]))
+            out[sl] = (m[sl].astype(np.int64) * int(v)).astype(dt)
+        return out
+
+    np.testing.assert_array_equal(paint(padded_boxes(g["bounding_boxes"], ids, (Z, Y, X), 1), g["red"][keep], np.uint8), g["rgb"][0])
+    np.testing.assert_array_equal(paint(padded_boxes(g["bounding_boxes"], ids, (Z, Y, X), 2), g["graph_order"][keep], np.uint16),
+                                  g["region_id"])
