@@ -98,6 +98,8 @@ SIGNATURES = {
     "dlv_cc_stats_raw_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint64, _P, _P, _P, _P]),
     "dlv_paint_owner_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_uint64, _P]),
     "dlv_paint_apply_dev": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "dlv_heatmap_counts_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
+    "dlv_gauss_blur_f32_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dlv_debug_stamps": (C.c_int, [_P, _P]),
     "dlv_debug_set_zm_variant": (C.c_int, [_P, C.c_int]),
     "dlv_debug_set_format": (C.c_int, [_P, C.c_int]),

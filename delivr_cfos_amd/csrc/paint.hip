@@ -108,3 +108,102 @@ int dlv_paint_apply_dev(dlv_ctx* ctx, const uint32_t* owner_dev, const uint8_t* 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// cell-density heat map: cells_to_atlas.py:174-200 create_heatmap
+//   heatmap[z,y,x] = number of cells at that atlas voxel;  gaussian_filter(heatmap.astype('float32'), sigma=2.25)
+// scipy.ndimage.gaussian_filter = three correlate1d passes (axis 0,1,2), each: line converted to double, symmetric
+// kernel evaluated as  t = c*w[0]; for j = r..1: t += (in[-j] + in[+j]) * w[j]  (ni_filters.c NI_Correlate1D), boundary
+// 'reflect' (d c b a | a b c d | d c b a), result stored as float32 before the next axis.  Same order, same
+// roundings (no fma contraction) -> bit-identical to scipy (tests/golden/scipy_heatmap.npz).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256) heat_count_kernel(const int* __restrict__ xyz, long long n, int Z, int Y, int X,
+                                                         unsigned int* __restrict__ hist) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z)
+            atomicAdd(hist + ((long long)z * Y + y) * X + x, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) u32_to_f32_kernel(const unsigned int* __restrict__ in, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    // scipy 'reflect': period 2n, -1 -> 0, n -> n-1 (also for lines shorter than the kernel radius)
+    if (n == 1) return 0;
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+// one thread per output element; `stride` = element stride of the filtered axis, `len` its length
+__global__ void __launch_bounds__(256) gauss_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long long n,
+                                                         long long stride, int len, const double* __restrict__ w, int radius) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int pos = (int)((i / stride) % len);
+        const long long base = i - (long long)pos * stride;
+        double t = __dmul_rn((double)in[i], w[0]);
+        for (int j = radius; j >= 1; --j) {
+            const double a = (double)in[base + (long long)reflect_idx(pos - j, len) * stride];
+            const double b = (double)in[base + (long long)reflect_idx(pos + j, len) * stride];
+            t = __dadd_rn(t, __dmul_rn(__dadd_rn(a, b), w[j]));
+        }
+        out[i] = (float)t;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlv_heatmap_counts_dev(dlv_ctx* ctx, const int32_t* xyz_dev, uint64_t n_cells, int Z, int Y, int X, float* heat_dev) {
+    if (!ctx || !heat_dev || (n_cells && !xyz_dev)) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty grid");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nvox = (long long)Z * Y * X;
+    unsigned int* hist;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, (size_t)nvox * 4, (void**)&hist));
+    DLV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)nvox * 4, ctx->stream));
+    if (n_cells) {
+        const int gs = (int)std::min<long long>(((long long)n_cells + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(heat_count_kernel, dim3(gs), dim3(256), 0, ctx->stream, xyz_dev, (long long)n_cells, Z, Y, X, hist);
+        DLV_LAUNCH_CHECK(ctx, "heat_count_kernel");
+    }
+    const int gv = (int)std::min<long long>((nvox + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(u32_to_f32_kernel, dim3(gv), dim3(256), 0, ctx->stream, hist, heat_dev, nvox);
+    DLV_LAUNCH_CHECK(ctx, "u32_to_f32_kernel");
+    return DLV_OK;
+}
+
+int dlv_gauss_blur_f32_dev(dlv_ctx* ctx, float* vol_dev, int Z, int Y, int X, const double* weights_host, int radius,
+                           float* tmp_dev) {
+    if (!ctx || !vol_dev || !tmp_dev || !weights_host) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0 || radius < 0 || radius > 1024) return dlv_fail(ctx, DLV_EINVAL, "bad blur arguments");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nvox = (long long)Z * Y * X;
+    double* w;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, (size_t)(radius + 1) * 8, (void**)&w));
+    DLV_HIP(ctx, hipMemcpyAsync(w, weights_host, (size_t)(radius + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int gv = (int)std::min<long long>((nvox + 255) / 256, 256 * 64);
+    const long long strides[3] = {(long long)Y * X, X, 1};
+    const int lens[3] = {Z, Y, X};
+    float* src = vol_dev;
+    float* dst = tmp_dev;
+    for (int ax = 0; ax < 3; ++ax) {
+        hipLaunchKernelGGL(gauss_axis_kernel, dim3(gv), dim3(256), 0, ctx->stream, src, dst, nvox, strides[ax], lens[ax], w, radius);
+        DLV_LAUNCH_CHECK(ctx, "gauss_axis_kernel");
+        std::swap(src, dst);
+    }
+    // three passes: the result sits in tmp_dev; copy it back so that vol_dev holds the blurred map
+    DLV_HIP(ctx, hipMemcpyAsync(vol_dev, tmp_dev, (size_t)nvox * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // weights_host and the workspace copy are consumed
+    return DLV_OK;
+}
+
+}  // extern "C"

@@ -383,6 +383,30 @@ class HipEngine:
         self.sync()
         return outs
 
+    # ---- atlas-space heat map ----------------------------------------------------------------------
+    def heatmap(self, cells_xyz: np.ndarray, shape_zyx, sigma: float = 2.25):
+        """create_heatmap (cells_to_atlas.py:174-200) on the device: float32 (Z,Y,X) tensor in HBM."""
+        torch = self.torch
+        Z, Y, X = (int(v) for v in shape_zyx)
+        xyz = np.ascontiguousarray(cells_xyz, dtype=np.int32).reshape(-1, 3)
+        n = int(xyz.shape[0])
+        heat = torch.empty((Z, Y, X), dtype=torch.float32, device=self.device)
+        tmp = torch.empty_like(heat)
+        xyz_dev = torch.from_numpy(xyz).to(self.device) if n else None
+        # scipy.ndimage._filters._gaussian_kernel1d, order 0
+        radius = int(4.0 * float(sigma) + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+        phi = phi / phi.sum()
+        w = np.ascontiguousarray(phi[radius:], dtype=np.float64)
+        self._enter()
+        self._check(self.lib.dlv_heatmap_counts_dev(self.ctx, C.c_void_p(xyz_dev.data_ptr()) if n else None, n, Z, Y, X,
+                                                    C.c_void_p(heat.data_ptr())))
+        self._check(self.lib.dlv_gauss_blur_f32_dev(self.ctx, C.c_void_p(heat.data_ptr()), Z, Y, X,
+                                                    w.ctypes.data_as(C.c_void_p), radius, C.c_void_p(tmp.data_ptr())))
+        self._leave()
+        return heat
+
     # ---- resamplers --------------------------------------------------------------------------------
     def block_mean_u16(self, vol, factors):
         torch = self.torch

@@ -200,6 +200,16 @@ int dlv_paint_owner_dev(dlv_ctx* ctx, const uint8_t* bin_dev, int Z, int Y, int 
 int dlv_paint_apply_dev(dlv_ctx* ctx, const uint32_t* owner_dev, const uint8_t* bin_dev, uint64_t nvox,
                         const void* values_dev, int elem_bytes, void* out_dev);
 
+/* ---- cell-density heat map in atlas space (region assignment step) --------------- */
+/* create_heatmap (cells_to_atlas.py:174-200): heat (Z,Y,X) float32 = number of cells per atlas voxel (cells (n,3) int32
+ * = x,y,z as in the reference's columns; cells outside the grid are ignored - the reference drops them before, :139-144),
+ * then scipy.ndimage.gaussian_filter(heat, sigma) = dlv_gauss_blur_f32_dev with the host-computed half kernel
+ * weights[0..radius] (weights[0] = centre; scipy: radius = int(4*sigma + 0.5), phi / phi.sum()), boundary 'reflect',
+ * float32 between the axis passes, in place (tmp_dev: scratch of the same size).  Bit-identical to scipy. */
+int dlv_heatmap_counts_dev(dlv_ctx* ctx, const int32_t* xyz_dev, uint64_t n_cells, int Z, int Y, int X, float* heat_dev);
+int dlv_gauss_blur_f32_dev(dlv_ctx* ctx, float* vol_dev, int Z, int Y, int X, const double* weights_host, int radius,
+                           float* tmp_dev);
+
 /* ---- resamplers (the steps either side of the path) ----------------------------------------- */
 /* transform.downscale_local_mean(chunk,(fz,fy,fx)).astype(uint16) (downsample_and_mask.py:44):
  * out (ceil(Z/fz),ceil(Y/fy),ceil(X/fx)) = floor(sum over zero-padded block / (fz*fy*fx)). */

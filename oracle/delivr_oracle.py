@@ -481,3 +481,33 @@ def paint_blobs(bin_img: np.ndarray, bounding_boxes: np.ndarray, cc_ids: Sequenc
         sl = (slice(int(bb[0]), int(bb[1])), slice(int(bb[2]), int(bb[3])), slice(int(bb[4]), int(bb[5])))
         out[sl] = (bin_img[sl].astype(np.int64) * int(val)).astype(dtype)
     return out
+
+
+def atlas_to_ccf(cells: dict, label_shape: Sequence[int]) -> dict:
+    """mbrainaligner_atlas_to_ccf (cells_to_atlas.py:114-151), column by column."""
+    c = {k: np.asarray(v, dtype=np.float64).copy() for k, v in cells.items()}
+    c["x"] = 264 - c["x"]
+    c["y"] = 160 - c["y"]
+    c["x"], c["y"] = c["y"], c["x"]
+    for k in ("x", "y", "z"):
+        c[k] = c[k] * 2
+    c["connected_component_id"] = c["connected_component_id"] + 1
+    c = {k: np.round(v).astype(np.int64) for k, v in c.items()}
+    Z, Y, X = label_shape
+    keep = np.ones(len(c["x"]), dtype=bool)
+    keep &= ~(c["x"] >= X)
+    keep &= ~(c["y"] >= Y)
+    keep &= ~(c["z"] >= Z)
+    keep &= ~(c["x"] < 0)
+    keep &= ~(c["y"] < 0)
+    keep &= ~(c["z"] < 0)
+    return {k: v[keep] for k, v in c.items()}
+
+
+def heatmap(cells: dict, label_shape: Sequence[int], sigma: float = 2.25) -> np.ndarray:
+    """create_heatmap (cells_to_atlas.py:174-200): counts per voxel, gaussian_filter in float32."""
+    from scipy.ndimage import gaussian_filter
+
+    h = np.zeros(tuple(label_shape), dtype=np.float64)
+    np.add.at(h, (cells["z"], cells["y"], cells["x"]), 1)
+    return gaussian_filter(h.astype(int).astype("float32"), sigma=sigma)

@@ -433,7 +433,58 @@ def golden_paint():
     print("ref_paint.npz", rgb.shape, rid.shape, "painted voxels", int((rgb.sum(0) > 0).sum()), "of", int(m.sum()))
 
 
-if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "paint":
+def golden_atlas():
+    """Outputs of the reference's own mbrainaligner_atlas_to_ccf and create_heatmap (cells_to_atlas.py:114-151,
+    :174-200), imported under stubs (nibabel, tifffile absent), for synthetic cells on a small label grid; the
+    RegionID gather of cells_to_atlas (:204-212) restated next to them (it needs the ontology XML only for the join)."""
+    import importlib.util
+
+    import pandas as pd
+
+    saved = {k: sys.modules.get(k) for k in ("nibabel", "tifffile")}
+    for k in saved:
+        if saved[k] is None:
+            sys.modules[k] = types.ModuleType(k)
+    spec = importlib.util.spec_from_file_location("delivr_ref_c2a", os.path.join(ref_harness.REFERENCE_ROOT, "cells_to_atlas.py"))
+    c2a = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(c2a)
+    rng = np.random.default_rng(9)
+    label = rng.integers(0, 40, size=(36, 50, 44)).astype(np.uint16)      # (z, y, x) like the CCF3 annotation volume
+    label[rng.random(label.shape) < 0.3] = 0
+    n = 3000
+    # atlas-space coordinates as mBrainAligner returns them (floats), some outside the grid after the transform
+    cells = pd.DataFrame({"connected_component_id": np.arange(n), "x": rng.uniform(236, 266, n), "y": rng.uniform(136, 162, n),
+                          "z": rng.uniform(-2, 20, n), "Size": rng.integers(1, 200, n)})
+    cells.loc[:40, ["x", "y", "z"]] = np.round(cells.loc[:40, ["x", "y", "z"]]) + 0.25   # ties after *2: round-half-even
+    raw = {c: cells[c].to_numpy().copy() for c in cells.columns}
+    out = c2a.mbrainaligner_atlas_to_ccf(cells.copy(), label)
+    region = label[out["z"].to_list(), out["y"].to_list(), out["x"].to_list()].astype(np.int64)
+    region[region != 0] += 1
+    # pandas 1.4.3 (requirements.txt): DataFrame.value_counts() gives an unnamed Series, so reset_index() names the
+    # count column 0 - which create_heatmap indexes (:186).  pandas 2.x names it 'count'; restore the old name.
+    real_vc = pd.DataFrame.value_counts
+
+    def vc_pd14(self, *a, **k):
+        s = real_vc(self, *a, **k)
+        s.name = None
+        return s
+
+    pd.DataFrame.value_counts = vc_pd14
+    try:
+        heat = c2a.create_heatmap(out, label)
+    finally:
+        pd.DataFrame.value_counts = real_vc
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+    np.savez_compressed(os.path.join(GOLD, "ref_atlas.npz"), label=label, **{"raw_" + k: v for k, v in raw.items()},
+                        **{"ccf_" + c: out[c].to_numpy() for c in out.columns}, region_id=region, heatmap=heat)
+    print("ref_atlas.npz cells kept", len(out), "of", n, "heat", heat.dtype, heat.shape, float(heat.sum()))
+
+
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "atlas":
+    golden_atlas()
+elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "paint":
     golden_paint()
 elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "swc":
     golden_swc()

@@ -291,3 +291,23 @@ def test_paint_random_boxes_vs_sequential_loop(eng):
         bad = boxes.copy()
         bad[3, 1] = Z + 1
         eng.paint_boxes(torch.from_numpy(m).cuda(), bad, [v8])
+
+
+def test_heatmap_bit_exact_vs_reference_and_scipy(eng, golden_dir):
+    """create_heatmap on the device == the reference's own output (tests/golden/ref_atlas.npz), bit for bit; and on a
+    grid with lines shorter than the kernel radius (reflect wraps more than once) == the oracle (scipy)."""
+    from delivr_cfos_amd.cells_to_atlas import create_heatmap
+    from oracle import delivr_oracle as orc
+
+    g = np.load(os.path.join(golden_dir, "ref_atlas.npz"))
+    cells = {k[4:]: g[k] for k in g.files if k.startswith("ccf_")}
+    got = create_heatmap(cells, g["label"].shape, engine=eng)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got.view(np.uint32), g["heatmap"].view(np.uint32))
+    rng = np.random.default_rng(2)
+    shape = (5, 23, 3)
+    n = 400
+    c2 = {"x": rng.integers(0, shape[2], n), "y": rng.integers(0, shape[1], n), "z": rng.integers(0, shape[0], n)}
+    for sigma in (2.25, 0.8):
+        got = create_heatmap(c2, shape, engine=eng, sigma=sigma)
+        np.testing.assert_array_equal(got.view(np.uint32), orc.heatmap(c2, shape, sigma).view(np.uint32))

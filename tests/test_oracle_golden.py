@@ -165,3 +165,21 @@ def test_paint_restatement_and_box_logic_match_reference_blob_highlighter(golden
     np.testing.assert_array_equal(paint(padded_boxes(g["bounding_boxes"], ids, (Z, Y, X), 1), g["red"][keep], np.uint8), g["rgb"][0])
     np.testing.assert_array_equal(paint(padded_boxes(g["bounding_boxes"], ids, (Z, Y, X), 2), g["graph_order"][keep], np.uint16),
                                   g["region_id"])
+
+
+def test_atlas_transform_and_heatmap_match_reference(golden_dir):
+    """mbrainaligner_atlas_to_ccf / create_heatmap of the reference (tests/golden/ref_atlas.npz) == the oracle == the
+    host mirror's coordinate logic (the heat map itself is a device kernel: tests/test_gpu_parity.py)."""
+    from delivr_cfos_amd.cells_to_atlas import mbrainaligner_atlas_to_ccf, region_ids
+
+    g = np.load(os.path.join(golden_dir, "ref_atlas.npz"))
+    raw = {k[4:]: g[k] for k in g.files if k.startswith("raw_")}
+    want = {k[4:]: g[k] for k in g.files if k.startswith("ccf_")}
+    label = g["label"]
+    for fn in (orc.atlas_to_ccf, mbrainaligner_atlas_to_ccf):
+        got = fn(raw, label.shape)
+        assert set(got) == set(want)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k])
+    np.testing.assert_array_equal(region_ids(want, label), g["region_id"])
+    np.testing.assert_array_equal(orc.heatmap(want, label.shape), g["heatmap"])
