@@ -100,6 +100,11 @@ SIGNATURES = {
     "dlv_paint_apply_dev": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_int, _P]),
     "dlv_heatmap_counts_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "dlv_gauss_blur_f32_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "dlv_tiff_last_error": (C.c_char_p, []),
+    "dlv_tiff_plane_size": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dlv_tiff_read_plane_u16": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "dlv_tiff_stack_to_device": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, _P, C.c_longlong,
+                                            C.c_longlong, C.c_int]),
     "dlv_debug_stamps": (C.c_int, [_P, _P]),
     "dlv_debug_set_zm_variant": (C.c_int, [_P, C.c_int]),
     "dlv_debug_set_format": (C.c_int, [_P, C.c_int]),

@@ -1,0 +1,360 @@
+// tiffio.hip - z-plane ingest: TIFF planes -> uint16 volume in HBM.
+//
+// The reference reads its raw stacks plane by plane with cv2.imread / skimage.io / tifffile
+// (downsample/downsample_and_mask.py:25-30, :36-41, :396-404) - codecs from third-party libraries, one plane at a
+// time on one core.  Once inference takes seconds, that dominates the wall clock.  Here: a classic-TIFF reader
+// (little/big endian, strips, 8/16-bit single channel, compression 1 = none and 5 = LZW with or without the
+// horizontal predictor - what light-sheet stitchers and the reference's own writers emit, blob_highlighter.py:131)
+// decodes planes on a pool of host threads straight into pinned staging buffers, from which they are copied to
+// their z offset in the device volume while the next planes are being decoded.
+// Decoder pinned by fixtures written with libtiff (tests/golden/tiff_*.tif, tests/test_host_cpu.py).
+#include "common.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct TiffInfo {
+    bool big = false;
+    uint32_t width = 0, height = 0, bits = 1, compression = 1, samples = 1, rows_per_strip = 0xffffffffu, predictor = 1,
+             photometric = 1, planar = 1, sample_format = 1;
+    std::vector<uint64_t> strip_off, strip_len;
+};
+
+struct Reader {
+    const uint8_t* p;
+    size_t n;
+    bool big;
+    bool ok(size_t off, size_t len) const { return off <= n && len <= n - off; }
+    uint16_t u16(size_t o) const { return big ? (uint16_t)(p[o] << 8 | p[o + 1]) : (uint16_t)(p[o] | p[o + 1] << 8); }
+    uint32_t u32(size_t o) const {
+        return big ? ((uint32_t)p[o] << 24 | (uint32_t)p[o + 1] << 16 | (uint32_t)p[o + 2] << 8 | p[o + 3])
+                   : ((uint32_t)p[o] | (uint32_t)p[o + 1] << 8 | (uint32_t)p[o + 2] << 16 | (uint32_t)p[o + 3] << 24);
+    }
+};
+
+// values of an IFD entry (types BYTE 1, SHORT 3, LONG 4) as u64
+bool entry_values(const Reader& r, size_t e, std::vector<uint64_t>& out) {
+    const uint16_t type = r.u16(e + 2);
+    const uint32_t count = r.u32(e + 4);
+    const size_t sz = type == 1 ? 1 : type == 3 ? 2 : type == 4 ? 4 : 0;
+    if (!sz || count > (1u << 28)) return false;
+    size_t off = e + 8;
+    if ((size_t)count * sz > 4) {
+        off = r.u32(e + 8);
+        if (!r.ok(off, (size_t)count * sz)) return false;
+    }
+    out.resize(count);
+    for (uint32_t i = 0; i < count; ++i)
+        out[i] = sz == 1 ? r.p[off + i] : sz == 2 ? r.u16(off + 2 * i) : r.u32(off + 4 * i);
+    return true;
+}
+
+const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
+    if (n < 8) return "file shorter than a TIFF header";
+    if (data[0] == 'I' && data[1] == 'I') t.big = false;
+    else if (data[0] == 'M' && data[1] == 'M') t.big = true;
+    else return "not a TIFF file";
+    Reader r{data, n, t.big};
+    if (r.u16(2) != 42) return "not a classic TIFF (BigTIFF is not supported)";
+    const size_t ifd = r.u32(4);
+    if (!r.ok(ifd, 2)) return "IFD offset outside the file";
+    const uint16_t ne = r.u16(ifd);
+    if (!r.ok(ifd + 2, (size_t)ne * 12)) return "IFD truncated";
+    std::vector<uint64_t> v;
+    for (uint16_t i = 0; i < ne; ++i) {
+        const size_t e = ifd + 2 + (size_t)i * 12;
+        const uint16_t tag = r.u16(e);
+        if (tag != 256 && tag != 257 && tag != 258 && tag != 259 && tag != 262 && tag != 273 && tag != 277 && tag != 278 &&
+            tag != 279 && tag != 284 && tag != 317 && tag != 339)
+            continue;
+        if (!entry_values(r, e, v) || v.empty()) return "unsupported IFD entry type";
+        switch (tag) {
+            case 256: t.width = (uint32_t)v[0]; break;
+            case 257: t.height = (uint32_t)v[0]; break;
+            case 258: t.bits = (uint32_t)v[0]; if (v.size() != 1) return "multi-sample planes are not supported"; break;
+            case 259: t.compression = (uint32_t)v[0]; break;
+            case 262: t.photometric = (uint32_t)v[0]; break;
+            case 273: t.strip_off = v; break;
+            case 277: t.samples = (uint32_t)v[0]; break;
+            case 278: t.rows_per_strip = (uint32_t)v[0]; break;
+            case 279: t.strip_len = v; break;
+            case 284: t.planar = (uint32_t)v[0]; break;
+            case 317: t.predictor = (uint32_t)v[0]; break;
+            case 339: t.sample_format = (uint32_t)v[0]; break;
+        }
+    }
+    if (!t.width || !t.height) return "image size missing";
+    if (t.samples != 1) return "only single-channel planes are supported";
+    if (t.bits != 8 && t.bits != 16) return "only 8- and 16-bit samples are supported";
+    if (t.sample_format != 1) return "only unsigned integer samples are supported";
+    if (t.compression != 1 && t.compression != 5) return "only uncompressed and LZW planes are supported";
+    if (t.predictor != 1 && t.predictor != 2) return "unsupported predictor";
+    if (t.strip_off.empty() || t.strip_off.size() != t.strip_len.size()) return "strip tables missing (tiled TIFF is not supported)";
+    if (t.rows_per_strip == 0) return "RowsPerStrip is 0";
+    for (size_t i = 0; i < t.strip_off.size(); ++i)
+        if (!r.ok((size_t)t.strip_off[i], (size_t)t.strip_len[i])) return "strip outside the file";
+    return nullptr;
+}
+
+// TIFF 6.0 LZW: MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, the code width grows one code
+// early ("early change").  Every table string is a substring of the output written so far - entry `next` is the
+// previous string plus the byte that follows it in the output - so the table holds (offset, length) pairs and a code
+// is decoded with one forward copy inside the output buffer.  Returns the number of bytes written (<= cap).
+size_t lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+    uint32_t off[4096];
+    uint32_t len[4096];
+    int width = 9, next = 258;
+    long long prev_pos = -1;  // where the previous code's string starts in dst
+    uint32_t prev_len = 0;
+    uint64_t acc = 0;
+    int nbits = 0;
+    size_t ip = 0, op = 0;
+    for (;;) {
+        while (nbits <= 56 && ip < n) {
+            acc = (acc << 8) | src[ip++];
+            nbits += 8;
+        }
+        if (nbits < width) break;
+        const int code = (int)((acc >> (nbits - width)) & ((1u << width) - 1));
+        nbits -= width;
+        if (code == 257) break;
+        if (code == 256) {
+            width = 9;
+            next = 258;
+            prev_pos = -1;
+            continue;
+        }
+        const size_t start = op;
+        uint32_t l;
+        if (code < 256) {
+            if (op >= cap) break;
+            dst[op++] = (uint8_t)code;
+            l = 1;
+        } else if (code < next) {
+            l = len[code];
+            if (op + l > cap) break;
+            const uint8_t* from = dst + off[code];
+            uint8_t* to = dst + op;
+            if (off[code] + l <= op && l >= 16) memcpy(to, from, l);
+            else for (uint32_t k = 0; k < l; ++k) to[k] = from[k];
+            op += l;
+        } else if (code == next && prev_pos >= 0) {  // KwKwK: previous string + its own first byte (overlapping copy)
+            l = prev_len + 1;
+            if (op + l > cap) break;
+            const uint8_t* from = dst + prev_pos;
+            uint8_t* to = dst + op;
+            for (uint32_t k = 0; k < l; ++k) to[k] = from[k];
+            op += l;
+        } else {
+            break;  // corrupt stream
+        }
+        if (prev_pos >= 0 && next < 4096) {
+            off[next] = (uint32_t)prev_pos;
+            len[next] = prev_len + 1;
+            ++next;
+        }
+        prev_pos = (long long)start;
+        prev_len = l;
+        if (next >= (1 << width) - 1 && width < 12) ++width;  // early change
+    }
+    return op < cap ? op : cap;
+}
+
+// decodes one plane into out (row-major uint16, 8-bit samples are widened); returns nullptr or an error text
+const char* decode_plane(const uint8_t* data, size_t n, const TiffInfo& t, uint16_t* out, std::vector<uint8_t>& scratch) {
+    const size_t bps = t.bits / 8;
+    const size_t row_bytes = (size_t)t.width * bps;
+    const uint32_t rps = t.rows_per_strip < t.height ? t.rows_per_strip : t.height;
+    const size_t nstrips = ((size_t)t.height + rps - 1) / rps;
+    if (t.strip_off.size() < nstrips) return "fewer strips than the image needs";
+    scratch.resize((size_t)rps * row_bytes);
+    for (size_t s = 0; s < nstrips; ++s) {
+        const uint32_t r0 = (uint32_t)(s * rps);
+        const uint32_t rows = r0 + rps <= t.height ? rps : t.height - r0;
+        const size_t want = (size_t)rows * row_bytes;
+        const uint8_t* src = data + t.strip_off[s];
+        const uint8_t* raw;
+        if (t.compression == 1) {
+            if (t.strip_len[s] < want) return "uncompressed strip shorter than its rows";
+            raw = src;
+        } else {
+            if (lzw_decode(src, (size_t)t.strip_len[s], scratch.data(), want) != want) return "LZW strip does not decode to its rows";
+            raw = scratch.data();
+        }
+        for (uint32_t r = 0; r < rows; ++r) {
+            const uint8_t* in = raw + (size_t)r * row_bytes;
+            uint16_t* o = out + (size_t)(r0 + r) * t.width;
+            if (bps == 1) {
+                uint8_t acc = 0;
+                for (uint32_t x = 0; x < t.width; ++x) {
+                    const uint8_t v = t.predictor == 2 ? (uint8_t)(acc + in[x]) : in[x];
+                    acc = v;
+                    o[x] = v;
+                }
+            } else if (!t.big && t.predictor == 1) {
+                memcpy(o, in, row_bytes);  // little-endian samples are already in host order
+            } else {
+                uint16_t acc = 0;
+                for (uint32_t x = 0; x < t.width; ++x) {
+                    const uint16_t w = t.big ? (uint16_t)(in[2 * x] << 8 | in[2 * x + 1]) : (uint16_t)(in[2 * x] | in[2 * x + 1] << 8);
+                    const uint16_t v = t.predictor == 2 ? (uint16_t)(acc + w) : w;
+                    acc = v;
+                    o[x] = v;
+                }
+            }
+        }
+    }
+    if (t.photometric == 0) {  // WhiteIsZero
+        const uint16_t top = t.bits == 8 ? 255 : 65535;
+        for (size_t i = 0; i < (size_t)t.width * t.height; ++i) out[i] = (uint16_t)(top - out[i]);
+    }
+    return nullptr;
+}
+
+bool read_file(const char* path, std::vector<uint8_t>& buf) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) {
+        fclose(f);
+        return false;
+    }
+    buf.resize((size_t)sz);
+    const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return got == (size_t)sz;
+}
+
+thread_local std::string g_tiff_error;
+
+}  // namespace
+
+extern "C" {
+
+const char* dlv_tiff_last_error(void) { return g_tiff_error.c_str(); }
+
+int dlv_tiff_plane_size(const char* path, int* height, int* width, int* bits) {
+    if (!path) return DLV_EINVAL;
+    std::vector<uint8_t> buf;
+    if (!read_file(path, buf)) {
+        g_tiff_error = std::string("cannot read ") + path;
+        return DLV_EINVAL;
+    }
+    TiffInfo t;
+    if (const char* e = parse_ifd(buf.data(), buf.size(), t)) {
+        g_tiff_error = std::string(path) + ": " + e;
+        return DLV_EUNSUP;
+    }
+    if (height) *height = (int)t.height;
+    if (width) *width = (int)t.width;
+    if (bits) *bits = (int)t.bits;
+    return DLV_OK;
+}
+
+int dlv_tiff_read_plane_u16(const char* path, uint16_t* out_host, int height, int width) {
+    if (!path || !out_host) return DLV_EINVAL;
+    std::vector<uint8_t> buf, scratch;
+    if (!read_file(path, buf)) {
+        g_tiff_error = std::string("cannot read ") + path;
+        return DLV_EINVAL;
+    }
+    TiffInfo t;
+    const char* e = parse_ifd(buf.data(), buf.size(), t);
+    if (!e && ((int)t.height != height || (int)t.width != width)) e = "plane size differs from the expected one";
+    if (!e) e = decode_plane(buf.data(), buf.size(), t, out_host, scratch);
+    if (e) {
+        g_tiff_error = std::string(path) + ": " + e;
+        return DLV_EUNSUP;
+    }
+    return DLV_OK;
+}
+
+// planes paths[0..n_planes) -> vol_dev[(z0 + i) * plane_stride + y * row_stride + x], decoded by n_threads host threads
+// into two pinned staging chunks that alternate between "being filled" and "being copied"
+int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_planes, int height, int width, uint16_t* vol_dev,
+                             long long plane_stride, long long row_stride, int n_threads) {
+    if (!ctx || !paths || !vol_dev) return DLV_EINVAL;
+    if (n_planes <= 0 || height <= 0 || width <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty stack");
+    if (row_stride < width || plane_stride < (long long)height * row_stride) return dlv_fail(ctx, DLV_EINVAL, "strides smaller than the plane");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    const size_t plane_elems = (size_t)height * width;
+    // planes per staging chunk: at least one per thread, about 256 MB
+    const int by_size = (int)std::max<size_t>(1, ((size_t)256 << 20) / (plane_elems * 2));
+    const int chunk = std::max(1, std::min(n_planes, std::max(n_threads, by_size)));
+    uint16_t* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2];
+    for (int b = 0; b < 2; ++b) {
+        DLV_HIP(ctx, hipHostMalloc((void**)&stage[b], (size_t)chunk * plane_elems * 2, hipHostMallocDefault));
+        DLV_HIP(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    }
+    std::string err;
+    std::atomic<bool> failed{false};
+    int rc = DLV_OK;
+    for (int c0 = 0, it = 0; c0 < n_planes && !failed; c0 += chunk, ++it) {
+        const int b = it & 1;
+        const int cn = std::min(chunk, n_planes - c0);
+        if (it >= 2) (void)hipEventSynchronize(done[b]);  // the copy that read this staging chunk has finished
+        std::atomic<int> next{0};
+        std::vector<std::string> errs(n_threads);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < std::min(n_threads, cn); ++t)
+            pool.emplace_back([&, t]() {
+                std::vector<uint8_t> buf, scratch;
+                for (;;) {
+                    const int i = next.fetch_add(1);
+                    if (i >= cn || failed) break;
+                    const char* path = paths[c0 + i];
+                    const char* e = nullptr;
+                    TiffInfo ti;
+                    if (!read_file(path, buf)) e = "cannot read the file";
+                    if (!e) e = parse_ifd(buf.data(), buf.size(), ti);
+                    if (!e && ((int)ti.height != height || (int)ti.width != width)) e = "plane size differs from the first plane";
+                    if (!e) e = decode_plane(buf.data(), buf.size(), ti, stage[b] + (size_t)i * plane_elems, scratch);
+                    if (e) {
+                        errs[t] = std::string(path) + ": " + e;
+                        failed = true;
+                    }
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (failed) {
+            for (auto& e : errs)
+                if (!e.empty()) err = e;
+            break;
+        }
+        hipError_t he = hipSuccess;
+        if (plane_stride == (long long)height * row_stride) {  // planes back to back: one 2-D copy for the chunk
+            he = hipMemcpy2DAsync(vol_dev + (long long)c0 * plane_stride, (size_t)row_stride * 2, stage[b], (size_t)width * 2,
+                                  (size_t)width * 2, (size_t)cn * height, hipMemcpyHostToDevice, ctx->stream);
+        } else {
+            for (int i = 0; i < cn && he == hipSuccess; ++i)
+                he = hipMemcpy2DAsync(vol_dev + (long long)(c0 + i) * plane_stride, (size_t)row_stride * 2,
+                                      stage[b] + (size_t)i * plane_elems, (size_t)width * 2, (size_t)width * 2, (size_t)height,
+                                      hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (he != hipSuccess) {
+            err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(he);
+            failed = true;
+            break;
+        }
+        (void)hipEventRecord(done[b], ctx->stream);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipEventDestroy(done[b]);
+        (void)hipHostFree(stage[b]);
+    }
+    if (failed) rc = dlv_fail(ctx, DLV_EUNSUP, "%s", err.c_str());
+    return rc;
+}
+
+}  // extern "C"

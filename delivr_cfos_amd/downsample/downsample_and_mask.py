@@ -54,26 +54,48 @@ def _tiff_ifd(path: str):
 
 
 def read_tiff_plane(path: str) -> np.ndarray:
-    """Baseline TIFF, uncompressed strips, 8/16-bit greyscale (what light-sheet stitchers emit when
-    compression is off).  Anything else raises - codecs are out of scope."""
-    e, t = _tiff_ifd(path)
-    w, h = t[256][0], t[257][0]
-    bits = t.get(258, (1,))[0]
-    if t.get(259, (1,))[0] != 1:
-        raise NotImplementedError(f"{path}: compressed TIFF (tag 259 = {t[259][0]}) - decode upstream; LZW/deflate "
-                                  "codecs are outside the accelerated path")
-    if t.get(277, (1,))[0] != 1 or bits not in (8, 16):
-        raise NotImplementedError(f"{path}: only 8/16-bit single-channel planes are supported")
-    dt = np.dtype(("<" if e == "<" else ">") + ("u2" if bits == 16 else "u1"))
-    out = np.empty(w * h, dtype=dt)
-    pos = 0
-    with open(path, "rb") as fh:
-        for off, nbytes in zip(t[273], t[279]):
-            fh.seek(off)
-            chunk = np.frombuffer(fh.read(nbytes), dtype=dt)
-            out[pos: pos + chunk.size] = chunk
-            pos += chunk.size
-    return out.reshape(h, w).astype(np.uint16)
+    """One z-plane as uint16 (8-bit planes are widened): classic TIFF, strips, uncompressed or LZW (with or without the
+    horizontal predictor), decoded by the native reader in libdelivr_hip.so (csrc/tiffio.hip; host code, no GPU needed).
+    Anything else (tiles, BigTIFF, deflate/JPEG, multi-channel) raises NotImplementedError."""
+    import ctypes as C
+
+    from .. import _lib
+
+    lib = _lib.load()
+    h, w, bits = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.dlv_tiff_plane_size(path.encode(), C.byref(h), C.byref(w), C.byref(bits))
+    if rc != 0:
+        msg = lib.dlv_tiff_last_error().decode()
+        raise (FileNotFoundError if rc == -1 else NotImplementedError)(msg)
+    out = np.empty((h.value, w.value), dtype=np.uint16)
+    if lib.dlv_tiff_read_plane_u16(path.encode(), out.ctypes.data_as(C.c_void_p), h.value, w.value) != 0:
+        raise NotImplementedError(lib.dlv_tiff_last_error().decode())
+    return out
+
+
+def load_stack_to_device(engine, planes: Sequence[str], out=None, n_threads: int = 0):
+    """All planes of a raw stack -> uint16 (Z,Y,X) tensor in HBM (reference: one cv2.imread per plane on one core,
+    :396-404).  Planes are decoded by a pool of host threads into pinned buffers and copied while the next chunk
+    decodes (dlv_tiff_stack_to_device).  ``out``: an existing uint16 tensor whose leading (Z,Y,X) corner is filled
+    (e.g. the zero-initialised padded network input); its strides are honoured."""
+    import ctypes as C
+
+    torch = engine.torch
+    lib = engine.lib
+    h, w, bits = C.c_int(), C.c_int(), C.c_int()
+    if lib.dlv_tiff_plane_size(planes[0].encode(), C.byref(h), C.byref(w), C.byref(bits)) != 0:
+        raise NotImplementedError(lib.dlv_tiff_last_error().decode())
+    Z, Y, X = len(planes), h.value, w.value
+    if out is None:
+        out = torch.empty((Z, Y, X), dtype=torch.uint16, device=engine.device)
+    if out.dtype != torch.uint16 or out.dim() != 3 or out.shape[0] < Z or out.shape[1] < Y or out.shape[2] < X or out.stride(2) != 1:
+        raise ValueError("out: uint16 (>=Z, >=Y, >=X) tensor with unit x stride")
+    arr = (C.c_char_p * Z)(*[p.encode() for p in planes])
+    engine._enter()
+    engine._check(lib.dlv_tiff_stack_to_device(engine.ctx, arr, Z, Y, X, C.c_void_p(out.data_ptr()), int(out.stride(0)),
+                                               int(out.stride(1)), int(n_threads)))
+    engine._leave()
+    return out[:Z, :Y, :X]
 
 
 def get_real_size(raw_folder: str) -> Tuple[int, int, int]:
@@ -142,11 +164,10 @@ def downsample_mask(settings: dict, brain: str, engine=None):
     planes = sorted(glob.glob(raw_location + "/*.tif"))
     if not planes:
         raise FileNotFoundError(f"no .tif planes under {raw_location}")
-    stack = np.stack([read_tiff_plane(p) for p in planes])
     own = engine is None
     eng = engine or HipEngine(0)
     try:
-        raw_dev = eng.to_device(stack)
+        raw_dev = load_stack_to_device(eng, planes)   # parallel decode -> pinned staging -> HBM
         ratios = downsample_ratios(md["downsample_steps"])
         results = os.path.join(md["output_location"], brain)
         os.makedirs(os.path.join(results, "masked_niftis"), exist_ok=True)

@@ -187,6 +187,23 @@ int dlv_relabel_u32_dev(dlv_ctx* ctx, uint32_t* labels_dev, uint64_t nvox, const
 int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n, uint32_t* counts,
                          uint32_t* bbmin, uint32_t* bbmax, uint64_t* sums);
 
+/* ---- TIFF z-plane ingest -------------------------------------------------------- */
+/* Replaces the per-plane cv2.imread / skimage.io / tifffile reads of the raw stack
+ * (downsample/downsample_and_mask.py:25-30, :36-41, :396-404).  Classic TIFF, II/MM, strips, 8/16-bit unsigned single
+ * channel, compression 1 (none) or 5 (LZW, predictor 1 or 2); anything else is refused with DLV_EUNSUP.
+ *  dlv_tiff_plane_size / dlv_tiff_read_plane_u16: host-only (no context, no GPU): header fields / one decoded plane
+ *    (8-bit samples widened) into a caller-owned (height,width) uint16 host array; dlv_tiff_last_error() holds the
+ *    message of the calling thread's last failure.
+ *  dlv_tiff_stack_to_device: planes paths[0..n_planes) are decoded by n_threads host threads (0 = one per core, at
+ *    most 32) into pinned staging buffers and copied to vol_dev[(i*plane_stride) + y*row_stride + x] (uint16 elements;
+ *    strides let the caller fill the zero-padded (Zp,Yp,Xp) network input directly) while the next chunk is being
+ *    decoded.  Synchronous. */
+const char* dlv_tiff_last_error(void);
+int dlv_tiff_plane_size(const char* path, int* height, int* width, int* bits);
+int dlv_tiff_read_plane_u16(const char* path, uint16_t* out_host, int height, int width);
+int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_planes, int height, int width, uint16_t* vol_dev,
+                             long long plane_stride, long long row_stride, int n_threads);
+
 /* ---- blob painting (visualisation step) ------------------------------------------ */
 /* The colouring loops of blob_highlighter.py:108-125 (RGB) and :150-158 (region id): cells are visited in CSV order
  * and IMG[box] = bin_img[box] * value is assigned over each cell's padded bounding box, so the last listed box that

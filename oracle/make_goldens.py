@@ -482,7 +482,45 @@ def golden_atlas():
     print("ref_atlas.npz cells kept", len(out), "of", n, "heat", heat.dtype, heat.shape, float(heat.sum()))
 
 
-if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "atlas":
+def golden_tiff():
+    """TIFF planes written by libtiff (through Pillow) - LZW with and without the horizontal predictor, one and many
+    strips, 8 and 16 bit - plus a hand-written big-endian uncompressed plane, with the pixel arrays they hold."""
+    import struct
+
+    from PIL import Image
+
+    rng = np.random.default_rng(4)
+    a = (np.cumsum(rng.integers(-3, 4, (97, 131)), axis=1) + 2000).clip(0, 65535).astype(np.uint16)
+    a[10:20, 30:60] = rng.integers(0, 65535, (10, 30))
+    Image.fromarray(a).save(os.path.join(GOLD, "tiff_lzw16.tif"), compression="tiff_lzw")
+    Image.fromarray(a).save(os.path.join(GOLD, "tiff_lzw16_pred.tif"), compression="tiff_lzw", tiffinfo={317: 2})
+    Image.fromarray(a).save(os.path.join(GOLD, "tiff_lzw16_strips.tif"), compression="tiff_lzw", tiffinfo={278: 10})
+    b = rng.integers(0, 256, (180, 200)).astype(np.uint8)      # > 4094 codes: the table fills up and is reset
+    b[50:120] = 7                                              # long runs: KwKwK codes
+    Image.fromarray(b).save(os.path.join(GOLD, "tiff_lzw8.tif"), compression="tiff_lzw")
+    c = rng.integers(0, 65535, (9, 13)).astype(np.uint16)
+    data = c.astype(">u2").tobytes()
+    tags = [(256, 3, 1, 13), (257, 3, 1, 9), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1),
+            (278, 3, 1, 9), (279, 4, 1, len(data))]
+    with open(os.path.join(GOLD, "tiff_be16.tif"), "wb") as fh:
+        fh.write(b"MM" + struct.pack(">HI", 42, 8 + len(data)))
+        fh.write(data)
+        fh.write(struct.pack(">H", len(tags)))
+        for tag, typ, cnt, val in tags:
+            fh.write(struct.pack(">HHI", tag, typ, cnt) + (struct.pack(">HH", val, 0) if typ == 3 else struct.pack(">I", val)))
+        fh.write(struct.pack(">I", 0))
+    np.savez_compressed(os.path.join(GOLD, "tiff_expected.npz"), lzw16=a, lzw8=b, be16=c)
+    for f in ("tiff_lzw16.tif", "tiff_lzw16_pred.tif", "tiff_lzw16_strips.tif", "tiff_lzw8.tif", "tiff_be16.tif"):
+        im = Image.open(os.path.join(GOLD, f))
+        t = dict(im.tag_v2)
+        print(f, os.path.getsize(os.path.join(GOLD, f)), "bytes", im.size, "compression", t.get(259), "predictor", t.get(317),
+              "rows/strip", t.get(278), "strips", len(t.get(273, ())))
+        assert (np.array(im) == {"tiff_lzw8.tif": b, "tiff_be16.tif": c}.get(f, a)).all()
+
+
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "tiff":
+    golden_tiff()
+elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "atlas":
     golden_atlas()
 elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "paint":
     golden_paint()

@@ -321,3 +321,33 @@ def test_blob_highlighter_writes_the_reference_planes(tmp_path, golden_dir):
     blob_highlighter(settings, [brain, ""], (1, 1, Z, Y, X))
     p = read_tiff_plane(os.path.join(d_out, brain, brain + "_region_id_tiffs", "region_id_0005.tif"))
     np.testing.assert_array_equal(p, g["region_id"][5])
+
+
+def test_tiff_stack_ingest_to_device(golden_dir):
+    """dlv_tiff_stack_to_device: LZW planes (three encodings of the same image, shuffled over 23 z positions) decoded
+    by the host thread pool land at the right z offsets, both into a fresh (Z,Y,X) tensor and into the corner of a
+    zero-initialised padded tensor (strides honoured, padding untouched)."""
+    import torch
+    from delivr_cfos_amd.downsample.downsample_and_mask import load_stack_to_device
+    from delivr_cfos_amd.engine import HipEngine
+
+    want = np.load(os.path.join(golden_dir, "tiff_expected.npz"))["lzw16"]
+    names = ["tiff_lzw16.tif", "tiff_lzw16_pred.tif", "tiff_lzw16_strips.tif"]
+    planes = [os.path.join(golden_dir, names[(5 * i) % 3]) for i in range(23)]
+    eng = HipEngine(0)
+    try:
+        vol = load_stack_to_device(eng, planes, n_threads=4)
+        assert tuple(vol.shape) == (23, 97, 131) and vol.dtype == torch.uint16
+        got = vol.cpu().numpy()
+        for z in range(23):
+            np.testing.assert_array_equal(got[z], want)
+        padded = torch.zeros((32, 128, 160), dtype=torch.uint16, device=eng.device)
+        view = load_stack_to_device(eng, planes, out=padded, n_threads=1)
+        p = padded.cpu().numpy()
+        np.testing.assert_array_equal(p[:23, :97, :131], np.broadcast_to(want, (23, 97, 131)))
+        assert p[23:].max() == 0 and p[:, 97:].max() == 0 and p[:, :, 131:].max() == 0
+        assert view.data_ptr() == padded.data_ptr()
+        with pytest.raises(RuntimeError):
+            load_stack_to_device(eng, planes[:2] + [os.path.join(golden_dir, "tiff_be16.tif")])   # size mismatch
+    finally:
+        eng.close()

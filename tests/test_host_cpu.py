@@ -311,3 +311,20 @@ def test_swc_writer_matches_reference_golden(golden_dir, tmp_path):
         assert open(c).read() == str(t)
     assert split_parameters(p) == [int(v) for v in s["params"]]
     assert sampling_factors(p, (25, 10, 10)) == (10.0, 10.0, 4.0)
+
+
+def test_native_tiff_reader_decodes_libtiff_planes(golden_dir):
+    """csrc/tiffio.hip (host code in libdelivr_hip.so) against planes written by libtiff: LZW, LZW + horizontal
+    predictor, many strips, 8 bit with table resets, big-endian uncompressed; unsupported files are refused loudly."""
+    from delivr_cfos_amd.downsample.downsample_and_mask import get_real_size, read_tiff_plane
+
+    want = np.load(os.path.join(golden_dir, "tiff_expected.npz"))
+    for name, key in (("tiff_lzw16.tif", "lzw16"), ("tiff_lzw16_pred.tif", "lzw16"), ("tiff_lzw16_strips.tif", "lzw16"),
+                      ("tiff_lzw8.tif", "lzw8"), ("tiff_be16.tif", "be16")):
+        got = read_tiff_plane(os.path.join(golden_dir, name))
+        assert got.dtype == np.uint16
+        np.testing.assert_array_equal(got, want[key])
+    with pytest.raises(FileNotFoundError):
+        read_tiff_plane(os.path.join(golden_dir, "no_such_plane.tif"))
+    with pytest.raises(NotImplementedError):
+        read_tiff_plane(os.path.join(golden_dir, "ref_csv.npz"))       # not a TIFF
