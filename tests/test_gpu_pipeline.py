@@ -351,3 +351,53 @@ def test_tiff_stack_ingest_to_device(golden_dir):
             load_stack_to_device(eng, planes[:2] + [os.path.join(golden_dir, "tiff_be16.tif")])   # size mismatch
     finally:
         eng.close()
+
+
+def test_all_background_volume_and_volume_smaller_than_the_window(tmp_path):
+    """Edge cases of the step mirror: (a) a volume that is all background - every window is skipped, the mask is empty,
+    cc3d would return N = 0 and the CSV holds the header only; (b) a volume smaller than the window in every axis - one
+    window, padded input, mask cropped back."""
+    import torch
+    from delivr_cfos_amd.count_blobs import count_blobs
+    from delivr_cfos_amd.inference.inference import run_inference
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    sd = random_state_dict(5)
+    wfile = str(tmp_path / "weights.tar")
+    torch.save({"state_dict": sd}, wfile)
+    crop = (32, 32, 32)
+    cases = {"empty": np.zeros((33, 40, 35), dtype=np.uint16),
+             "small": np.random.default_rng(3).integers(200, 4000, (20, 17, 30)).astype(np.uint16)}
+    for brain, vol in cases.items():
+        root = tmp_path / brain
+        mask_dir = root / "01" / brain / "masked_niftis"
+        os.makedirs(mask_dir)
+        pad = _write_padded_npy(str(mask_dir / "masked_nifti.npy"), vol, crop)
+        settings = {"blob_detection": {"window_dimensions": {"window_dim_0": 32, "window_dim_1": 32, "window_dim_2": 32}},
+                    "postprocessing": {"output_location": str(root / "03") + "/"},
+                    "mi355x": {"precision": "fp32"}, "FLAGS": {"SAVE_ACTIVATED_OUTPUT": False}}
+        out = run_inference(niftis=[str(mask_dir / "masked_nifti.npy")], output_folder=str(root / "02") + "/",
+                            stack_shape=(1, 1, *vol.shape), model_weights=wfile, tta=False, comment=brain, load_all_ram=True,
+                            settings=settings)
+        binaries = np.load(os.path.join(str(out), "binary_segmentations", "binaries.npy"))
+        assert binaries.shape == vol.shape and binaries.dtype == np.uint8
+        net = orc.build_unet(seed=None)
+        net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+        padded = np.zeros(pad, dtype=np.uint16)
+        padded[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+        acc = np.zeros(pad, dtype=np.float32)
+        orc.sliding_window_pass(padded, crop, lambda x: orc.unet_forward(net, x), acc, None, 0.5, None, 1, fp16=False)
+        ref = orc.finalize(acc, None, padded, vol.shape, 0.5, 30)
+        margin = np.abs(acc[: vol.shape[0], : vol.shape[1], : vol.shape[2]]) < 1e-3
+        assert np.array_equal(binaries[~margin], ref[~margin])
+        if brain == "empty":
+            assert binaries.max() == 0
+        n = count_blobs(settings, str(root / "02") + "/", 0, brain, (1, 1, *vol.shape))
+        lab_ref, n_ref = orc.ccl26(binaries)
+        assert n == n_ref
+        post = str(root / "03")
+        csv_path = os.path.join(post, f"{vol.shape}_{brain}.csv")
+        assert open(csv_path).read() == orc.cells_csv_text(orc.cc_stats(lab_ref, n_ref), n_ref)
+        if brain == "empty":
+            assert n == 0 and open(csv_path).read().strip() == ",Blob,Coords,Size"
