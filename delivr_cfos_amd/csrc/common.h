@@ -143,9 +143,10 @@ int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, in
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
                         int h, int w, int flip_dim, float scale, float* acc, int f16);
 int dlv_pack_weights_bf16(dlv_ctx* ctx);
-// z-marching conv for Cout = 32, Cin in {32, 64} (conv_zmarch.hip)
-int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
-                            const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts);
+// z-marching conv for Cout in {32, 64, ...} (blocks of 32), Cin in {32, 64} (conv_zmarch.hip)
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
+                            const void* wpk, const float* bias, void* out, float* partials, int B, int D, int H, int W,
+                            int* nparts);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

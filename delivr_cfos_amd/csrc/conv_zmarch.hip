@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                            uint4* __restrict__ out, float* __restrict__ partials, int D,
                                                            int H, int W, int tilesY, int tilesX, int zseg,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps, int nseg, int cout8) {
     using C = ZmCfg<CIN, TYT>;
     constexpr bool LATE = false;
     constexpr int NT = 64 * TYT / VB;            // threads: TYT rows / VB rows per wave
@@ -56,7 +56,9 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
     float* red = reinterpret_cast<float*>(lds_p + C::PELEMS);  // [4 waves][32][2]
 
     const int n = blockIdx.z;
-    const int seg = blockIdx.y;
+    // blockIdx.y = z segment + nseg * output-channel block (32 channels each; Cout = 64 layers run two blocks
+    // over the same input)
+    const int seg = blockIdx.y % nseg, cb = blockIdx.y / nseg;
     const int tile = blockIdx.x;
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int y0 = ty * TYT, x0 = tx * ZM_TX;
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
     const long long vox = (long long)D * plane;
 
     // ---- weights -> LDS (A-fragment order, lane-linear) ------------------------------------------------
-    for (int i = threadIdx.x; i < C::WELEMS; i += NT) lds_w[i] = wpk[i];
+    for (int i = threadIdx.x; i < C::WELEMS; i += NT) lds_w[i] = wpk[(size_t)cb * C::WELEMS + i];
 
     // ---- per-thread staging map of the halo plane (constant along z) ----------------------------------
     long long goff[NPRE];
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
     float bs[16], ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+        bs[r] = bias[cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
         ssum[r] = ssq[r] = 0.f;
     }
 
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
             for (int w8 = 0; w8 < TYT / VB; ++w8) v += red[w8 * 64 + i];
             const long long nparts = (long long)gridDim.x * nzc;
             const long long part = (long long)zc * gridDim.x + tile;
-            partials[(((long long)n * nparts + part) * 32 + (i >> 1)) * 2 + (i & 1)] = v;
+            partials[(((long long)n * nparts + part) * (cout8 * 8) + cb * 32 + (i >> 1)) * 2 + (i & 1)] = v;
         }
         __syncthreads();
     };
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
                     uint2 u;
                     u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
                     u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
-                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * cout8 + cb * 4 + g) * vox + o);
                     if (ABL & 8) {  // streaming store: the output is not re-read by this kernel
                         __builtin_nontemporal_store(u.x, &dst[h].x);
                         __builtin_nontemporal_store(u.y, &dst[h].y);
@@ -907,8 +909,11 @@ __global__ void __launch_bounds__(512, 2) conv3_zmarch4_kernel(const uint4* __re
 }  // namespace
 
 // returns the number of partial-sum rows per sample (columns) or a negative error
-int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, int c1, const void* in2, int c2, const void* wpk,
-                            const float* bias, void* out, float* partials, int B, int D, int H, int W, int* nparts) {
+int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
+                            const void* wpk, const float* bias, void* out, float* partials, int B, int D, int H, int W,
+                            int* nparts) {
+    if (cout % 32 || cout <= 0) return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cout must be a multiple of 32");
+    const int ncb = cout / 32;
     const int variant = ctx->zm_variant;  // DLV_ZM_VARIANT at context creation, or dlv_debug_set_zm_variant
     // 16-row tiles (8 waves x 2 rows) for the single-source layers unless a variant asks otherwise
     // 16-row tiles (8 waves x 2 rows) only as A/B variant 3: measured equal/slower than 8 rows x 1 (profiles/README.md)
@@ -916,9 +921,9 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, in
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, ZM_TX);
     // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
     int zseg = ((D + 15) / 16) * 16;
-    while ((long long)B * tilesY * tilesX * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
+    while ((long long)B * tilesY * tilesX * ncb * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
     const int nseg = dlv_cdiv(D, zseg);
-    dim3 grid(tilesY * tilesX, nseg, B);
+    dim3 grid(tilesY * tilesX, nseg * ncb, B);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
     // kernel variants (DLV_ZM_VARIANT selects one for A/B timing): VB rows per wave, TYT tile rows -> TYT/VB waves
 #define DLV_ZM_LAUNCH_P(P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_)                                                                                  \
@@ -931,7 +936,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, in
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_zmarch_kernel<P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
-                           (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg, (unsigned long long*)ctx->stamp_buf);           \
+                           (uint4*)out, partials, D, H, W, tilesY, tilesX, zseg, (unsigned long long*)ctx->stamp_buf, nseg, cout / 8); \
     } while (0)
 #define DLV_ZM2_LAUNCH(P_, NSRC_, ABL_, DMA_, PIPE_)                                                                              \
     do {                                                                                                                 \
@@ -945,7 +950,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, in
                            ctx->stream, (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out,      \
                            partials, D, H, W, tilesY, tilesX, zseg, (const uint4*)ctx->zero_page);                       \
     } while (0)
-    if (variant >= 40 && variant <= 45 && H % 8 == 0 && W % 32 == 0 && (long long)4 * D * H * W * 16 < (1ll << 32) &&
+    if (cout == 32 && variant >= 40 && variant <= 45 && H % 8 == 0 && W % 32 == 0 && (long long)4 * D * H * W * 16 < (1ll << 32) &&
         ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
 #define DLV_ZM4_LAUNCH(P_, NSRC_, ST_, ABL_)                                                                                       \
     do {                                                                                                                 \
@@ -975,7 +980,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, const void* in1, in
 #undef DLV_ZM4_LAUNCH
     } else
     // variants 20 (double-buffered half-planes, register staging), 24 (LDS-DMA staging), 25 (20 + pipelined epilogue)
-    if ((variant == 20 || variant == 24 || variant == 25) && ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
+    if (cout == 32 && (variant == 20 || variant == 24 || variant == 25) && ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
 #define DLV_ZM2_PICK(P_, NSRC_)                                   \
     do {                                                          \
         if (variant == 24) DLV_ZM2_LAUNCH(P_, NSRC_, 0, true, false);   \

@@ -872,14 +872,19 @@ struct Net16 {
         const DlvConvLayer& L = ctx->conv[li];
         if (c1 + c2 != L.cin) return dlv_fail(ctx, DLV_ESTATE, "conv %d: %d+%d input channels, expected %d", li, c1, c2, L.cin);
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
-        if (L.cout == 32 && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
+        // z-march: weights of one 32-channel output block resident in LDS (54 / 108 KB), so Cin <= 64; Cout = 64 runs as
+        // two blocks over the same input (the 32^3 level: 226 -> ~135 us per conv against the generic kernel)
+        if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
             char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx32", P::IS_F16 ? "f16" : "bf16", L.cin);
-            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * 32 * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + 32));
+            snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
             int np = 0;
-            DLV_TRY(dlv_conv3_zmarch_launch(ctx, P::IS_F16, L.cin, in1, c1, in2, c2, wpack<P>(L), L.bias, out, partials, B, d.D, d.H, d.W, &np));
+            if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
+                return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
+            DLV_TRY(dlv_conv3_zmarch_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, in2, c2, wpack<P>(L), L.bias, out, partials, B,
+                                            d.D, d.H, d.W, &np));
             zp.end();
-            if ((size_t)B * np * 64 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
+            if ((size_t)B * np * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
             return stats(np, li, d);
         }
         const bool tx16 = d.W >= 16;

@@ -54,6 +54,9 @@ CONV_CASES = [
     (17, 32, 0, 40, 16, 64),
     (16, 32, 32, 9, 8, 32),
     (14, 32, 32, 24, 20, 72),
+    # Cout = 64 with W >= 32: z-march with two output-channel blocks (z segments, ragged rows)
+    (4, 32, 0, 20, 12, 32),
+    (5, 64, 0, 33, 24, 64),
 ]
 
 
@@ -198,7 +201,8 @@ def test_sw_pass_fast_kernels_vs_generic_and_fp32(net):
 # ---------------------------------------------------------------------------------------------------
 # IEEE-half variant of the same kernels (precision="fp16"): 11 significant bits instead of 8
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("li,c1,c2,D,H,W", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[5], CONV_CASES[8], CONV_CASES[11]])
+@pytest.mark.parametrize("li,c1,c2,D,H,W", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[5], CONV_CASES[8], CONV_CASES[11], CONV_CASES[12],
+                                            CONV_CASES[13]])
 def test_conv_block_fp16(eng, net, li, c1, c2, D, H, W):
     """Same check as test_conv_block_bf16 on fp16-rounded inputs/weights: errors shrink by the 3 extra mantissa bits."""
     import torch
