@@ -897,6 +897,10 @@ struct Net16 {
         const bool wlds = d.vox() <= 1024;
         int ncb = wlds ? (L.cout >= 64 ? 2 : 1) : (L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1));
         while (ncb > 1 && (long long)B * ntiles * (L.cout / (32 * ncb)) < 512) ncb >>= 1;
+        if (const char* e = getenv("DLV_GENERIC_NCB")) {  // A/B switch (profiles/README.md)
+            const int want = atoi(e);
+            if ((want == 1 || want == 2 || (want == 4 && !wlds)) && L.cout % (32 * want) == 0) ncb = want;
+        }
         if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
         const size_t slab_bytes = (size_t)(tx16 ? ConvTile<16>::SLAB : ConvTile<8>::SLAB) * 16;
         const size_t lds = std::max<size_t>(slab_bytes + (wlds ? (size_t)ncb * 27 * 2 * 64 * 16 : 0), (size_t)4 * ncb * 32 * 2 * 4);
