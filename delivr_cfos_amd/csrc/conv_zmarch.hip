@@ -1003,6 +1003,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
         if (cin == 32) {
             if (variant == 6) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 8, false);
             else if (variant == 30) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 16, false);
+            else if (variant == 31) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 19, false);  // stamped, no staging, no epilogue
             else DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 0, false);
         } else if (cin == 64) {
             if (variant == 6) DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 8, false);

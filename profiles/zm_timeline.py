@@ -33,7 +33,7 @@ if VAR == "41":
     t = s[:, :, steps, :6].astype(np.float64)
     names = ["mfma_loop(issue)+fetch+pieces", "flush", "write_plane", "pack", "barrier"]
 else:
-    s = st.cpu().numpy().reshape(tiles, 8, E + 4, 8)
+    s = st.cpu().numpy()[: tiles * 8 * (E + 4) * 8].reshape(tiles, 8, E + 4, 8)
     steps = slice(8, E - 8)                  # steady state
     t = s[:, :, steps, :7].astype(np.float64)
     names = ["issue_loads", "mfma_loop(issue)", "epilogue", "barrierA", "write_plane", "barrierB"]
