@@ -429,9 +429,17 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
     for (int v = 0; v < 2; ++v) lbase[v] = ((h * T::HZ + wave) * T::HY + (v * T::RV + vr)) * T::HX + vx;
 
     const int nslab = cin8 / 4;
-    for (int sl = 0; sl < nslab; ++sl) {
-        __syncthreads();  // previous slab fully consumed
-        for (int i = threadIdx.x; i < T::SLAB; i += 256) {
+    // staging map of one 32-channel slab (the same for every slab: only the base pointer moves): element i of the
+    // halo tile <- chunk c, voxel (gz,gy,gx).  The next slab is fetched into registers while the current one is being
+    // multiplied (issue early / write late), so the HBM/L2 latency of the staging no longer sits between two MFMA phases.
+    constexpr int NPF = (T::SLAB + 255) / 256;
+    int poff[NPF];
+    unsigned pvalid = 0;
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        poff[j] = 0;
+        if (i < T::SLAB) {
             const int xh = i % T::HX;
             int r = i / T::HX;
             const int yh = r % T::HY;
@@ -439,14 +447,26 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
             const int zh = r % T::HZ;
             const int c = r / T::HZ;
             const int gz = z0 + zh - 1, gy = y0 + yh - 1, gx = x0 + xh - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
             if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                const int cg = sl * 4 + c;
-                const uint4* src = cg < c1_8 ? in1 + ((long long)n * c1_8 + cg) * vox
-                                             : in2 + ((long long)n * c2_8 + (cg - c1_8)) * vox;
-                v = src[((long long)gz * H + gy) * W + gx];
+                poff[j] = (int)((long long)c * vox + ((long long)gz * H + gy) * W + gx);
+                pvalid |= 1u << j;
             }
-            slab[i] = v;
+        }
+    }
+    uint4 pf[NPF];
+    auto fetch_slab = [&](int sl) __attribute__((always_inline)) {
+        const int cg = sl * 4;  // a 32-channel slab lies entirely in one of the two sources (c1 % 32 == 0)
+        const uint4* src = cg < c1_8 ? in1 + ((long long)n * c1_8 + cg) * vox : in2 + ((long long)n * c2_8 + (cg - c1_8)) * vox;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) pf[j] = src[poff[j]];
+    };
+    fetch_slab(0);
+    for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();  // previous slab fully consumed
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < T::SLAB) slab[i] = ((pvalid >> j) & 1u) ? pf[j] : make_uint4(0, 0, 0, 0);
         }
         if (WLDS) {
             // the slab's weights are fetched cooperatively in one coalesced sweep (deep levels have few
@@ -458,6 +478,7 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
             }
         }
         __syncthreads();
+        if (sl + 1 < nslab) fetch_slab(sl + 1);  // in flight during this slab's MFMAs
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
