@@ -328,3 +328,50 @@ def test_native_tiff_reader_decodes_libtiff_planes(golden_dir):
         read_tiff_plane(os.path.join(golden_dir, "no_such_plane.tif"))
     with pytest.raises(NotImplementedError):
         read_tiff_plane(os.path.join(golden_dir, "ref_csv.npz"))       # not a TIFF
+
+
+def test_merge_components_random_slabs_vs_whole_volume():
+    """parallel.merge_components on random masks, random cuts (incl. empty slabs): per-slab labelling + seam pairs +
+    union + renumbering == labelling of the whole volume (pure host logic, no process group)."""
+    from delivr_cfos_amd.parallel import merge_components, merge_stats
+
+    rng = np.random.default_rng(0)
+    eng = _OracleCclEngine(orc)
+    import torch
+    for trial in range(12):
+        Z, Y, X = int(rng.integers(6, 26)), int(rng.integers(4, 16)), int(rng.integers(4, 16))
+        m = (rng.random((Z, Y, X)) < rng.choice([0.05, 0.2, 0.5])).astype(np.uint8)
+        full, n_full = orc.ccl26(m)
+        cuts = sorted(set([0, Z] + [int(v) for v in rng.integers(0, Z + 1, size=int(rng.integers(1, 4)))]))
+        slabs = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+        if trial % 3 == 0:
+            slabs.insert(1, (slabs[0][1], slabs[0][1]))   # an empty slab in the middle
+        labs, counts, raws = [], [], []
+        for lo, hi in slabs:
+            if hi > lo:
+                lab, n = eng.ccl26(torch.from_numpy(m[lo:hi].copy()))
+                labs.append(lab)
+                counts.append(n)
+                raws.append(eng.cc_stats_raw(lab, n))
+            else:
+                labs.append(None)
+                counts.append(0)
+                raws.append(None)
+        live = [r for r, (lo, hi) in enumerate(slabs) if hi > lo]
+        seams = []
+        for k, r in enumerate(live[:-1]):
+            pr = eng.seam_pairs(labs[r][-1], labs[live[k + 1]][0])
+            if len(pr):
+                seams.append((r, live[k + 1], pr))
+        luts, n = merge_components(counts, seams)
+        assert n == n_full
+        out = np.zeros(m.shape, dtype=np.int64)
+        for (lo, hi), lab, lut in zip(slabs, labs, luts):
+            if hi > lo:
+                out[lo:hi] = lut.astype(np.int64)[lab.numpy()]
+        np.testing.assert_array_equal(out, full.astype(np.int64))
+        st = merge_stats(luts, raws, [s[0] for s in slabs], m.shape, n)
+        want = orc.cc_stats(full, n_full)
+        np.testing.assert_array_equal(st["voxel_counts"], want["voxel_counts"])
+        np.testing.assert_array_equal(st["bounding_boxes"], want["bounding_boxes"])
+        np.testing.assert_array_equal(st["centroids"], want["centroids"])
