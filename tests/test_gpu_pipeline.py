@@ -176,6 +176,15 @@ class _ThreadDist:
     def get_backend(self):
         return "threads"
 
+    def get_rank(self):
+        return self.local.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def barrier(self, group=None):
+        self.bar.wait()
+
     class P2POp:
         def __init__(self, op, tensor, peer, group=None):
             self.op, self.tensor, self.peer = op, tensor, peer
@@ -401,3 +410,50 @@ def test_all_background_volume_and_volume_smaller_than_the_window(tmp_path):
         assert open(csv_path).read() == orc.cells_csv_text(orc.cc_stats(lab_ref, n_ref), n_ref)
         if brain == "empty":
             assert n == 0 and open(csv_path).read().strip() == ",Blob,Coords,Size"
+
+
+@pytest.mark.gpu
+def test_count_blobs_sharded_path_gathers_the_single_volume_result():
+    """count_blobs' multi-rank branch (_count_blobs_sharded: even z-slabs, ccl_sharded, label slabs gathered to rank 0)
+    with three thread-ranks on device 0: labels, N and statistics equal the single-engine result."""
+    import threading
+    import torch
+    from delivr_cfos_amd.count_blobs import _count_blobs_sharded
+    from delivr_cfos_amd.engine import HipEngine
+
+    m = _ccl_volume()
+    world = 3
+    fake = _ThreadDist(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            fake.bind(rank)
+            torch.cuda.set_device(0)
+            eng = HipEngine(0)
+            results[rank] = _count_blobs_sharded(eng, m, fake)
+            eng.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                fake.bar.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors
+    eng = HipEngine(0)
+    lab, n = eng.ccl26(torch.from_numpy(m).cuda())
+    st1 = eng.cc_stats(lab, n)
+    single = lab.cpu().numpy().view(np.uint32)
+    eng.close()
+    labels0, n0, stats0 = results[0]
+    assert n0 == n and all(r[1] == n for r in results)
+    assert results[1][0] is None and results[2][2] is None
+    np.testing.assert_array_equal(labels0, single)
+    for k in ("voxel_counts", "bounding_boxes", "centroids"):
+        np.testing.assert_array_equal(stats0[k], st1[k])
