@@ -50,6 +50,9 @@ class SwParams(C.Structure):
         ("win_end", C.c_int64),
         ("z0", C.c_int), ("nz", C.c_int),
         ("repeat", C.c_int),
+        ("blend_mode", C.c_int),
+        ("sigma_scale", C.c_float),
+        ("wsum_dev", C.c_void_p),
     ]
 
 

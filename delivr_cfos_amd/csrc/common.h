@@ -50,6 +50,7 @@ enum DlvWsSlot {
     WS_TILE_IN,       // gathered fp32 tiles
     WS_TILE_OUT,      // logits of a batch
     WS_TILE_META,     // window starts / maxima
+    WS_BLEND_W,       // Gaussian blend factors (d+h+w floats)
     WS_ERODE,         // distance maps
     WS_CCL,           // CCL scratch
     WS_MISC,
@@ -78,6 +79,10 @@ struct dlv_ctx {
     // weights
     bool weights_loaded = false;
     int features[6] = {0, 0, 0, 0, 0, 0};
+    // Gaussian blend of the current dlv_sw_infer_dev call (null = constant weights): d+h+w normalised 1-D factors in HBM
+    const float* blend_w = nullptr;
+    float blend_min = 0.f;
+    float* blend_wsum = nullptr;
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
     void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
     void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads

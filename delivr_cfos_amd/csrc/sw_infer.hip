@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <cmath>
 
 namespace {
 
@@ -122,7 +123,8 @@ __global__ void __launch_bounds__(256) gather_f32_kernel(const uint16_t* __restr
 __global__ void __launch_bounds__(256) blend_add_kernel(const float* __restrict__ logits, const int* __restrict__ starts,
                                                         int d, int h, int w, int flip_dim, int Yp, int Xp,
                                                         float scale, int rep, float* __restrict__ acc,
-                                                        uint8_t* __restrict__ cnt) {
+                                                        uint8_t* __restrict__ cnt, const float* __restrict__ bw, float bmin,
+                                                        float* __restrict__ wsum) {
     const int b = blockIdx.y;
     const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
     const long long n = (long long)d * h * w;
@@ -133,23 +135,28 @@ __global__ void __launch_bounds__(256) blend_add_kernel(const float* __restrict_
         if (flip_dim == 3) fy = h - 1 - yy;
         if (flip_dim == 4) fx = w - 1 - xx;
         const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
-        acc[o] += scale * logits[(long long)b * n + ((long long)fz * h + fy) * w + fx];
+        const float wgt = bw ? fmaxf(bw[zz] * bw[d + yy] * bw[d + h + xx], bmin) * scale : scale;
+        acc[o] += wgt * logits[(long long)b * n + ((long long)fz * h + fy) * w + fx];
         if (cnt) cnt[o] += (uint8_t)rep;
+        if (wsum) wsum[o] += wgt;
     }
 }
 
 // background-skipped windows: acc += value (-1000), cnt += 1
 __global__ void __launch_bounds__(256) fill_add_kernel(const int* __restrict__ starts, int d, int h, int w, int Yp,
                                                        int Xp, float value, int rep, float* __restrict__ acc,
-                                                       uint8_t* __restrict__ cnt) {
+                                                       uint8_t* __restrict__ cnt, const float* __restrict__ bw, float bmin,
+                                                       float* __restrict__ wsum) {
     const int b = blockIdx.y;
     const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
     const long long n = (long long)d * h * w;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
         const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
-        if (value != 0.f) acc[o] += value;
+        const float wgt = bw ? fmaxf(bw[zz] * bw[d + yy] * bw[d + h + xx], bmin) : 1.f;
+        if (value != 0.f) acc[o] += value * wgt;
         if (cnt) cnt[o] += (uint8_t)rep;
+        if (wsum && value != 0.f) wsum[o] += wgt * (float)rep;
     }
 }
 
@@ -237,6 +244,48 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     const int nz = p->nz > 0 ? p->nz : p->Zp;
     const int Yp = p->Yp, Xp = p->Xp;
     const int rep = p->repeat > 0 ? p->repeat : 1;
+    // Gaussian importance map (option): MONAI 1.2.0 compute_importance_map(mode="gaussian") [3P-recall] - a delta at
+    // roi//2 filtered by separable truncated (4 sigma) erf-form Gaussians = outer product of three 1-D factors,
+    // divided by its maximum, floored at its smallest non-zero value
+    ctx->blend_w = nullptr;
+    ctx->blend_wsum = nullptr;
+    ctx->blend_min = 0.f;
+    if (p->blend_mode == DLV_BLEND_GAUSSIAN) {
+        if (cnt_dev) return dlv_fail(ctx, DLV_EINVAL, "Gaussian blend: pass wsum_dev (fp32) instead of the uint8 count map");
+        const float ss = p->sigma_scale > 0.f ? p->sigma_scale : 0.125f;
+        std::vector<float> g((size_t)d + h + w);
+        float gmin = 1.f;
+        size_t off = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int len = t.roi[k], center = len / 2;
+            const float sigma = (float)len * ss;
+            const int tail = (int)(std::max(sigma * 4.0f, 0.5f) + 0.5f);
+            const float tt = 0.70710678f / std::fabs(sigma);  // float arithmetic like MONAI's gaussian_1d
+            float mx = 0.f, mn = 0.f;
+            for (int i = 0; i < len; ++i) {
+                const int x = i - center;
+                float v = 0.f;
+                if (x >= -tail && x <= tail) v = std::max(0.f, 0.5f * (std::erf(tt * ((float)x + 0.5f)) - std::erf(tt * ((float)x - 0.5f))));
+                g[off + i] = v;
+                mx = std::max(mx, v);
+            }
+            for (int i = 0; i < len; ++i) {
+                g[off + i] /= mx;
+                if (g[off + i] > 0.f && (mn == 0.f || g[off + i] < mn)) mn = g[off + i];
+            }
+            gmin *= mn;
+            off += len;
+        }
+        float* gw;
+        DLV_TRY(dlv_ws_get(ctx, WS_BLEND_W, g.size() * sizeof(float), (void**)&gw));
+        DLV_HIP(ctx, hipMemcpyAsync(gw, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // g is a local
+        ctx->blend_w = gw;
+        ctx->blend_min = gmin;
+        ctx->blend_wsum = p->wsum_dev;
+    } else if (p->blend_mode != DLV_BLEND_CONSTANT) {
+        return dlv_fail(ctx, DLV_EINVAL, "unknown blend_mode %d", p->blend_mode);
+    }
     if (stats) {
         stats->n_windows = std::max<int64_t>(we - wb, 0);
         stats->n_skipped = 0;
@@ -347,7 +396,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                 rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, p->precision == DLV_PREC_F16 ? 1 : 0);
                 if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
-                                       Xp, 0.0f, rep, acc_dev, cnt_dev);
+                                       Xp, 0.0f, rep, acc_dev, cnt_dev, nullptr, 0.f, nullptr);
                     if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel(count) failed");
                 }
                 lane = (lane + 1) % nlanes;
@@ -361,7 +410,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                 rc = dlv_unet_forward_f32(ctx, tin, tout, B, d, h, w);
                 if (rc != DLV_OK) break;
                 hipLaunchKernelGGL(blend_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, tout, st_dev, d, h, w,
-                                   p->flip_dim, Yp, Xp, (float)rep, rep, acc_dev, cnt_dev);
+                                   p->flip_dim, Yp, Xp, (float)rep, rep, acc_dev, cnt_dev, ctx->blend_w, ctx->blend_min, ctx->blend_wsum);
                 if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of gather/blend kernel failed");
             }
             ++launches;
@@ -372,7 +421,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
             const int* st_dev = list_dev + (s.off + s.n_active) * 3;
             DlvProf pr(ctx, "skip_fill_f32", 0.0, 8.0 * tile_vox * s.n_skipped);
             hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, s.n_skipped), dim3(256), 0, ctx->stream, st_dev, d, h, w,
-                               Yp, Xp, -1000.0f * rep, rep, acc_dev, cnt_dev);
+                               Yp, Xp, -1000.0f * rep, rep, acc_dev, cnt_dev, ctx->blend_w, ctx->blend_min, ctx->blend_wsum);
             pr.end();
             if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel failed");
         }

@@ -787,7 +787,8 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
                                                          const float* __restrict__ wf, const float* __restrict__ bf,
                                                          float* __restrict__ logits, const int* __restrict__ starts,
                                                          int flip_dim, int Yp, int Xp, float scale, float* __restrict__ acc,
-                                                         int D, int H, int W) {
+                                                         int D, int H, int W, const float* __restrict__ bw, float bmin,
+                                                         float* __restrict__ wsum) {
     __shared__ float sc[32], sh[32], ww[32];
     const int n = blockIdx.y;
     if (threadIdx.x < 32) {
@@ -821,7 +822,14 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
             if (flip_dim == 2) zz = D - 1 - zz;
             if (flip_dim == 3) yy = H - 1 - yy;
             if (flip_dim == 4) xx = W - 1 - xx;
-            acc[((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx)] += scale * a;
+            const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
+            if (bw) {  // Gaussian importance map, indexed in volume orientation (after the un-flip)
+                const float wgt = fmaxf(bw[zz] * bw[D + yy] * bw[D + H + xx], bmin) * scale;
+                acc[o] += wgt * a;
+                if (wsum) wsum[o] += wgt;
+            } else {
+                acc[o] += scale * a;
+            }
         }
     }
 }
@@ -1100,10 +1108,11 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
         if (acc)
             hipLaunchKernelGGL((final_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
-                               ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w);
+                               ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w, ctx->blend_w, ctx->blend_min,
+                               ctx->blend_wsum);
         else
             hipLaunchKernelGGL((final_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
-                               ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w);
+                               ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w, nullptr, 0.f, nullptr);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "final_conv_kernel");
     }

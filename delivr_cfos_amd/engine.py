@@ -212,7 +212,8 @@ class HipEngine:
 
     # ---- sliding window ----------------------------------------------------------------------------
     def make_sw_params(self, padded_shape, roi, overlap=0.5, flip_dim=None, skip_threshold=0, precision="fp16",
-                       sw_batch=0, win_range=None, slab=None, repeat=1) -> _lib.SwParams:
+                       sw_batch=0, win_range=None, slab=None, repeat=1, blend="constant", sigma_scale=0.125,
+                       wsum=None) -> _lib.SwParams:
         p = _lib.SwParams()
         p.Zp, p.Yp, p.Xp = (int(v) for v in padded_shape)
         for k in range(3):
@@ -225,6 +226,15 @@ class HipEngine:
         p.win_begin, p.win_end = (0, 0) if win_range is None else (int(win_range[0]), int(win_range[1]))
         p.z0, p.nz = (0, 0) if slab is None else (int(slab[0]), int(slab[1]))
         p.repeat = int(repeat)
+        # "constant" is what the reference does (its mode="gaussian" argument is ignored); "gaussian" = MONAI's
+        # importance map as an option, with `wsum` (fp32 tensor shaped like acc, optional) collecting the weight sums
+        p.blend_mode = {"constant": 0, "gaussian": 1}[blend]
+        p.sigma_scale = float(sigma_scale)
+        if wsum is not None:
+            if blend != "gaussian":
+                raise ValueError("wsum is the float count map of the Gaussian blend")
+            p.wsum_dev = self._dev(wsum, self.torch.float32, "wsum").value
+            p._keep = wsum
         return p
 
     def num_windows(self, params) -> int:
@@ -270,6 +280,10 @@ class HipEngine:
         torch = self.torch
         Z, Y, X = (int(v) for v in stack_shape)
         Yp, Xp = int(acc.shape[-2]), int(acc.shape[-1])
+        if cnt is not None and cnt.dtype == torch.float32:
+            # Gaussian blend: the count map holds weight sums; the mean logit is formed here, the kernel sees no count
+            acc = acc / cnt.clamp_min(torch.finfo(torch.float32).tiny)
+            cnt = None
         out = torch.empty((Z, Y, X), dtype=torch.uint8, device=self.device)
         prob = torch.empty((Z, Y, X), dtype=torch.float32, device=self.device) if want_prob else None
         self._enter()

@@ -106,8 +106,12 @@ def run_inference(
 
         broadcast_weights(eng, dist, rank)  # ONE broadcast instead of DataParallel's per-forward replicate
     model.eval()
+    # settings["mi355x"]["blend"] = "gaussian" makes the mode argument take effect (option; the reference's own call
+    # passes mode="gaussian" too, but its inferer blends with constant weights: SURVEY D2)
+    gaussian = bool(settings and settings.get("mi355x", {}).get("blend", "constant") == "gaussian")
     inferer = SlidingWindowInferer(roi_size=crop_size, sw_batch_size=sw_batch_size, sw_device=eng.device,
-                                   device=eng.device, overlap=overlap, mode="gaussian", padding_mode="replicate")
+                                   device=eng.device, overlap=overlap, mode="gaussian", padding_mode="replicate",
+                                   honour_mode=gaussian)
 
     # ### DATA PREP ###  (reference :225-251)
     print(f"{datetime.datetime.now()} : Loading Data")
@@ -119,7 +123,8 @@ def run_inference(
         os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
     save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
     output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
-    count_map = torch.zeros(pad[2:], dtype=torch.uint8, device=eng.device) if save_activated else None
+    count_map = (torch.zeros(pad[2:], dtype=torch.float32 if gaussian else torch.uint8, device=eng.device)
+                 if save_activated else None)
     print("output_image shape", tuple(output_image.shape))
 
     testing_session_path = os.path.abspath(output_folder + "/" + comment)
@@ -154,8 +159,12 @@ def run_inference(
         for flip_dim, repeat in pass_schedule(bool(tta)):
             wb, we = plan.win_ranges[rank]
             if we > wb:
-                eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
-                                                repeat=repeat), dataset, output_image, count_map)
+                if gaussian:
+                    eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
+                                                    repeat=repeat, blend="gaussian", wsum=count_map), dataset, output_image)
+                else:
+                    eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
+                                                    repeat=repeat), dataset, output_image, count_map)
         eng.sync()
         exchange_seams(output_image, plan, rank, dist)
         if count_map is not None:

@@ -68,10 +68,16 @@ def sliding_window_inference(
     window_data_threshold: int = 0,
     *args: Any,
     repeat: int = 1,
+    honour_mode: bool = False,
     **kwargs: Any,
 ):
     """One sliding-window pass; ``output_image`` / ``count_map`` are mutated in place, returns None
-    (as the reference does).  ``predictor`` must be a HipBasicUNet."""
+    (as the reference does).  ``predictor`` must be a HipBasicUNet.
+
+    ``mode``: the reference accepts "gaussian" but blends with constant weights - the argument never reaches
+    compute_importance_map (:148) - and so does this function unless ``honour_mode=True``, which applies
+    MONAI's Gaussian importance map (``sigma_scale``); ``count_map`` must then be a float32 tensor (it accumulates the
+    weights) or None."""
     import torch
 
     if overlap < 0 or overlap >= 1:
@@ -100,10 +106,20 @@ def sliding_window_inference(
         return view.to(device=eng.device, dtype=dtype).contiguous(), view
 
     acc, acc_home = staged(output_image, torch.float32)
-    cnt, cnt_home = staged(count_map, torch.uint8)
-    p = eng.make_sw_params(vol.shape, roi, overlap, flip_dim, window_data_threshold, predictor.precision,
-                           sw_batch=0, repeat=repeat)
-    stats = eng.sw_infer(p, vol, acc, cnt)
+    gaussian = bool(honour_mode) and str(getattr(mode, "value", mode)) == "gaussian"
+    if gaussian:
+        if count_map is not None and count_map.dtype != torch.float32:
+            raise TypeError("Gaussian blend: count_map accumulates fractional weights and must be float32")
+        cnt, cnt_home = staged(count_map, torch.float32)
+        ss = float(sigma_scale if not isinstance(sigma_scale, (tuple, list)) else sigma_scale[0])
+        p = eng.make_sw_params(vol.shape, roi, overlap, flip_dim, window_data_threshold, predictor.precision,
+                               sw_batch=0, repeat=repeat, blend="gaussian", sigma_scale=ss, wsum=cnt)
+        stats = eng.sw_infer(p, vol, acc, None)
+    else:
+        cnt, cnt_home = staged(count_map, torch.uint8)
+        p = eng.make_sw_params(vol.shape, roi, overlap, flip_dim, window_data_threshold, predictor.precision,
+                               sw_batch=0, repeat=repeat)
+        stats = eng.sw_infer(p, vol, acc, cnt)
     if acc_home is not None:
         acc_home.copy_(acc.to(acc_home.dtype))
     if cnt_home is not None:
@@ -116,7 +132,8 @@ class SlidingWindowInferer:
     """Same constructor and call convention as the reference's class (:278-370)."""
 
     def __init__(self, roi_size, sw_batch_size: int = 1, overlap: float = 0.25, mode: str = "constant",
-                 sigma_scale=0.125, padding_mode: str = "constant", cval: float = 0.0, sw_device=None, device=None):
+                 sigma_scale=0.125, padding_mode: str = "constant", cval: float = 0.0, sw_device=None, device=None,
+                 honour_mode: bool = False):
         if str(getattr(mode, "value", mode)) not in ("constant", "gaussian"):
             raise ValueError(f"unsupported blend mode {mode!r}")
         self.roi_size = roi_size
@@ -128,8 +145,9 @@ class SlidingWindowInferer:
         self.cval = cval
         self.sw_device = sw_device
         self.device = device
+        self.honour_mode = honour_mode  # False = the reference's behaviour: constant weights whatever `mode` says
 
     def __call__(self, inputs, network, *args: Any, **kwargs: Any):
         return sliding_window_inference(inputs, self.roi_size, self.sw_batch_size, network, self.overlap, self.mode,
                                         self.sigma_scale, self.padding_mode, self.cval, self.sw_device, self.device,
-                                        *args, **kwargs)
+                                        *args, honour_mode=self.honour_mode, **kwargs)

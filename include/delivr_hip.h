@@ -120,7 +120,17 @@ typedef struct dlv_sw_params {
     int repeat;          /* this call stands for `repeat` identical passes (>= 1): acc += repeat*logit,
                             cnt += repeat.  The reference's 13-pass TTA schedule (inference.py:265-279)
                             has only 3 distinct passes once its <=1e-3 noise is dropped (5:4:4) */
+    int blend_mode;      /* DLV_BLEND_CONSTANT (0): weights 1 - what the reference does, its mode="gaussian" argument
+                            never reaches compute_importance_map (sliding_window_inferer.py:148).
+                            DLV_BLEND_GAUSSIAN (1): MONAI 1.2.0's Gaussian importance map (sigma = sigma_scale*roi,
+                            truncated at 4 sigma, erf form, normalised to max 1, floored at its smallest non-zero
+                            value): acc += w*logit, wsum += w.  Option; no reference output exists for it. */
+    float sigma_scale;   /* Gaussian mode: 0.125 in the reference's constructor call (inference.py:206); <= 0 -> 0.125 */
+    float* wsum_dev;     /* Gaussian mode: optional fp32 (nz,Yp,Xp) sum of weights (the float count map); cnt_dev must
+                            be NULL in that mode */
 } dlv_sw_params;
+#define DLV_BLEND_CONSTANT 0
+#define DLV_BLEND_GAUSSIAN 1
 
 typedef struct dlv_sw_stats {
     int64_t n_windows;   /* windows in the shard */

@@ -201,6 +201,7 @@ def sliding_window_pass(
     sw_batch_size: int = 1,
     threshold: int = 0,
     fp16: bool = True,
+    importance: Optional[np.ndarray] = None,  # (d,h,w) float weights; count then accumulates them (float array)
 ) -> dict:
     """inference/sliding_window_inferer.py:161-251.  ``fp16=True`` reproduces the reference's
     half-precision accumulate exactly (logits cast to fp16, fp16 += fp16); ``fp16=False`` is the
@@ -225,6 +226,11 @@ def sliding_window_pass(
         if fp16:
             prob = prob.astype(np.float16)
         for (z, y, x), p in zip(batch, prob):
+            if importance is not None:  # :248-251 with a non-constant map (option; the reference always gets ones)
+                out_sum[z : z + d, y : y + h, x : x + w] += (importance * p).astype(out_sum.dtype)
+                if count is not None:
+                    count[z : z + d, y : y + h, x : x + w] += importance.astype(count.dtype)
+                continue
             out_sum[z : z + d, y : y + h, x : x + w] += p.astype(out_sum.dtype)
             if count is not None:
                 count[z : z + d, y : y + h, x : x + w] += 1
@@ -511,3 +517,38 @@ def heatmap(cells: dict, label_shape: Sequence[int], sigma: float = 2.25) -> np.
     h = np.zeros(tuple(label_shape), dtype=np.float64)
     np.add.at(h, (cells["z"], cells["y"], cells["x"]), 1)
     return gaussian_filter(h.astype(int).astype("float32"), sigma=sigma)
+
+
+def gaussian_importance_map(patch_size: Sequence[int], sigma_scale: float = 0.125) -> np.ndarray:
+    """MONAI 1.2.0 ``compute_importance_map(patch_size, mode=BlendMode.GAUSSIAN, sigma_scale)`` [3P-recall]
+    (monai/data/utils.py; called at inference/sliding_window_inferer.py:148-149 - with mode CONSTANT, the Gaussian
+    the caller asks for at inference/inference.py:206 never arrives: SURVEY D2).  A one at ``[i // 2]`` filtered by
+    ``GaussianFilter(3, sigma_scale * size)`` (separable, zero padding, ``gaussian_1d(approx="erf", truncated=4)``),
+    divided by its maximum, floored at its smallest non-zero entry; float32.  Restated with torch's conv so that the
+    arithmetic is the library's own."""
+    import torch
+    import torch.nn.functional as F
+
+    def gaussian_1d(sigma: float) -> "torch.Tensor":
+        sig = torch.as_tensor(sigma, dtype=torch.float)
+        tail = int(max(float(sig) * 4.0, 0.5) + 0.5)
+        x = torch.arange(-tail, tail + 1, dtype=torch.float)
+        t = 0.70710678 / torch.abs(sig)
+        out = 0.5 * ((t * (x + 0.5)).erf() - (t * (x - 0.5)).erf())
+        return out.clamp(min=0)
+
+    m = torch.zeros(tuple(int(v) for v in patch_size))
+    m[tuple(int(v) // 2 for v in patch_size)] = 1
+    x = m[None, None]
+    for d, size in enumerate(patch_size):
+        k = gaussian_1d(float(size) * sigma_scale)
+        shape = [1, 1, 1, 1, 1]
+        shape[2 + d] = -1
+        pad = [0, 0, 0]
+        pad[d] = (len(k) - 1) // 2
+        x = F.conv3d(x, k.reshape(shape), padding=pad)
+    m = x[0, 0]
+    m = m / torch.max(m)
+    m = m.float()
+    mn = m[m != 0].min().item()
+    return torch.clamp(m, min=mn).numpy()

@@ -311,3 +311,52 @@ def test_heatmap_bit_exact_vs_reference_and_scipy(eng, golden_dir):
     for sigma in (2.25, 0.8):
         got = create_heatmap(c2, shape, engine=eng, sigma=sigma)
         np.testing.assert_array_equal(got.view(np.uint32), orc.heatmap(c2, shape, sigma).view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Gaussian importance-weighted blend (option; the reference always blends with constant weights)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,flip", [("fp32", None), ("fp32", 3), ("fp16", None), ("fp16", 2)])
+def test_sw_pass_gaussian_blend_vs_oracle(eng_w, net, golden_dir, precision, flip):
+    """acc += w*logit, wsum += w with MONAI's Gaussian importance map (oracle: the map built with torch's own conv, the
+    reference loop with that map): weighted sums within 1e-3 (fp32 path) / 2 % of the logit scale (fp16 path), weight
+    sums within 1e-5 where they matter, skipped windows contribute -1000*w; a uint8 count map is refused in this mode."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    vol = _g(golden_dir, "ref_blend.npz")["volume"]
+    roi = (32, 32, 16)
+    imp = orc.gaussian_importance_map(roi, 0.125)
+    acc_ref = np.zeros(vol.shape, dtype=np.float32)
+    ws_ref = np.zeros(vol.shape, dtype=np.float32)
+    info = orc.sliding_window_pass(vol, roi, lambda x: orc.unet_forward(net, x), acc_ref, ws_ref, 0.5, flip, sw_batch_size=1,
+                                   fp16=False, importance=imp)
+    v = eng_w.to_device(vol)
+    acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    p = eng_w.make_sw_params(vol.shape, roi, 0.5, flip, 0, precision, sw_batch=3, blend="gaussian", sigma_scale=0.125, wsum=ws)
+    st = eng_w.sw_infer(p, v, acc)
+    eng_w.sync()
+    assert st["n_skipped"] == info["n_skipped"] > 0
+    # the far tails (1e-10) come from 0.5*(erf(a) - erf(b)) in float32: a few 1e-4 relative between libm and torch there
+    np.testing.assert_allclose(ws.cpu().numpy(), ws_ref, rtol=1e-3, atol=1e-9)
+    core = ws_ref > 0.05
+    np.testing.assert_allclose(ws.cpu().numpy()[core], ws_ref[core], rtol=1e-5)
+    a = acc.cpu().numpy()
+    live = acc_ref > -100
+    if precision == "fp32":
+        assert np.abs(a - acc_ref)[live].max() < 1e-3
+        np.testing.assert_allclose(a[~live], acc_ref[~live], rtol=1e-5)
+    else:
+        rel = float(np.sqrt(np.mean((a - acc_ref)[live] ** 2)) / acc_ref[live].std())
+        assert rel < 2e-2, rel
+    # the mean logit differs from the constant-weight blend (the weighting is not a no-op) ...
+    acc_c = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+    cnt_c = torch.zeros(vol.shape, dtype=torch.uint8, device="cuda")
+    eng_w.sw_infer(eng_w.make_sw_params(vol.shape, roi, 0.5, flip, 0, precision, sw_batch=3), v, acc_c, cnt_c)
+    mean_c = (acc_c / cnt_c.clamp(min=1)).cpu().numpy()
+    mean_g = (acc / ws.clamp(min=1e-30)).cpu().numpy()
+    assert np.abs(mean_c - mean_g)[live].max() > 1e-3
+    # ... and the uint8 count map cannot hold fractional weights
+    with pytest.raises(RuntimeError):
+        eng_w.sw_infer(p, v, acc, cnt_c)

@@ -457,3 +457,45 @@ def test_count_blobs_sharded_path_gathers_the_single_volume_result():
     np.testing.assert_array_equal(labels0, single)
     for k in ("voxel_counts", "bounding_boxes", "centroids"):
         np.testing.assert_array_equal(stats0[k], st1[k])
+
+
+def test_run_inference_with_gaussian_blend_option(tmp_path):
+    """settings["mi355x"]["blend"] = "gaussian": the step mirror blends with MONAI's importance map (option) - mask and
+    network_output.npy against the oracle's pass with the same map (fp32 path)."""
+    import torch
+    from delivr_cfos_amd.inference.inference import run_inference
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    sd = random_state_dict(5)
+    wfile = str(tmp_path / "weights.tar")
+    torch.save({"state_dict": sd}, wfile)
+    crop = (32, 32, 32)
+    vol = synth_volume_np((40, 50, 66), seed=4, dense=True)
+    vol[:, :, :8] = 0
+    mask_dir = tmp_path / "01" / "b" / "masked_niftis"
+    os.makedirs(mask_dir)
+    pad = _write_padded_npy(str(mask_dir / "masked_nifti.npy"), vol, crop)
+    settings = {"blob_detection": {"window_dimensions": {"window_dim_0": 32, "window_dim_1": 32, "window_dim_2": 32}},
+                "mi355x": {"precision": "fp32", "blend": "gaussian"}, "FLAGS": {"SAVE_ACTIVATED_OUTPUT": True}}
+    out = run_inference(niftis=[str(mask_dir / "masked_nifti.npy")], output_folder=str(tmp_path / "02") + "/",
+                        stack_shape=(1, 1, *vol.shape), model_weights=wfile, tta=False, comment="b", load_all_ram=True,
+                        settings=settings)
+    binaries = np.load(os.path.join(str(out), "binary_segmentations", "binaries.npy"))
+    prob = np.load(os.path.join(str(out), "binary_segmentations", "network_output.npy"))
+    net = orc.build_unet(seed=None)
+    net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+    padded = np.zeros(pad, dtype=np.uint16)
+    padded[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+    acc = np.zeros(pad, dtype=np.float32)
+    ws = np.zeros(pad, dtype=np.float32)
+    orc.sliding_window_pass(padded, crop, lambda x: orc.unet_forward(net, x), acc, ws, 0.5, None, 1, fp16=False,
+                            importance=orc.gaussian_importance_map(crop, 0.125))
+    mean = acc / np.maximum(ws, np.finfo(np.float32).tiny)
+    ref = orc.finalize(mean, None, padded, vol.shape, 0.5, 30)
+    Z, Y, X = vol.shape
+    margin = np.abs(mean[:Z, :Y, :X]) < 1e-3
+    assert np.array_equal(binaries[~margin], ref[~margin])
+    want = 1.0 / (1.0 + np.exp(-mean[:Z, :Y, :X].astype(np.float64)))
+    assert np.abs(prob - want).max() < 1e-3
