@@ -327,7 +327,7 @@ def main():
         extras["voxels"] = vox
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only (bench contract)
         try:
             threads = os.cpu_count() or 1
             # crop: the central region (tissue), cpu_windows windows stacked along z with 50 % overlap
