@@ -290,12 +290,23 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
     // planes per staging chunk: at least one per thread, about 256 MB
     const int by_size = (int)std::max<size_t>(1, ((size_t)256 << 20) / (plane_elems * 2));
     const int chunk = std::max(1, std::min(n_planes, std::max(n_threads, by_size)));
-    uint16_t* stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2];
+    // staging buffers and events are released on every exit path
+    struct Staging {
+        uint16_t* buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Staging() {
+            for (int b = 0; b < 2; ++b) {
+                if (ev[b]) (void)hipEventDestroy(ev[b]);
+                if (buf[b]) (void)hipHostFree(buf[b]);
+            }
+        }
+    } stg;
     for (int b = 0; b < 2; ++b) {
-        DLV_HIP(ctx, hipHostMalloc((void**)&stage[b], (size_t)chunk * plane_elems * 2, hipHostMallocDefault));
-        DLV_HIP(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        DLV_HIP(ctx, hipHostMalloc((void**)&stg.buf[b], (size_t)chunk * plane_elems * 2, hipHostMallocDefault));
+        DLV_HIP(ctx, hipEventCreateWithFlags(&stg.ev[b], hipEventDisableTiming));
     }
+    uint16_t** stage = stg.buf;
+    hipEvent_t* done = stg.ev;
     std::string err;
     std::atomic<bool> failed{false};
     int rc = DLV_OK;
@@ -348,11 +359,7 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
         }
         (void)hipEventRecord(done[b], ctx->stream);
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int b = 0; b < 2; ++b) {
-        (void)hipEventDestroy(done[b]);
-        (void)hipHostFree(stage[b]);
-    }
+    (void)hipStreamSynchronize(ctx->stream);  // before the staging buffers go away
     if (failed) rc = dlv_fail(ctx, DLV_EUNSUP, "%s", err.c_str());
     return rc;
 }

@@ -941,11 +941,11 @@ struct Net16 {
         DlvProf pr(ctx, name, flops, bytes);
 #define DLV_CONV_LAUNCH(NCB_, TX_, WLDS_)                                                                                \
     do {                                                                                                                 \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) {                                                                                                \
+        static unsigned long long attr_done = 0; /* bit per device */                                                              \
+        if (!((attr_done >> (ctx->device & 63)) & 1ull)) {                                                                                                \
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<P, NCB_, TX_, WLDS_>,                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_done = true;                                                                                            \
+            attr_done |= 1ull << (ctx->device & 63);                                                                                            \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_mfma_kernel<P, NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
                            c2 / 8, reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, out, partials, L.cout, d.D, d.H,    \
