@@ -106,6 +106,7 @@ SIGNATURES = {
     "dlv_tiff_last_error": (C.c_char_p, []),
     "dlv_tiff_plane_size": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dlv_tiff_read_plane_u16": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "dlv_tiff_write_plane": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dlv_tiff_stack_to_device": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, _P, C.c_longlong,
                                             C.c_longlong, C.c_int]),
     "dlv_debug_stamps": (C.c_int, [_P, _P]),

@@ -9,7 +9,7 @@ out: <output_location>/<brain>_rgb_tiffs/<brain>rgb_C0{0,1,2}_z####.tif     uint
 
 The per-cell loop (bounding box x colour, later boxes overwrite earlier ones) is one scatter + one gather on the GPU
 (csrc/paint.hip); the box arithmetic, including pad_bb's in-place mutation of the statistics between the two loops, is
-hostlogic.padded_boxes.  Planes are written as uncompressed baseline TIFF (tiffio.py) instead of LZW.
+hostlogic.padded_boxes.  Planes are written as LZW-compressed TIFF like the reference's (native writer, tiffio.py).
 """
 from __future__ import annotations
 

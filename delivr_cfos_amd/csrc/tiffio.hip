@@ -217,6 +217,74 @@ const char* decode_plane(const uint8_t* data, size_t n, const TiffInfo& t, uint1
     return nullptr;
 }
 
+// TIFF 6.0 LZW encoder (the counterpart of lzw_decode; same conventions as libtiff's writer: every strip starts with
+// ClearCode, the code width grows when the entry that fills the current width has been added - "early change" - the
+// table is reset with a ClearCode when entry 4093 has been added, EndOfInformation closes the strip).
+void lzw_encode(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
+    constexpr int HSIZE = 16384;  // open addressing, keys (prefix << 8 | byte) + 1
+    static thread_local std::vector<uint32_t> keys;
+    static thread_local std::vector<uint16_t> vals;
+    keys.assign(HSIZE, 0);
+    vals.resize(HSIZE);
+    uint64_t acc = 0;
+    int nbits = 0, width = 9, next = 258;
+    auto put = [&](int code) {
+        acc = (acc << width) | (uint32_t)code;
+        nbits += width;
+        while (nbits >= 8) {
+            out.push_back((uint8_t)(acc >> (nbits - 8)));
+            nbits -= 8;
+        }
+    };
+    put(256);
+    if (n == 0) {
+        put(257);
+        if (nbits) out.push_back((uint8_t)(acc << (8 - nbits)));
+        return;
+    }
+    int prefix = src[0];
+    for (size_t i = 1; i < n; ++i) {
+        const uint8_t c = src[i];
+        const uint32_t key = ((uint32_t)prefix << 8 | c) + 1;
+        uint32_t hsh = (key * 2654435761u) >> 18;  // 14 bits
+        int found = -1;
+        while (keys[hsh]) {
+            if (keys[hsh] == key) {
+                found = vals[hsh];
+                break;
+            }
+            hsh = (hsh + 1) & (HSIZE - 1);
+        }
+        if (found >= 0) {
+            prefix = found;
+            continue;
+        }
+        put(prefix);
+        keys[hsh] = key;
+        vals[hsh] = (uint16_t)next;
+        ++next;
+        if (next == 4094) {  // table full: ClearCode at the current (12-bit) width, start over
+            put(256);
+            keys.assign(HSIZE, 0);
+            width = 9;
+            next = 258;
+        } else if (next > (1 << width) - 1) {
+            ++width;
+        }
+        prefix = c;
+    }
+    put(prefix);
+    ++next;
+    if (next == 4094) {
+        put(256);
+        width = 9;
+    } else if (next > (1 << width) - 1) {
+        ++width;
+    }
+    put(257);
+    if (nbits) out.push_back((uint8_t)(acc << (8 - nbits)));
+}
+
 bool read_file(const char* path, std::vector<uint8_t>& buf) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
@@ -274,6 +342,86 @@ int dlv_tiff_read_plane_u16(const char* path, uint16_t* out_host, int height, in
         g_tiff_error = std::string(path) + ": " + e;
         return DLV_EUNSUP;
     }
+    return DLV_OK;
+}
+
+// one 8/16-bit single-channel plane -> little-endian classic TIFF, strips of ~64 KB, compression 1 (none) or 5 (LZW,
+// no predictor) - what tifffile.imwrite(..., compression='lzw') produces for the reference's plane files
+int dlv_tiff_write_plane(const char* path, const void* data_host, int height, int width, int bits, int compression) {
+    if (!path || !data_host) return DLV_EINVAL;
+    if (height <= 0 || width <= 0 || (bits != 8 && bits != 16) || (compression != 1 && compression != 5)) {
+        g_tiff_error = "dlv_tiff_write_plane: 8/16-bit planes, compression 1 or 5";
+        return DLV_EINVAL;
+    }
+    const size_t row_bytes = (size_t)width * (bits / 8);
+    const uint32_t rps = (uint32_t)std::min<size_t>((size_t)height, std::max<size_t>(1, ((size_t)64 << 10) / row_bytes));
+    const uint32_t nstrips = ((uint32_t)height + rps - 1) / rps;
+    std::vector<uint8_t> file(8);
+    std::vector<uint32_t> offs(nstrips), lens(nstrips);
+    const uint8_t* src = (const uint8_t*)data_host;  // host is little-endian, like the file
+    std::vector<uint8_t> enc;
+    for (uint32_t st = 0; st < nstrips; ++st) {
+        const uint32_t r0 = st * rps, rows = std::min(rps, (uint32_t)height - r0);
+        const uint8_t* p = src + (size_t)r0 * row_bytes;
+        const size_t nb = (size_t)rows * row_bytes;
+        offs[st] = (uint32_t)file.size();
+        if (compression == 5) {
+            enc.clear();
+            lzw_encode(p, nb, enc);
+            file.insert(file.end(), enc.begin(), enc.end());
+            lens[st] = (uint32_t)enc.size();
+        } else {
+            file.insert(file.end(), p, p + nb);
+            lens[st] = (uint32_t)nb;
+        }
+        if (file.size() & 1) file.push_back(0);
+        if (file.size() > 0xfff00000ull) {
+            g_tiff_error = "plane too large for classic TIFF";
+            return DLV_EUNSUP;
+        }
+    }
+    auto put16 = [&](uint16_t v) { file.push_back((uint8_t)v); file.push_back((uint8_t)(v >> 8)); };
+    auto put32 = [&](uint32_t v) { put16((uint16_t)v); put16((uint16_t)(v >> 16)); };
+    uint32_t off_tab = 0, len_tab = 0;
+    if (nstrips > 1) {
+        off_tab = (uint32_t)file.size();
+        for (uint32_t v : offs) put32(v);
+        len_tab = (uint32_t)file.size();
+        for (uint32_t v : lens) put32(v);
+    }
+    const uint32_t ifd = (uint32_t)file.size();
+    struct Tag { uint16_t tag, type; uint32_t count, value; };
+    const Tag tags[] = {{256, 4, 1, (uint32_t)width}, {257, 4, 1, (uint32_t)height}, {258, 3, 1, (uint32_t)bits},
+                        {259, 3, 1, (uint32_t)compression}, {262, 3, 1, 1}, {273, 4, nstrips, nstrips > 1 ? off_tab : offs[0]},
+                        {277, 3, 1, 1}, {278, 4, 1, rps}, {279, 4, nstrips, nstrips > 1 ? len_tab : lens[0]}, {339, 3, 1, 1}};
+    put16((uint16_t)(sizeof(tags) / sizeof(tags[0])));
+    for (const Tag& t : tags) {
+        put16(t.tag);
+        put16(t.type);
+        put32(t.count);
+        if (t.type == 3 && t.count == 1) {
+            put16((uint16_t)t.value);
+            put16(0);
+        } else {
+            put32(t.value);
+        }
+    }
+    put32(0);
+    file[0] = 'I';
+    file[1] = 'I';
+    file[2] = 42;
+    file[3] = 0;
+    file[4] = (uint8_t)ifd;
+    file[5] = (uint8_t)(ifd >> 8);
+    file[6] = (uint8_t)(ifd >> 16);
+    file[7] = (uint8_t)(ifd >> 24);
+    FILE* f = fopen(path, "wb");
+    if (!f || fwrite(file.data(), 1, file.size(), f) != file.size()) {
+        if (f) fclose(f);
+        g_tiff_error = std::string("cannot write ") + path;
+        return DLV_EINVAL;
+    }
+    fclose(f);
     return DLV_OK;
 }
 

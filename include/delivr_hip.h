@@ -211,6 +211,10 @@ int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y,
 const char* dlv_tiff_last_error(void);
 int dlv_tiff_plane_size(const char* path, int* height, int* width, int* bits);
 int dlv_tiff_read_plane_u16(const char* path, uint16_t* out_host, int height, int width);
+/* egress: one (height,width) plane of 8- or 16-bit samples (host, native little-endian) as a classic TIFF with
+ * ~64 KB strips, compression 1 (none) or 5 (LZW) - the plane files of blob_highlighter.py:131-133, :160 and
+ * cells_to_atlas.py:320 (tifffile.imwrite(..., compression='lzw')).  Host-only. */
+int dlv_tiff_write_plane(const char* path, const void* data_host, int height, int width, int bits, int compression);
 int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_planes, int height, int width, uint16_t* vol_dev,
                              long long plane_stride, long long row_stride, int n_threads);
 
