@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -64,3 +65,26 @@ def test_bad_geometry_is_an_error_code():
     p.roi[0] = 32
     p.overlap = 1.0
     assert lib.dlv_sw_num_windows(C.byref(p), C.byref(n)) == _lib.DLV_EINVAL
+
+
+def test_plain_c_host_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    """examples/c_host.c drives the path through include/delivr_hip.h from C99 (no Python, no torch): the header is
+    valid C, every entry point it uses links against libdelivr_hip.so, and without a GPU the program says so and exits
+    non-zero (on the GPU box it runs the pass: see INTEGRATION.md)."""
+    import shutil
+    import subprocess
+
+    import torch
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    lib_dir = os.path.join(ROOT, "delivr_cfos_amd", "lib")
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-o", exe, "-L" + lib_dir, "-ldelivr_hip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-lm"])
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "delivr_hip.h")])
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "needs an MI355X" in r.stderr
