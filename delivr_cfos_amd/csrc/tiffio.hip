@@ -90,6 +90,7 @@ const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
         }
     }
     if (!t.width || !t.height) return "image size missing";
+    if (t.width > (1u << 20) || t.height > (1u << 20) || (uint64_t)t.width * t.height > (1ull << 34)) return "implausible image size";
     if (t.samples != 1) return "only single-channel planes are supported";
     if (t.bits != 8 && t.bits != 16) return "only 8- and 16-bit samples are supported";
     if (t.sample_format != 1) return "only unsigned integer samples are supported";
@@ -310,119 +311,146 @@ extern "C" {
 const char* dlv_tiff_last_error(void) { return g_tiff_error.c_str(); }
 
 int dlv_tiff_plane_size(const char* path, int* height, int* width, int* bits) {
-    if (!path) return DLV_EINVAL;
-    std::vector<uint8_t> buf;
-    if (!read_file(path, buf)) {
-        g_tiff_error = std::string("cannot read ") + path;
-        return DLV_EINVAL;
-    }
-    TiffInfo t;
-    if (const char* e = parse_ifd(buf.data(), buf.size(), t)) {
-        g_tiff_error = std::string(path) + ": " + e;
+    try {
+        if (!path) return DLV_EINVAL;
+        std::vector<uint8_t> buf;
+        if (!read_file(path, buf)) {
+            g_tiff_error = std::string("cannot read ") + path;
+            return DLV_EINVAL;
+        }
+        TiffInfo t;
+        if (const char* e = parse_ifd(buf.data(), buf.size(), t)) {
+            g_tiff_error = std::string(path) + ": " + e;
+            return DLV_EUNSUP;
+        }
+        if (height) *height = (int)t.height;
+        if (width) *width = (int)t.width;
+        if (bits) *bits = (int)t.bits;
+        return DLV_OK;
+    
+    } catch (const std::exception& e) {  // nothing throws across the C ABI
+        g_tiff_error = std::string("dlv_tiff_plane_size: ") + e.what();
+        return DLV_EUNSUP;
+    } catch (...) {
+        g_tiff_error = "dlv_tiff_plane_size: unknown exception";
         return DLV_EUNSUP;
     }
-    if (height) *height = (int)t.height;
-    if (width) *width = (int)t.width;
-    if (bits) *bits = (int)t.bits;
-    return DLV_OK;
 }
 
 int dlv_tiff_read_plane_u16(const char* path, uint16_t* out_host, int height, int width) {
-    if (!path || !out_host) return DLV_EINVAL;
-    std::vector<uint8_t> buf, scratch;
-    if (!read_file(path, buf)) {
-        g_tiff_error = std::string("cannot read ") + path;
-        return DLV_EINVAL;
-    }
-    TiffInfo t;
-    const char* e = parse_ifd(buf.data(), buf.size(), t);
-    if (!e && ((int)t.height != height || (int)t.width != width)) e = "plane size differs from the expected one";
-    if (!e) e = decode_plane(buf.data(), buf.size(), t, out_host, scratch);
-    if (e) {
-        g_tiff_error = std::string(path) + ": " + e;
+    try {
+        if (!path || !out_host) return DLV_EINVAL;
+        std::vector<uint8_t> buf, scratch;
+        if (!read_file(path, buf)) {
+            g_tiff_error = std::string("cannot read ") + path;
+            return DLV_EINVAL;
+        }
+        TiffInfo t;
+        const char* e = parse_ifd(buf.data(), buf.size(), t);
+        if (!e && ((int)t.height != height || (int)t.width != width)) e = "plane size differs from the expected one";
+        if (!e) e = decode_plane(buf.data(), buf.size(), t, out_host, scratch);
+        if (e) {
+            g_tiff_error = std::string(path) + ": " + e;
+            return DLV_EUNSUP;
+        }
+        return DLV_OK;
+    
+    } catch (const std::exception& e) {  // nothing throws across the C ABI
+        g_tiff_error = std::string("dlv_tiff_read_plane_u16: ") + e.what();
+        return DLV_EUNSUP;
+    } catch (...) {
+        g_tiff_error = "dlv_tiff_read_plane_u16: unknown exception";
         return DLV_EUNSUP;
     }
-    return DLV_OK;
 }
 
 // one 8/16-bit single-channel plane -> little-endian classic TIFF, strips of ~64 KB, compression 1 (none) or 5 (LZW,
 // no predictor) - what tifffile.imwrite(..., compression='lzw') produces for the reference's plane files
 int dlv_tiff_write_plane(const char* path, const void* data_host, int height, int width, int bits, int compression) {
-    if (!path || !data_host) return DLV_EINVAL;
-    if (height <= 0 || width <= 0 || (bits != 8 && bits != 16) || (compression != 1 && compression != 5)) {
-        g_tiff_error = "dlv_tiff_write_plane: 8/16-bit planes, compression 1 or 5";
-        return DLV_EINVAL;
-    }
-    const size_t row_bytes = (size_t)width * (bits / 8);
-    const uint32_t rps = (uint32_t)std::min<size_t>((size_t)height, std::max<size_t>(1, ((size_t)64 << 10) / row_bytes));
-    const uint32_t nstrips = ((uint32_t)height + rps - 1) / rps;
-    std::vector<uint8_t> file(8);
-    std::vector<uint32_t> offs(nstrips), lens(nstrips);
-    const uint8_t* src = (const uint8_t*)data_host;  // host is little-endian, like the file
-    std::vector<uint8_t> enc;
-    for (uint32_t st = 0; st < nstrips; ++st) {
-        const uint32_t r0 = st * rps, rows = std::min(rps, (uint32_t)height - r0);
-        const uint8_t* p = src + (size_t)r0 * row_bytes;
-        const size_t nb = (size_t)rows * row_bytes;
-        offs[st] = (uint32_t)file.size();
-        if (compression == 5) {
-            enc.clear();
-            lzw_encode(p, nb, enc);
-            file.insert(file.end(), enc.begin(), enc.end());
-            lens[st] = (uint32_t)enc.size();
-        } else {
-            file.insert(file.end(), p, p + nb);
-            lens[st] = (uint32_t)nb;
+    try {
+        if (!path || !data_host) return DLV_EINVAL;
+        if (height <= 0 || width <= 0 || (bits != 8 && bits != 16) || (compression != 1 && compression != 5)) {
+            g_tiff_error = "dlv_tiff_write_plane: 8/16-bit planes, compression 1 or 5";
+            return DLV_EINVAL;
         }
-        if (file.size() & 1) file.push_back(0);
-        if (file.size() > 0xfff00000ull) {
-            g_tiff_error = "plane too large for classic TIFF";
-            return DLV_EUNSUP;
+        const size_t row_bytes = (size_t)width * (bits / 8);
+        const uint32_t rps = (uint32_t)std::min<size_t>((size_t)height, std::max<size_t>(1, ((size_t)64 << 10) / row_bytes));
+        const uint32_t nstrips = ((uint32_t)height + rps - 1) / rps;
+        std::vector<uint8_t> file(8);
+        std::vector<uint32_t> offs(nstrips), lens(nstrips);
+        const uint8_t* src = (const uint8_t*)data_host;  // host is little-endian, like the file
+        std::vector<uint8_t> enc;
+        for (uint32_t st = 0; st < nstrips; ++st) {
+            const uint32_t r0 = st * rps, rows = std::min(rps, (uint32_t)height - r0);
+            const uint8_t* p = src + (size_t)r0 * row_bytes;
+            const size_t nb = (size_t)rows * row_bytes;
+            offs[st] = (uint32_t)file.size();
+            if (compression == 5) {
+                enc.clear();
+                lzw_encode(p, nb, enc);
+                file.insert(file.end(), enc.begin(), enc.end());
+                lens[st] = (uint32_t)enc.size();
+            } else {
+                file.insert(file.end(), p, p + nb);
+                lens[st] = (uint32_t)nb;
+            }
+            if (file.size() & 1) file.push_back(0);
+            if (file.size() > 0xfff00000ull) {
+                g_tiff_error = "plane too large for classic TIFF";
+                return DLV_EUNSUP;
+            }
         }
-    }
-    auto put16 = [&](uint16_t v) { file.push_back((uint8_t)v); file.push_back((uint8_t)(v >> 8)); };
-    auto put32 = [&](uint32_t v) { put16((uint16_t)v); put16((uint16_t)(v >> 16)); };
-    uint32_t off_tab = 0, len_tab = 0;
-    if (nstrips > 1) {
-        off_tab = (uint32_t)file.size();
-        for (uint32_t v : offs) put32(v);
-        len_tab = (uint32_t)file.size();
-        for (uint32_t v : lens) put32(v);
-    }
-    const uint32_t ifd = (uint32_t)file.size();
-    struct Tag { uint16_t tag, type; uint32_t count, value; };
-    const Tag tags[] = {{256, 4, 1, (uint32_t)width}, {257, 4, 1, (uint32_t)height}, {258, 3, 1, (uint32_t)bits},
-                        {259, 3, 1, (uint32_t)compression}, {262, 3, 1, 1}, {273, 4, nstrips, nstrips > 1 ? off_tab : offs[0]},
-                        {277, 3, 1, 1}, {278, 4, 1, rps}, {279, 4, nstrips, nstrips > 1 ? len_tab : lens[0]}, {339, 3, 1, 1}};
-    put16((uint16_t)(sizeof(tags) / sizeof(tags[0])));
-    for (const Tag& t : tags) {
-        put16(t.tag);
-        put16(t.type);
-        put32(t.count);
-        if (t.type == 3 && t.count == 1) {
-            put16((uint16_t)t.value);
-            put16(0);
-        } else {
-            put32(t.value);
+        auto put16 = [&](uint16_t v) { file.push_back((uint8_t)v); file.push_back((uint8_t)(v >> 8)); };
+        auto put32 = [&](uint32_t v) { put16((uint16_t)v); put16((uint16_t)(v >> 16)); };
+        uint32_t off_tab = 0, len_tab = 0;
+        if (nstrips > 1) {
+            off_tab = (uint32_t)file.size();
+            for (uint32_t v : offs) put32(v);
+            len_tab = (uint32_t)file.size();
+            for (uint32_t v : lens) put32(v);
         }
+        const uint32_t ifd = (uint32_t)file.size();
+        struct Tag { uint16_t tag, type; uint32_t count, value; };
+        const Tag tags[] = {{256, 4, 1, (uint32_t)width}, {257, 4, 1, (uint32_t)height}, {258, 3, 1, (uint32_t)bits},
+                            {259, 3, 1, (uint32_t)compression}, {262, 3, 1, 1}, {273, 4, nstrips, nstrips > 1 ? off_tab : offs[0]},
+                            {277, 3, 1, 1}, {278, 4, 1, rps}, {279, 4, nstrips, nstrips > 1 ? len_tab : lens[0]}, {339, 3, 1, 1}};
+        put16((uint16_t)(sizeof(tags) / sizeof(tags[0])));
+        for (const Tag& t : tags) {
+            put16(t.tag);
+            put16(t.type);
+            put32(t.count);
+            if (t.type == 3 && t.count == 1) {
+                put16((uint16_t)t.value);
+                put16(0);
+            } else {
+                put32(t.value);
+            }
+        }
+        put32(0);
+        file[0] = 'I';
+        file[1] = 'I';
+        file[2] = 42;
+        file[3] = 0;
+        file[4] = (uint8_t)ifd;
+        file[5] = (uint8_t)(ifd >> 8);
+        file[6] = (uint8_t)(ifd >> 16);
+        file[7] = (uint8_t)(ifd >> 24);
+        FILE* f = fopen(path, "wb");
+        if (!f || fwrite(file.data(), 1, file.size(), f) != file.size()) {
+            if (f) fclose(f);
+            g_tiff_error = std::string("cannot write ") + path;
+            return DLV_EINVAL;
+        }
+        fclose(f);
+        return DLV_OK;
+    
+    } catch (const std::exception& e) {  // nothing throws across the C ABI
+        g_tiff_error = std::string("dlv_tiff_write_plane: ") + e.what();
+        return DLV_EUNSUP;
+    } catch (...) {
+        g_tiff_error = "dlv_tiff_write_plane: unknown exception";
+        return DLV_EUNSUP;
     }
-    put32(0);
-    file[0] = 'I';
-    file[1] = 'I';
-    file[2] = 42;
-    file[3] = 0;
-    file[4] = (uint8_t)ifd;
-    file[5] = (uint8_t)(ifd >> 8);
-    file[6] = (uint8_t)(ifd >> 16);
-    file[7] = (uint8_t)(ifd >> 24);
-    FILE* f = fopen(path, "wb");
-    if (!f || fwrite(file.data(), 1, file.size(), f) != file.size()) {
-        if (f) fclose(f);
-        g_tiff_error = std::string("cannot write ") + path;
-        return DLV_EINVAL;
-    }
-    fclose(f);
-    return DLV_OK;
 }
 
 // planes paths[0..n_planes) -> vol_dev[(z0 + i) * plane_stride + y * row_stride + x], decoded by n_threads host threads

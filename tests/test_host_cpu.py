@@ -410,3 +410,36 @@ def test_native_tiff_writer_roundtrip_and_libtiff_readback(tmp_path, golden_dir)
     big = str(tmp_path / "big.tif")
     write_tiff_plane(big, planes["runs8"])
     assert os.path.getsize(big) < planes["runs8"].nbytes // 4     # it does compress
+
+
+def test_native_tiff_reader_survives_corrupt_files(tmp_path, golden_dir):
+    """Random byte corruption and truncation of the fixtures: the reader either decodes or refuses with an exception -
+    no crash, no exception across the C ABI; a header that claims a 900000 x 900000 plane is refused."""
+    import struct
+    from delivr_cfos_amd.downsample.downsample_and_mask import read_tiff_plane
+
+    rng = np.random.default_rng(0)
+    p = str(tmp_path / "f.tif")
+    for name in ("tiff_lzw16.tif", "tiff_lzw16_strips.tif", "tiff_lzw8.tif", "tiff_be16.tif", "tiff_lzw16_pred.tif"):
+        data = bytearray(open(os.path.join(golden_dir, name), "rb").read())
+        for it in range(60):
+            d = bytearray(data)
+            for _ in range(int(rng.integers(1, 8))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+            if it % 5 == 0:
+                d = d[: int(rng.integers(8, len(d)))]
+            open(p, "wb").write(d)
+            try:
+                read_tiff_plane(p)
+            except (NotImplementedError, FileNotFoundError, OSError, MemoryError):
+                pass
+    tags = [(256, 4, 1, 900000), (257, 4, 1, 900000), (258, 3, 1, 16), (259, 3, 1, 5), (262, 3, 1, 1), (273, 4, 1, 8),
+            (277, 3, 1, 1), (278, 4, 1, 900000), (279, 4, 1, 4)]
+    with open(p, "wb") as fh:
+        fh.write(b"II" + struct.pack("<HI", 42, 12) + b"\\x80\\x00\\x00\\x00")
+        fh.write(struct.pack("<H", len(tags)))
+        for tag, typ, cnt, val in tags:
+            fh.write(struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val)))
+        fh.write(struct.pack("<I", 0))
+    with pytest.raises(NotImplementedError):
+        read_tiff_plane(p)
