@@ -160,3 +160,84 @@ def test_mask_iou_vs_fp32_path_256cube():
     assert i16 >= 0.999, i16
     assert ib >= 0.995, ib
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the headline size: (1024, 2048, 2048) = 2^32 voxels, 14 415 windows of 128^3 (BASELINE configs 3/4)
+# ---------------------------------------------------------------------------------------------------
+C3 = (1024, 2048, 2048)
+
+
+def test_c3_size_pass_properties():
+    """One default-format pass over the 2^32-voxel volume: 14 415 windows, a third of them background-skipped; the
+    uint8 count map equals the analytic coverage (1/2/4/8, separable: 15 x 31 x 31 windows); voxels covered only by
+    skipped windows hold exactly -1000 x coverage; everything is finite.  Voxel indices exceed 2^31 here."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    try:
+        eng.load_state_dict({"state_dict": random_state_dict(0)})
+        vol = synth_volume_torch(C3, 2, eng.device)
+        p = eng.make_sw_params(C3, ROI, 0.5, None, 0, "fp16")
+        assert eng.num_windows(p) == 15 * 31 * 31
+        acc = torch.zeros(C3, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(C3, dtype=torch.uint8, device="cuda")
+        st = eng.sw_infer(p, vol, acc, cnt)
+        eng.sync()
+        assert st["n_windows"] == 14415 and 0.2 < st["n_skipped"] / 14415 < 0.6
+        covs = []
+        for n in C3:
+            c = np.ones(n, dtype=np.int64)
+            c[64: n - 64] = 2
+            covs.append(torch.from_numpy(c).cuda())
+        for z0 in range(0, C3[0], 128):   # compare slab by slab (the full product would need another 4 GB)
+            expect = (covs[0][z0:z0 + 128, None, None] * covs[1][None, :, None] * covs[2][None, None, :]).to(torch.uint8)
+            assert torch.equal(cnt[z0:z0 + 128], expect)
+        assert bool(torch.isfinite(acc[::7]).all())
+        # the corner block is outside the ellipsoid brain: only skipped windows cover it
+        corner = acc[:64, :64, :64]
+        assert torch.equal(corner, torch.full_like(corner, -1000.0))
+        far = acc[-64:, -64:, -64:]      # linear indices just below 2^32
+        assert torch.equal(far, torch.full_like(far, -1000.0))
+    finally:
+        eng.close()
+
+
+def test_c3_size_ccl_and_stats_at_the_index_limits():
+    """CCL-26 + statistics on a 2^32-voxel mask with components placed where 32-bit index arithmetic would break: at
+    linear index 0, across index 2^31, at the last voxel (2^32 - 1), a diagonal 26-connected chain, and a plane-spanning
+    bar.  Labels are numbered in raster order of the first voxel; counts, boxes and centroids are exact."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+
+    Z, Y, X = C3
+    eng = HipEngine(0)
+    try:
+        m = torch.zeros(C3, dtype=torch.uint8, device="cuda")
+        m[0, 0, 0:3] = 1                                   # 1: starts at linear index 0
+        for k in range(5):
+            m[10 + k, 20 + k, 30 + k] = 1                  # 2: diagonal chain (26-connectivity only)
+        m[511:513, 2047, 2040:2048] = 1                    # 3: crosses linear index 2^31 (z 511 -> 512)
+        m[700, 100:1900, 77] = 1                           # 4: a long bar
+        m[1023, 2047, 2045:2048] = 1                       # 5: ends at the last voxel, index 2^32 - 1
+        m[1023, 2040, 2047] = 1                            # 6: isolated voxel in the last plane ... comes before 5 in raster order
+        labels, n = eng.ccl26(m)
+        assert n == 6
+        lab = labels.view(torch.int32)
+        assert int(lab[0, 0, 1]) == 1 and int(lab[12, 22, 32]) == 2 and int(lab[512, 2047, 2047]) == 3
+        assert int(lab[700, 1000, 77]) == 4
+        assert int(lab[1023, 2040, 2047]) == 5 and int(lab[1023, 2047, 2047]) == 6
+        assert int((lab != 0).sum()) == 3 + 5 + 16 + 1800 + 1 + 3
+        st = eng.cc_stats(labels, n)
+        np.testing.assert_array_equal(st["voxel_counts"][1:], [3, 5, 16, 1800, 1, 3])
+        np.testing.assert_array_equal(st["bounding_boxes"][3], [511, 512, 2047, 2047, 2040, 2047])
+        np.testing.assert_array_equal(st["bounding_boxes"][6], [1023, 1023, 2047, 2047, 2045, 2047])
+        np.testing.assert_allclose(st["centroids"][3], [511.5, 2047.0, 2043.5], rtol=0, atol=0)
+        np.testing.assert_allclose(st["centroids"][4], [700.0, 999.5, 77.0], rtol=0, atol=0)
+        np.testing.assert_allclose(st["centroids"][6], [1023.0, 2047.0, 2046.0], rtol=0, atol=0)
+        assert int(st["voxel_counts"][0]) == (Z * Y * X - 1828) % (1 << 32)   # the background count wraps in uint32 like cc3d's
+    finally:
+        eng.close()
