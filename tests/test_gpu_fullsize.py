@@ -241,3 +241,36 @@ def test_c3_size_ccl_and_stats_at_the_index_limits():
         assert int(st["voxel_counts"][0]) == (Z * Y * X - 1828) % (1 << 32)   # the background count wraps in uint32 like cc3d's
     finally:
         eng.close()
+
+
+def test_c3_size_finalize_blocks_equal_per_block_evaluation():
+    """create_nifti_seg at the headline size: the reference erodes inside Arrayterator z-blocks of floor(1e9/(Y*X)) = 238
+    planes (inference/inference.py:53); finalize(zblock=238) over 1024 planes must equal finalize(zblock=0) applied to
+    each 238-plane block on its own (5 blocks, the last one short), and differ from a whole-volume erosion at the
+    block seams."""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.hostlogic import arrayterator_zblock
+    from delivr_cfos_amd.synth import synth_volume_torch
+
+    Z, Y, X = C3
+    nb = arrayterator_zblock(C3)
+    assert nb == 238
+    eng = HipEngine(0)
+    try:
+        raw = synth_volume_torch(C3, 2, eng.device)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        acc = torch.empty(C3, dtype=torch.float32, device="cuda")
+        for z0 in range(0, Z, 128):
+            acc[z0:z0 + 128] = torch.randn((min(128, Z - z0), Y, X), generator=g, device="cuda") + 0.5
+        whole = eng.finalize(acc, None, raw, C3, 0.5, 30, nb)
+        for z0 in range(0, Z, nb):
+            z1 = min(z0 + nb, Z)
+            part = eng.finalize(acc[z0:z1].contiguous(), None, raw[z0:z1].contiguous(), (z1 - z0, Y, X), 0.5, 30, 0)
+            assert torch.equal(whole[z0:z1], part), (z0, z1)
+        noblock = eng.finalize(acc, None, raw, C3, 0.5, 30, 0)
+        assert not torch.equal(noblock, whole)            # the block seams matter (border_value=1 inside each block)
+        assert torch.equal(noblock[40:190], whole[40:190])  # but only within 30 planes of a seam
+        assert 0.05 < float(whole.float().mean()) < 0.6
+    finally:
+        eng.close()
