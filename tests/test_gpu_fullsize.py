@@ -274,3 +274,40 @@ def test_c3_size_finalize_blocks_equal_per_block_evaluation():
         assert 0.05 < float(whole.float().mean()) < 0.6
     finally:
         eng.close()
+
+
+def test_c5_shape_resamplers_at_the_headline_size():
+    """BASELINE config 5: raw (1024,2048,2048) -> block mean (4,15,15) with the reference's dropped last z-chunk ->
+    (255,137,137) -> threshold mask -> spline-2 zoom back to 2^32 voxels -> raw * mask into the padded
+    network input.  Exact integer spot checks, partial-block zero padding, align-corners corners, padding region zero."""
+    import torch
+    from delivr_cfos_amd.downsample.downsample_and_mask import downsample_volume, mask_and_pad, upsample_mask
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.hostlogic import padded_shape
+    from delivr_cfos_amd.synth import synth_volume_torch
+
+    Z, Y, X = C3
+    eng = HipEngine(0)
+    try:
+        raw = synth_volume_torch(C3, 2, eng.device)
+        ds = downsample_volume(eng, raw, (4, 15, 15))
+        assert tuple(ds.shape) == (255, 137, 137)
+        blk = raw[400:408, 900:930, 1200:1230].to(torch.int64).reshape(2, 4, 2, 15, 2, 15).sum(dim=(1, 3, 5)) // 900
+        assert torch.equal(ds[100:102, 60:62, 80:82].to(torch.int64), blk)
+        # last in-plane block is partial (2048 = 136*15 + 8): zero padded, still divided by the full block size
+        edge = raw[0:4, 2040:2048, 2040:2048].to(torch.int64).sum() // 900
+        assert int(ds[0, 136, 136]) == int(edge)
+        small = (ds.to(torch.int32) > 300).to(torch.uint8)
+        up = upsample_mask(eng, small, C3)
+        assert tuple(up.shape) == C3 and set(torch.unique(up[::16, ::16, ::16]).tolist()) <= {0, 1}
+        assert int(up[0, 0, 0]) == int(small[0, 0, 0]) and int(up[-1, -1, -1]) == int(small[-1, -1, -1])
+        assert int(up[512, 1024, 1024]) == 1 and int(up[0, 0, 0]) == 0      # brain centre in, box corner out
+        crop = (96, 96, 64)                                                  # the reference's default window
+        padded = mask_and_pad(eng, raw, up, crop)
+        Zp, Yp, Xp = padded_shape(C3, crop)
+        assert tuple(padded.shape) == (Zp, Yp, Xp) and padded.dtype == torch.uint16
+        sl = padded[500:520, :Y, :X].to(torch.int32)
+        assert torch.equal(sl, raw[500:520].to(torch.int32) * up[500:520].to(torch.int32))
+        assert int(padded[Z:].to(torch.int32).abs().sum()) == 0 and int(padded[:, Y:].to(torch.int32).abs().sum()) == 0
+    finally:
+        eng.close()
