@@ -47,7 +47,6 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
                                                            int H, int W, int tilesY, int tilesX, int zseg,
                                                            unsigned long long* __restrict__ stamps, int nseg, int cout8) {
     using C = ZmCfg<CIN, TYT>;
-    constexpr bool LATE = false;
     constexpr int NT = 64 * TYT / VB;            // threads: TYT rows / VB rows per wave
     constexpr int NPRE = (C::PELEMS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -915,7 +914,6 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
     if (cout % 32 || cout <= 0) return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cout must be a multiple of 32");
     const int ncb = cout / 32;
     const int variant = ctx->zm_variant;  // DLV_ZM_VARIANT at context creation, or dlv_debug_set_zm_variant
-    // 16-row tiles (8 waves x 2 rows) for the single-source layers unless a variant asks otherwise
     // 16-row tiles (8 waves x 2 rows) only as A/B variant 3: measured equal/slower than 8 rows x 1 (profiles/README.md)
     const int tyt = (cin == 32 && variant == 3) ? 16 : 8;
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, ZM_TX);
