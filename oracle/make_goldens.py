@@ -261,6 +261,24 @@ def golden_unet():
           "frac>=0", (out["logits32"] >= 0).mean())
 
 
+def golden_unet_c1():
+    """BASELINE config 1 / SURVEY 8(d) C1: one 64^3 patch x = randn(1,1,64,64,64, seed 0)*100 + 500 through the
+    seeded random-weight oracle U-Net (torch fp32 CPU).  The full logits are 1 MB; the fixture keeps every 4th voxel
+    per axis (16^3 samples) plus the global mean/std, enough to pin the oracle across machines and to check the HIP
+    path at this shape without re-running the oracle."""
+    import torch
+
+    net = orc.build_unet(seed=0)
+    orc.randomize_affine(net, seed=1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 1, 64, 64, 64), generator=g) * 100.0 + 500.0
+    lg = orc.unet_forward(net, x.numpy())[0, 0]
+    np.savez_compressed(os.path.join(GOLD, "orc_unet_c1.npz"), logits_s4=lg[::4, ::4, ::4].copy(),
+                        mean=np.array(float(lg.astype(np.float64).mean())), std=np.array(float(lg.astype(np.float64).std())),
+                        frac_pos=np.array(float((lg >= 0).mean())), x_checksum=np.array(float(x.double().sum())))
+    print("orc_unet_c1.npz mean/std", lg.mean(), lg.std(), "frac>=0", (lg >= 0).mean())
+
+
 def golden_resample():
     rng = np.random.default_rng(11)
     vol = rng.integers(0, 65535, size=(9, 31, 47)).astype(np.uint16)
@@ -280,6 +298,7 @@ def main():
     golden_finalize(inf)
     golden_ccl_and_csv()
     golden_unet()
+    golden_unet_c1()
     golden_resample()
     golden_swc()
 
@@ -518,7 +537,9 @@ def golden_tiff():
         assert (np.array(im) == {"tiff_lzw8.tif": b, "tiff_be16.tif": c}.get(f, a)).all()
 
 
-if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "tiff":
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "unet_c1":
+    golden_unet_c1()
+elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "tiff":
     golden_tiff()
 elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "atlas":
     golden_atlas()

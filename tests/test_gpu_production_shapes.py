@@ -1,0 +1,208 @@
+"""The 16-bit production path against the ORACLE (torch-fp32 CPU restatement of MONAI's BasicUNet, oracle/delivr_oracle.py)
+at the tile shapes production uses: one 64^3 patch (BASELINE config 1), one 96x96x64 window (the reference's default,
+config.json:24-28), 128^3 windows (BASELINE configs 2-5), a batch-16 launch of the fused sliding-window path, and the
+mask after blend + finalize on a 256^3 crop with 27 windows.  Batch-16 launches, z-segment splitting of the z-march conv,
+the LDS-weights variant of the 8^3 level and the pipeline lanes only occur at these sizes.
+
+Tolerances (north_star: "mask IoU >= 0.999 vs reference"):
+    fp32 VALU path   max |logit - oracle| <= 5e-4 (logit std ~0.4), sign agreement >= 0.9995
+    fp16 MFMA path   relative RMS <= 1e-2, sign agreement >= 0.999, mask IoU vs the ORACLE's mask >= 0.999
+    bf16 MFMA path   relative RMS <= 5e-2, sign agreement >= 0.99; mask IoU is REPORTED and asserted >= 0.995 only:
+                     bf16 (8 significant bits) does NOT meet the north_star tolerance on the margin-free logits of the
+                     seeded random weights - fp16 is the default format for that reason.
+The oracle needs ~1.7 s per 128^3 window on the GPU box's host cores, so the module computes the 27 windows of the crop once.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROI = (128, 128, 128)
+CROP = (256, 256, 256)
+
+
+@pytest.fixture(scope="module")
+def net():
+    import torch
+    from oracle import delivr_oracle as orc
+
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    n = orc.build_unet(seed=0)
+    orc.randomize_affine(n, seed=1)
+    return n
+
+
+@pytest.fixture(scope="module")
+def eng(net):
+    from delivr_cfos_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    e.load_state_dict({"state_dict": net.state_dict()})
+    yield e
+    e.close()
+
+
+def _stats(out, ref):
+    rel = float(np.sqrt(np.mean((out - ref) ** 2)) / ref.std())
+    agree = float(((out >= 0) == (ref >= 0)).mean())
+    return rel, agree, float(np.abs(out - ref).max())
+
+
+TOL = {"fp32": (1e-3, 0.9995), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.99)}
+
+
+def _check(tag, prec, out, ref):
+    rel, agree, mx = _stats(out, ref)
+    print(f"{tag} [{prec}]: rel rms {rel:.2e}  sign agreement {agree:.5f}  max abs {mx:.2e}  (ref std {ref.std():.3f})")
+    assert np.isfinite(out).all()
+    assert rel < TOL[prec][0], (tag, prec, rel)
+    assert agree >= TOL[prec][1], (tag, prec, agree)
+    if prec == "fp32":
+        assert mx < 5e-4, (tag, mx)
+
+
+@pytest.fixture(scope="module")
+def crop(net):
+    """256^3 synthetic brain crop, its 27 windows of 128^3 at 50 % overlap through the oracle (per-window logits kept),
+    the oracle's blended sum and its mask after create_nifti_seg."""
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    vol = synth_volume_np(CROP, seed=21)
+    wins = orc.window_list(CROP, ROI, 0.5)
+    assert len(wins) == 27
+    logits = {}
+
+    def predictor(x):
+        out = orc.unet_forward(net, x)
+        logits[len(logits)] = out[0, 0].copy()
+        return out
+
+    acc = np.zeros(CROP, dtype=np.float32)
+    cnt = np.zeros(CROP, dtype=np.uint8)
+    info = orc.sliding_window_pass(vol, ROI, predictor, acc, cnt, 0.5, None, 1, fp16=False)
+    assert info["n_skipped"] == 0 and len(logits) == 27
+    mask = orc.finalize(acc, cnt, vol, CROP, 0.5, 30)
+    return {"vol": vol, "wins": np.asarray(wins), "logits": logits, "acc": acc, "cnt": cnt, "mask": mask}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_c1_single_64cube_patch_vs_oracle(eng, net, prec):
+    """BASELINE config 1 / SURVEY 8(d) C1: x = randn(1,1,64,64,64, seed 0)*100 + 500."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 1, 64, 64, 64), generator=g) * 100.0 + 500.0
+    ref = orc.unet_forward(net, x.numpy())[0, 0]
+    out = eng.unet_forward(x.cuda(), prec).cpu().numpy()[0, 0]
+    _check("C1 64^3", prec, out, ref)
+    # the committed samples of the same logits (made in the build container: tests/golden/orc_unet_c1.npz)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "orc_unet_c1.npz"))
+    np.testing.assert_allclose(ref[::4, ::4, ::4], g["logits_s4"], atol=2e-5, rtol=0)
+    if prec == "fp32":
+        assert np.abs(out[::4, ::4, ::4] - g["logits_s4"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_default_window_96_96_64_vs_oracle(eng, net, prec):
+    """The reference's default window (config.json:24-28: 96,96,64) as one fused sliding-window launch."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    roi = (96, 96, 64)
+    vol = synth_volume_np(roi, seed=5, dense=True)
+    ref = orc.unet_forward(net, vol.astype(np.float32)[None, None])[0, 0]
+    acc = torch.zeros(roi, dtype=torch.float32, device="cuda")
+    st = eng.sw_infer(eng.make_sw_params(roi, roi, 0.5, None, 0, prec), eng.to_device(vol), acc)
+    eng.sync()
+    assert st["n_windows"] == 1 and st["n_skipped"] == 0
+    _check("96x96x64", prec, acc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_window_128cube_forward_vs_oracle(eng, crop, prec):
+    """dlv_unet_forward_dev on the centre window of the crop (fp32 patch input) vs the oracle's logits of that window."""
+    import torch
+
+    i = 13
+    z, y, x = crop["wins"][i]
+    patch = crop["vol"][z : z + 128, y : y + 128, x : x + 128].astype(np.float32)
+    out = eng.unet_forward(torch.from_numpy(patch)[None, None].cuda(), prec).cpu().numpy()[0, 0]
+    _check("128^3 window", prec, out, crop["logits"][i])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_batch16_fused_pass_vs_oracle(eng, crop, prec):
+    """16 windows of 128^3 in ONE forward launch of the fused path (stem reads the uint16 volume, final layer blends):
+    16 of the crop's windows are laid out side by side in a (256,256,512) volume and run with overlap 0 (one colour
+    class, sw_batch 16), so that the accumulator holds exactly the per-window logits the oracle already computed."""
+    import torch
+
+    ids = [0, 2, 4, 6, 8, 10, 12, 13, 14, 16, 18, 20, 22, 24, 25, 26]
+    big = np.zeros((256, 256, 512), dtype=np.uint16)
+    ref = np.zeros(big.shape, dtype=np.float32)
+    k = 0
+    for bz in range(2):
+        for by in range(2):
+            for bx in range(4):
+                z, y, x = crop["wins"][ids[k]]
+                sl = np.s_[bz * 128 : bz * 128 + 128, by * 128 : by * 128 + 128, bx * 128 : bx * 128 + 128]
+                big[sl] = crop["vol"][z : z + 128, y : y + 128, x : x + 128]
+                ref[sl] = crop["logits"][ids[k]]
+                k += 1
+    acc = torch.zeros(big.shape, dtype=torch.float32, device="cuda")
+    st = eng.sw_infer(eng.make_sw_params(big.shape, ROI, 0.0, None, 0, prec, sw_batch=16), eng.to_device(big), acc)
+    eng.sync()
+    assert st["n_windows"] == 16 and st["n_skipped"] == 0
+    if prec != "fp32":
+        assert st["n_forward_launches"] == 1  # one batch of 16
+    out = acc.cpu().numpy()
+    _check("batch 16 x 128^3", prec, out, ref)
+    # every window individually (a wrong window would hide in the global RMS)
+    for bz in range(2):
+        for by in range(2):
+            for bx in range(4):
+                sl = np.s_[bz * 128 : bz * 128 + 128, by * 128 : by * 128 + 128, bx * 128 : bx * 128 + 128]
+                rel, agree, _ = _stats(out[sl], ref[sl])
+                assert rel < TOL[prec][0] * 1.5 and agree >= TOL[prec][1] - 0.002, (prec, bz, by, bx, rel, agree)
+
+
+def _iou(a, b):
+    a = a.astype(bool)
+    b = b.astype(bool)
+    return float((a & b).sum()) / max(float((a | b).sum()), 1.0)
+
+
+def test_mask_iou_vs_oracle_256cube(eng, crop):
+    """north_star tolerance, against the ORACLE (not the build's own fp32 path): blend of 27 windows + count map +
+    create_nifti_seg (sigmoid >= 0.5, L1-30 eroded re-mask) -> mask IoU.  Also at threshold 0.3, which needs the mean
+    (sum / count), not just the sign of the sum (reference inference.py:295)."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    v = eng.to_device(crop["vol"])
+    ious = {}
+    for prec in ("fp32", "fp16", "bf16"):
+        acc = torch.zeros(CROP, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(CROP, dtype=torch.uint8, device="cuda")
+        st = eng.sw_infer(eng.make_sw_params(CROP, ROI, 0.5, None, 0, prec), v, acc, cnt)
+        eng.sync()
+        assert st["n_windows"] == 27 and st["n_skipped"] == 0
+        assert np.array_equal(cnt.cpu().numpy(), crop["cnt"])
+        _check("blended sum 256^3", prec, acc.cpu().numpy(), crop["acc"])
+        mask = eng.finalize(acc, cnt, v, CROP, 0.5, 30, 0).cpu().numpy()
+        ious[prec] = _iou(mask, crop["mask"])
+        fg = float(crop["mask"].mean())
+        print(f"mask IoU vs ORACLE mask [{prec}]: {ious[prec]:.5f} (foreground fraction {fg:.3f})")
+        if prec == "fp16":
+            m03 = eng.finalize(acc, cnt, v, CROP, 0.3, 30, 0).cpu().numpy()
+            ref03 = orc.finalize(crop["acc"], crop["cnt"], crop["vol"], CROP, 0.3, 30)
+            assert _iou(m03, ref03) >= 0.999
+            assert abs(float(ref03.mean()) - fg) > 1e-3  # the other threshold really selects another mask
+    assert ious["fp32"] >= 0.9995, ious
+    assert ious["fp16"] >= 0.999, ious
+    assert ious["bf16"] >= 0.995, ious  # reported; bf16 does not meet 0.999 (module docstring)

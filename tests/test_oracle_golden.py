@@ -183,3 +183,19 @@ def test_atlas_transform_and_heatmap_match_reference(golden_dir):
             np.testing.assert_array_equal(got[k], want[k])
     np.testing.assert_array_equal(region_ids(want, label), g["region_id"])
     np.testing.assert_array_equal(orc.heatmap(want, label.shape), g["heatmap"])
+
+
+def test_unet_c1_64cube_reproduces_the_committed_samples(golden_dir):
+    """BASELINE config 1 (one 64^3 patch, seeded input and weights): the oracle on this machine reproduces the samples
+    committed from the build container (torch CPU kernels differ in summation order between thread counts: 2e-5)."""
+    import torch
+
+    g = _load(golden_dir, "orc_unet_c1.npz")
+    net = orc.build_unet(seed=0)
+    orc.randomize_affine(net, seed=1)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 1, 64, 64, 64), generator=gen) * 100.0 + 500.0
+    assert abs(float(x.double().sum()) - float(g["x_checksum"])) < 1e-3
+    lg = orc.unet_forward(net, x.numpy())[0, 0]
+    np.testing.assert_allclose(lg[::4, ::4, ::4], g["logits_s4"], atol=2e-5, rtol=0)
+    assert abs(float(lg.astype(np.float64).std()) - float(g["std"])) < 1e-5
