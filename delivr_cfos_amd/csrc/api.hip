@@ -136,7 +136,11 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         // the stem (i == 0) keeps a 4-k-step hi/lo A-fragment pack for the MFMA stem (4 KiB)
         uint16_t* wb = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
         uint16_t* wh = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
+        uint16_t* wb16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
+        uint16_t* wh16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         if (base) {
+            ctx->conv[i].w16_bf16 = wb16;
+            ctx->conv[i].w16_f16 = wh16;
             ctx->conv[i].w_f16 = wh;
             ctx->conv[i].cin = cin[i];
             ctx->conv[i].cout = cout[i];

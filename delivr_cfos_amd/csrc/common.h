@@ -34,6 +34,8 @@ struct DlvConvLayer {
     float* beta = nullptr;      // (Cout)
     uint16_t* w_bf16 = nullptr; // MFMA A-operand fragment order (see unet_bf16.hip)
     uint16_t* w_f16 = nullptr;  // same order, IEEE half
+    uint16_t* w16_bf16 = nullptr;  // v_mfma_f32_16x16x32 A-fragment order (conv_zreg.hip): 16-channel output blocks
+    uint16_t* w16_f16 = nullptr;
 };
 struct DlvDeconvLayer {
     int cin = 0, cout = 0;
@@ -152,6 +154,12 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx);
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
                             const void* wpk, const float* bias, void* out, float* partials, int B, int D, int H, int W,
                             int* nparts);
+// register-resident-weights z-march conv (conv_zreg.hip): Cout blocks of 32, Cin = 32, 32+32 or 64; ss1 / ss2 =
+// InstanceNorm scale/shift of the layer that produced in1 / in2 (applied with Mish while staging) or nullptr
+int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,
+                          int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
+                          int* nparts);
+int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

@@ -903,6 +903,20 @@ struct Net16 {
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
         // z-march: weights of one 32-channel output block resident in LDS (54 / 108 KB), so Cin <= 64; Cout = 64 runs as
         // two blocks over the same input (the 32^3 level: 226 -> ~135 us per conv against the generic kernel)
+        static const int zreg_mask = getenv("DLV_ZREG_MASK") ? atoi(getenv("DLV_ZREG_MASK")) : 3;  // development: 1 = Cin 32, 2 = Cin 64
+        if (ctx->zm_variant == 50 && (L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch &&
+            (c2 == 0 || (c1 == 32 && c2 == 32)) && ((L.cin == 32 ? 1 : 2) & zreg_mask)) {
+            char zname[48];
+            snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
+            int np = 0;
+            if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
+                return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zreg)");
+            DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, nullptr, in2, c2, nullptr,
+                                          P::IS_F16 ? L.w16_f16 : L.w16_bf16, out, partials, B, d.D, d.H, d.W, &np));
+            zp.end();
+            return stats(np, li, d);
+        }
         if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
@@ -1129,6 +1143,7 @@ int pack_weights_16(dlv_ctx* ctx) {
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: %d->%d not multiples of 32", i, L.cin, L.cout);
         hipLaunchKernelGGL(pack_conv_w_kernel<P>, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->conv[i]), L.cout, L.cin);
         DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
+        DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cout, L.cin));
     }
     for (int j = 0; j < DLV_N_DECONV; ++j) {
         const DlvDeconvLayer& L = ctx->deconv[j];
@@ -1143,7 +1158,7 @@ template <class P>
 int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev, int c2,
                    float* out_dev, int B, int D, int H, int W) {
     const long long vox = (long long)D * H * W;
-    if (kind == 0) {
+    if (kind == 0 || kind == 2 || kind == 3) {  // 2: raw conv output (no InstanceNorm / Mish), 3: the layer's scale/shift pairs: kernel debugging
         if (index < 1 || index >= DLV_N_CONV) return dlv_fail(ctx, DLV_EINVAL, "conv index must be 1..17");
         const DlvConvLayer& L = ctx->conv[index];
         if (c1 + c2 != L.cin || c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EINVAL, "bad channel split");
@@ -1161,7 +1176,11 @@ int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int 
         hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
         if (c2) hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c2 / 8, B), dim3(256), 0, ctx->stream, in2_dev, i2, c2, vox);
         DLV_TRY(net.conv(index, i1, c1, c2 ? i2 : nullptr, c2, o, Dims{D, H, W}));
-        DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr));
+        if (kind == 0) DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr));
+        if (kind == 3) {
+            DLV_HIP(ctx, hipMemcpyAsync(out_dev, net.ss, (size_t)B * L.cout * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+            return DLV_OK;
+        }
         hipLaunchKernelGGL(cp_to_f32_kernel<P>, dim3(g, L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev, L.cout, vox);
         DLV_LAUNCH_CHECK(ctx, "debug conv");
         return DLV_OK;

@@ -191,7 +191,7 @@ class HipEngine:
         torch = self.torch
         B, c1, D, H, W = in1.shape
         c2 = 0 if in2 is None else int(in2.shape[1])
-        if kind == 0:
+        if kind in (0, 2, 3):
             cout = {i: None for i in range(18)}
             blk_out = [self.features[0], self.features[0], self.features[1], self.features[1], self.features[2],
                        self.features[2], self.features[3], self.features[3], self.features[4], self.features[4],

@@ -266,7 +266,7 @@ def test_sw_pass_fp16_matches_fp32_engine(eng, golden_dir):
 # ---------------------------------------------------------------------------------------------------
 # opt-in builds of the z-march conv (dlv_debug_set_zm_variant): same torch reference, same tolerance
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [6, 20, 24, 40])
+@pytest.mark.parametrize("variant", [6, 20, 24, 40, 50])
 @pytest.mark.parametrize("li,c1,c2,prec", [(1, 32, 0, "fp16"), (16, 32, 32, "fp16"), (1, 32, 0, "bf16"), (16, 32, 32, "bf16")])
 def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     """Streaming-store (6), double-buffered half-plane (20), LDS-DMA (24) and software-pipelined (40) builds of the
