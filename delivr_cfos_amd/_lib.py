@@ -10,6 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdelivr_hip.so")
+# development: A/B of two builds of the library on one device (profiles/): DLV_LIB names the file under lib/
+if os.environ.get("DLV_LIB"):
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), os.environ["DLV_LIB"])
 
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2

@@ -39,6 +39,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;  // native vector: usable with inline-asm register constraints
 
 constexpr int ZR_HX = 34;
+#ifndef ZR_RA8
+#define ZR_RA8 2
+#endif
+// wait states in front of every asm MFMA: a compiler-generated VALU write of an MFMA operand (register copy, spill
+// reload) right before the asm would otherwise be read stale - hipcc pads nothing for an asm statement
+#ifndef ZR_NOP
+#define ZR_NOP "s_nop 1"
+#endif
 
 template <int CIN, int TYT>
 struct ZrCfg {
@@ -52,7 +60,7 @@ struct ZrCfg {
     static constexpr int NIT = (PL + 63) / 64;        // 64-lane pieces of one chunk plane
     static constexpr int BUF = NCH * CS;              // uint4 per plane buffer
     static constexpr int RW = TYT / 2;                // output rows per wave
-    static constexpr int RA = CIN == 32 ? (RW <= 4 ? RW : 5) : 1;  // of which accumulate in AGPRs (the rest in VGPRs):
+    static constexpr int RA = CIN == 32 ? (RW <= 4 ? ZR_RA8 : 5) : 1;  // of which accumulate in AGPRs (the rest in VGPRs):
                                                       // Cin 32: 108 weights + 120 = 228 AGPR; Cin 64: 216 + 24 = 240 AGPR
     static constexpr int NG = (RW + 2) * KS;          // MFMA groups per step: (input row, k-step)
     static constexpr int NPIECE = SPW * NIT;          // staged pieces per step (<= NG: one per group)
@@ -78,23 +86,24 @@ __device__ __forceinline__ float zr_row_sum16(float v) {
 }
 
 // acc (+)= W (AGPR) x B (VGPR); FIRST: acc = W x B (zero C operand, starts a new output plane)
-template <class P, bool AGPR_ACC, bool FIRST>
+template <class P, bool AGPR_ACC, bool FIRST, bool PAD>
 __device__ __forceinline__ void zr_mfma(f32x4& acc, const u32x4& w, const u32x4& b) {
+    if constexpr (PAD) asm volatile(ZR_NOP);  // (adjacent volatile asm statements keep their order)
     if constexpr (P::IS_F16) {
         if constexpr (AGPR_ACC) {
-            if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
+            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
         } else {
-            if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
         }
     } else {
         if constexpr (AGPR_ACC) {
-            if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
+            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
         } else {
-            if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
-            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
         }
     }
 }
@@ -288,10 +297,14 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             uint2 u;
             u.x = P::pack2(v[0], v[1]);
             u.y = P::pack2(v[2], v[3]);
-            unsigned o = ok ? ooff + (unsigned)b * 256u : toff;
-            asm volatile("" : "+v"(o));
-            char* const base = uok ? obase + ((long long)oz * plane + (long long)r * W) * 16 : trash;
-            *reinterpret_cast<uint2*>(base + o) = u;
+            if constexpr (INT) {
+                unsigned o = ooff + (unsigned)b * 256u;
+                asm volatile("" : "+v"(o));
+                *reinterpret_cast<uint2*>(obase + ((long long)oz * plane + (long long)r * W) * 16 + o) = u;
+            } else {  // per-lane address: the real voxel or this lane's slot of the trash line
+                char* const real = obase + ((long long)oz * plane + (long long)r * W) * 16 + ooff + (unsigned)b * 256u;
+                *reinterpret_cast<uint2*>(ok ? real : trash + toff) = u;
+            }
         }
     };
     constexpr int EPI_OPS = 18;  // per row: 2 blocks x 9
@@ -373,11 +386,11 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
                             const int set = kz == 0 ? SC : (kz == 1 ? SB : SA);
                             const bool first = (kz == 0 && ky == 0 && ks == 0 && kx == 0);
                             if (r < RA) {
-                                if (first) zr_mfma<P, true, true>(acca[set][r < RA ? r : 0][b], w, bf);
-                                else zr_mfma<P, true, false>(acca[set][r < RA ? r : 0][b], w, bf);
+                                if (first) zr_mfma<P, true, true, !INT>(acca[set][r < RA ? r : 0][b], w, bf);
+                                else zr_mfma<P, true, false, !INT>(acca[set][r < RA ? r : 0][b], w, bf);
                             } else {
-                                if (first) zr_mfma<P, false, true>(accv[set][r >= RA ? r - RA : 0][b], w, bf);
-                                else zr_mfma<P, false, false>(accv[set][r >= RA ? r - RA : 0][b], w, bf);
+                                if (first) zr_mfma<P, false, true, !INT>(accv[set][r >= RA ? r - RA : 0][b], w, bf);
+                                else zr_mfma<P, false, false, !INT>(accv[set][r >= RA ? r - RA : 0][b], w, bf);
                             }
                             // the side ops that belong behind MFMA m of this group
                             const int m = ((vr * 3 + kx) * 2 + b) * 3 + kz;
@@ -419,15 +432,35 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     using T = std::true_type;
     using F = std::false_type;
     const int pmax = min(ze, D - 1);  // last plane that is fetched
-    for (int p = zs - 1; p <= ze + 1; p += 3) {
-        if (full_tile && p - 2 >= zs && p + 4 <= pmax && p + 1 < ze) {
-            step(T{}, p + 0, IC<0>{}, IC<1>{}, IC<2>{});
-            step(T{}, p + 1, IC<1>{}, IC<2>{}, IC<0>{});
-            step(T{}, p + 2, IC<2>{}, IC<0>{}, IC<1>{});
-        } else {
+    auto int_ok = [&](int p) { return full_tile && p - 2 >= zs && p + 4 <= pmax && p + 1 < ze; };
+    // every accumulator is (re)defined at this point: whatever register copies the allocator needs at a control-flow join
+    // (loop entry / back edge) land in front of it, and the wait states behind it cover them - inside the interior loop
+    // the asm MFMAs carry no padding
+    auto pin_accs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int r = 0; r < RA; ++r) asm volatile("" : "+a"(acca[st][r][b]));
+#pragma unroll
+                for (int r = 0; r < RV; ++r) asm volatile("" : "+v"(accv[st][r][b]));
+            }
+        asm volatile("s_nop 3");
+    };
+    int p = zs - 1;
+    for (;;) {  // at most two rounds: edge steps, interior steps, edge steps
+        for (; p <= ze + 1 && !int_ok(p); p += 3) {
             step(F{}, p + 0, IC<0>{}, IC<1>{}, IC<2>{});
             step(F{}, p + 1, IC<1>{}, IC<2>{}, IC<0>{});
             step(F{}, p + 2, IC<2>{}, IC<0>{}, IC<1>{});
+        }
+        if (p > ze + 1) break;
+        for (; int_ok(p); p += 3) {
+            pin_accs();
+            step(T{}, p + 0, IC<0>{}, IC<1>{}, IC<2>{});
+            step(T{}, p + 1, IC<1>{}, IC<2>{}, IC<0>{});
+            step(T{}, p + 2, IC<2>{}, IC<0>{}, IC<1>{});
         }
     }
 }
