@@ -160,6 +160,7 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
                           int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
                           int* nparts);
 int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin);
+bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

@@ -619,7 +619,10 @@ __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const floa
     return r;
 }
 
-template <class P, bool POOL>
+// WB: write the activated tensor back in place.  POOL && !WB: only the pooled tensor is produced - the full-resolution
+// tensor stays raw and every consumer applies scale/shift + Mish while it loads (conv_zreg.hip's staging, the
+// transposed conv below, the final 1x1x1 conv)
+template <class P, bool POOL, bool WB>
 __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C,
                                                         int D, int H, int W, uint4* __restrict__ pooled) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -649,8 +652,11 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const long long o = ((long long)(2 * zz + a) * H + (2 * yy + b)) * W + 2 * xx;
-                    p[o] = norm_mish8<P>(p[o], sc, sh, mx);
-                    p[o + 1] = norm_mish8<P>(p[o + 1], sc, sh, mx);
+                    const uint4 r0 = norm_mish8<P>(p[o], sc, sh, mx), r1 = norm_mish8<P>(p[o + 1], sc, sh, mx);
+                    if (WB) {
+                        p[o] = r0;
+                        p[o + 1] = r1;
+                    }
                 }
             uint4 r;
             r.x = P::pack2(mx[0], mx[1]);
@@ -723,7 +729,8 @@ __global__ void __launch_bounds__(256) deconv2_mfma_kernel(const uint4* __restri
 template <class P, int KP>
 __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
                                                            const float* __restrict__ bias, uint4* __restrict__ out,
-                                                           int cout, int D, int H, int W, int segs) {
+                                                           int cout, int D, int H, int W, int segs,
+                                                           const float2* __restrict__ ss) {
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
@@ -740,7 +747,17 @@ __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restri
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
-        const uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vin];
+        uint4 u = in[((long long)n * (2 * KP) + 2 * kp + h) * vox + vin];
+        if (ss) {  // the input is the raw output of a conv: its InstanceNorm + Mish are applied here (wave-uniform branch)
+            float sc[8], sh[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 v = ss[n * (16 * KP) + (2 * kp + h) * 8 + k];
+                sc[k] = v.x;
+                sh[k] = v.y;
+            }
+            u = norm_mish8<P>(u, sc, sh, nullptr);
+        }
         b0[kp] = AS_FRAG((ok && !odd) ? u : zero4);
         b1[kp] = AS_FRAG((ok && odd) ? u : zero4);
     }
@@ -882,42 +899,77 @@ struct Net16 {
     int B;
     float* partials;
     size_t partials_floats;
-    float2* ss;  // [B][256]
+    float2* ss_base;  // [DLV_N_CONV][B][256]: scale/shift of every conv layer of this forward (skip tensors stay raw)
+    float2* ss_of(int li) const { return ss_base + (size_t)li * B * 256; }
+    static size_t ss_bytes(int B) { return (size_t)DLV_N_CONV * B * 256 * sizeof(float2); }
+
+    // a tensor of the forward: chunk-planar data + the scale/shift it still awaits (nullptr: final values)
+    struct Act {
+        uint4* p;
+        int C;
+        const float2* ss;
+    };
 
     int grid1d(long long n) const { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
+
+    // does the register-resident-weights conv run this layer (and with which inputs may it apply the activation itself)?
+    bool zreg_runs(int li, int c1, int c2, Dims d) const {
+        const DlvConvLayer& L = ctx->conv[li];
+        static const int zreg_mask = getenv("DLV_ZREG_MASK") ? atoi(getenv("DLV_ZREG_MASK")) : 3;  // development: 1 = Cin 32, 2 = Cin 64
+        return (ctx->zm_variant == 0 || ctx->zm_variant == 50) && !ctx->no_zmarch && d.vox() > 32768 &&
+               dlv_conv3_zreg_supports(L.cin, L.cout, c1, c2, d.W) && ((L.cin == 32 ? 1 : 2) & zreg_mask);
+    }
+    bool fuses_first_input(int li, int c1, int c2, Dims d) const {
+        // which levels' raw tensors are activated by the consuming conv while it stages them (bit l = level l).  Measured
+        // (profiles/README.md, round 2): the Mish costs the staging conv more VALU time than the separate pass costs HBM
+        // time at level 0, so the default fuses nothing into the convs; the transposed convs and the final 1x1x1 conv
+        // always activate on load.  DLV_FUSE_LEVELS overrides (A/B).
+        static const int fuse_levels = getenv("DLV_FUSE_LEVELS") ? atoi(getenv("DLV_FUSE_LEVELS")) : 0;
+        static const int level_of[DLV_N_CONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
+        return ((fuse_levels >> level_of[li]) & 1) && c1 == 32 && zreg_runs(li, c1, c2, d);
+    }
+    // InstanceNorm + Mish in place (the tensor becomes final)
+    int materialise(Act& t, Dims d) {
+        if (!t.ss) return DLV_OK;
+        DLV_TRY(norm_mish(t.p, t.C, d, nullptr, t.ss, true));
+        t.ss = nullptr;
+        return DLV_OK;
+    }
 
     int stats(int nparts, int li, Dims d) {
         const DlvConvLayer& L = ctx->conv[li];
         // the fp16 format stores the raw stem output scaled by 2^-8: eps scales with its square (same normalised value)
         const float eps = li == 0 ? 1e-5f * P::STEM_SCALE * P::STEM_SCALE : 1e-5f;
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(B * L.cout), dim3(64), 0, ctx->stream, partials, nparts, L.cout,
-                           1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss);
+                           1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss_of(li));
         DLV_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
         return DLV_OK;
     }
 
-    // raw conv output + InstanceNorm scale/shift into ss
-    int conv(int li, const uint4* in1, int c1, const uint4* in2, int c2, uint4* out, Dims d) {
+    // raw conv output + its InstanceNorm scale/shift into ss_of(li).  Inputs that still await their activation are either
+    // activated by the kernel while it stages them (conv_zreg.hip) or made final by a normalisation pass first.
+    int conv(int li, Act& a1, Act* a2, uint4* out, Dims d) {
         const DlvConvLayer& L = ctx->conv[li];
+        const int c1 = a1.C, c2 = a2 ? a2->C : 0;
         if (c1 + c2 != L.cin) return dlv_fail(ctx, DLV_ESTATE, "conv %d: %d+%d input channels, expected %d", li, c1, c2, L.cin);
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
-        // z-march: weights of one 32-channel output block resident in LDS (54 / 108 KB), so Cin <= 64; Cout = 64 runs as
-        // two blocks over the same input (the 32^3 level: 226 -> ~135 us per conv against the generic kernel)
-        static const int zreg_mask = getenv("DLV_ZREG_MASK") ? atoi(getenv("DLV_ZREG_MASK")) : 3;  // development: 1 = Cin 32, 2 = Cin 64
-        if (ctx->zm_variant == 50 && (L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch &&
-            (c2 == 0 || (c1 == 32 && c2 == 32)) && ((L.cin == 32 ? 1 : 2) & zreg_mask)) {
+        if (a2) DLV_TRY(materialise(*a2, d));
+        if (!fuses_first_input(li, c1, c2, d)) DLV_TRY(materialise(a1, d));
+        const uint4* in1 = a1.p;
+        const uint4* in2 = a2 ? a2->p : nullptr;
+        if (zreg_runs(li, c1, c2, d)) {
             char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
+            snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d%s", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, a1.ss ? "_act" : "");
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
             int np = 0;
             if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
                 return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zreg)");
-            DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, nullptr, in2, c2, nullptr,
+            DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, a1.ss, in2, c2, nullptr,
                                           P::IS_F16 ? L.w16_f16 : L.w16_bf16, out, partials, B, d.D, d.H, d.W, &np));
             zp.end();
             return stats(np, li, d);
         }
-        if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {
+        if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {  // LDS-weights z-march (conv_zmarch.hip)
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
@@ -988,24 +1040,31 @@ struct Net16 {
         return stats(ntiles, li, d);
     }
 
-    int norm_mish(uint4* x, int C, Dims d, uint4* pooled) {
+    // InstanceNorm apply + Mish (+ MaxPool into `pooled`); writeback = false (pool only): x stays raw for consumers that
+    // activate while loading
+    int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
         const long long work = pooled ? d.vox() / 8 : d.vox();
         dim3 grid(std::max(1, std::min(grid1d(work), 2048)), C / 8, B);
-        DlvProf pr(ctx, pooled ? "norm_mish_pool_bf16" : "norm_mish_bf16", 0.0,
-                   (double)d.vox() * B * C * 2 * 2 + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
-        if (pooled)
-            hipLaunchKernelGGL((norm_mish_kernel<P, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+        DlvProf pr(ctx, pooled ? (writeback ? "norm_mish_pool_bf16" : "pool_act_bf16") : "norm_mish_bf16", 0.0,
+                   (double)d.vox() * B * C * 2 * (writeback ? 2 : 1) + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
+        if (pooled && writeback)
+            hipLaunchKernelGGL((norm_mish_kernel<P, true, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+        else if (pooled)
+            hipLaunchKernelGGL((norm_mish_kernel<P, true, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
         else
-            hipLaunchKernelGGL((norm_mish_kernel<P, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+            hipLaunchKernelGGL((norm_mish_kernel<P, false, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "norm_mish_kernel");
         return DLV_OK;
     }
 
-    int deconv(int j, const uint4* in, uint4* out, Dims din) {
+    int deconv(int j, Act& a, uint4* out, Dims din) {
         const DlvDeconvLayer& L = ctx->deconv[j];
         const uint4* w = reinterpret_cast<const uint4*>(wpack<P>(L));
         const bool rows = !ctx->no_zmarch;
+        if (!rows) DLV_TRY(materialise(a, din));  // the per-parity kernel has no activation on load
+        const uint4* in = a.p;
+        const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
         DlvProf pr(ctx, "deconv2_mfma_bf16", 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
@@ -1014,7 +1073,7 @@ struct Net16 {
     do {                                                                                                                 \
         if (rows)                                                                                                        \
             hipLaunchKernelGGL((deconv2_rows_kernel<P, KP_>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
-                               din.D, din.H, din.W, segs);                                                               \
+                               din.D, din.H, din.W, segs, ssin);                                                               \
         else                                                                                                             \
             hipLaunchKernelGGL((deconv2_mfma_kernel<P, KP_>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout,     \
                                din.D, din.H, din.W);                                                                     \
@@ -1057,12 +1116,14 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
     const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
     char* sbase;
-    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
+    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + Net16<P>::ss_bytes(B) + 256, (void**)&sbase));
     Net16<P> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
+    using Act = typename Net16<P>::Act;
     auto buf = [&](int l, int k) { return (uint4*)(base + offs[l][k]); };
     enum { A = 0, Bf = 1, S = 2, U = 3 };
 
     // stem
+    Act x0{buf(0, A), 32, nullptr};
     {
         dim3 grid(dlv_cdiv((long long)h * w, 256), dlv_cdiv(d, STEM_ZR), B);
         int nblk = grid.x * grid.y;
@@ -1081,7 +1142,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
             DLV_LAUNCH_CHECK(ctx, "stem_mfma_kernel<1>");
             DLV_TRY(net.stats(nblk, 0, dm[0]));
             hipLaunchKernelGGL((stem_mfma_kernel<P, 2>), grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim, wst,
-                               L.bias, buf(0, A), net.partials, (const float2*)net.ss, d, h, w, tY, tX);
+                               L.bias, buf(0, A), net.partials, (const float2*)net.ss_of(0), d, h, w, tY, tX);
             two_pass_stem = true;
         } else if (vol)
             hipLaunchKernelGGL((stem_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
@@ -1093,39 +1154,62 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         DLV_LAUNCH_CHECK(ctx, "stem_conv_kernel");
         if (!two_pass_stem) {
             DLV_TRY(net.stats(nblk, 0, dm[0]));
-            DLV_TRY(net.norm_mish(buf(0, A), 32, dm[0], nullptr));
+            x0.ss = net.ss_of(0);  // raw: the first conv activates it while staging, or it is made final first
         }
     }
-    DLV_TRY(net.conv(1, buf(0, A), 32, nullptr, 0, buf(0, S), dm[0]));
-    DLV_TRY(net.norm_mish(buf(0, S), 32, dm[0], buf(1, A)));
     const int encC[5] = {32, f[1], f[2], f[3], f[4]};
-    for (int l = 1; l <= 4; ++l) {
-        DLV_TRY(net.conv(2 * l, buf(l, A), encC[l - 1], nullptr, 0, buf(l, Bf), dm[l]));
-        DLV_TRY(net.norm_mish(buf(l, Bf), encC[l], dm[l], nullptr));
-        DLV_TRY(net.conv(2 * l + 1, buf(l, Bf), encC[l], nullptr, 0, buf(l, S), dm[l]));
-        DLV_TRY(net.norm_mish(buf(l, S), encC[l], dm[l], l < 4 ? buf(l + 1, A) : nullptr));
+    // encoder.  skip[l] = output of level l (consumed pooled by level l+1 and, as the skip connection, by upcat_{l+1}).
+    // Where both consumers of a raw tensor activate on load, no normalised copy of it is ever written: only the pooled
+    // tensor is produced (levels 0 and 1 of the default windows); elsewhere the normalisation pass writes it back.
+    Act skip[5];
+    {
+        Act s0{buf(0, S), 32, nullptr};
+        DLV_TRY(net.conv(1, x0, nullptr, s0.p, dm[0]));
+        s0.ss = net.ss_of(1);
+        skip[0] = s0;
     }
-    const uint4* cur = buf(4, S);
+    for (int l = 1; l <= 4; ++l) {
+        // pool level l-1 into the input of level l
+        Act& up = skip[l - 1];
+        const int li_cat = 18 - 2 * l;  // upcat conv that takes skip[l-1]: 16, 14, 12, 10
+        const int c_up = ctx->deconv[4 - l].cout;
+        const bool keep_raw = net.fuses_first_input(li_cat, up.C, c_up, dm[l - 1]);
+        DLV_TRY(net.norm_mish(up.p, up.C, dm[l - 1], buf(l, A), up.ss, !keep_raw));
+        if (!keep_raw) up.ss = nullptr;
+        Act a{buf(l, A), encC[l - 1], nullptr};
+        Act b{buf(l, Bf), encC[l], nullptr};
+        DLV_TRY(net.conv(2 * l, a, nullptr, b.p, dm[l]));
+        b.ss = net.ss_of(2 * l);
+        Act s{buf(l, S), encC[l], nullptr};
+        DLV_TRY(net.conv(2 * l + 1, b, nullptr, s.p, dm[l]));
+        s.ss = net.ss_of(2 * l + 1);
+        skip[l] = s;
+    }
+    // decoder: transposed conv (activates its input on load), concat [skip, up], two convs
+    Act cur = skip[4];
     for (int j = 0; j < 4; ++j) {
         const int l = 3 - j;
         DLV_TRY(net.deconv(j, cur, buf(l, U), dm[l + 1]));
+        Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
         const int li = 10 + 2 * j;
-        DLV_TRY(net.conv(li, buf(l, S), encC[l], buf(l, U), ctx->deconv[j].cout, buf(l, Bf), dm[l]));
-        DLV_TRY(net.norm_mish(buf(l, Bf), ctx->conv[li].cout, dm[l], nullptr));
-        DLV_TRY(net.conv(li + 1, buf(l, Bf), ctx->conv[li].cout, nullptr, 0, buf(l, A), dm[l]));
-        if (j < 3) DLV_TRY(net.norm_mish(buf(l, A), ctx->conv[li + 1].cout, dm[l], nullptr));
-        cur = buf(l, A);
+        Act b{buf(l, Bf), ctx->conv[li].cout, nullptr};
+        DLV_TRY(net.conv(li, skip[l], &u, b.p, dm[l]));
+        b.ss = net.ss_of(li);
+        Act o{buf(l, A), ctx->conv[li + 1].cout, nullptr};
+        DLV_TRY(net.conv(li + 1, b, nullptr, o.p, dm[l]));
+        o.ss = net.ss_of(li + 1);
+        cur = o;
     }
     {
         dim3 grid(std::min(net.grid1d(dm[0].vox()), 2048), B);
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
         if (acc)
-            hipLaunchKernelGGL((final_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+            hipLaunchKernelGGL((final_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, cur.p, cur.ss, ctx->final_w,
                                ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w, ctx->blend_w, ctx->blend_min,
                                ctx->blend_wsum);
         else
-            hipLaunchKernelGGL((final_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, cur, net.ss, ctx->final_w,
+            hipLaunchKernelGGL((final_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, cur.p, cur.ss, ctx->final_w,
                                ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w, nullptr, 0.f, nullptr);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "final_conv_kernel");
@@ -1168,17 +1252,18 @@ int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int 
         char* base;
         DLV_TRY(dlv_ws_get(ctx, WS_BF16_ACT, b1 + b2 + bo + 1024, (void**)&base));
         char* sbase;
-        DLV_TRY(dlv_ws_get(ctx, WS_STATS, pf * 4 + (size_t)B * 256 * sizeof(float2) + 256, (void**)&sbase));
+        DLV_TRY(dlv_ws_get(ctx, WS_STATS, pf * 4 + Net16<P>::ss_bytes(B) + 256, (void**)&sbase));
         uint4 *i1 = (uint4*)base, *i2 = (uint4*)(base + ((b1 + 255) & ~(size_t)255)),
               *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255) + ((b2 + 255) & ~(size_t)255));
         Net16<P> net{ctx, B, (float*)sbase, pf, (float2*)(sbase + ((pf * 4 + 255) & ~(size_t)255))};
         const int g = net.grid1d(vox);
         hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
         if (c2) hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(g, c2 / 8, B), dim3(256), 0, ctx->stream, in2_dev, i2, c2, vox);
-        DLV_TRY(net.conv(index, i1, c1, c2 ? i2 : nullptr, c2, o, Dims{D, H, W}));
-        if (kind == 0) DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr));
+        typename Net16<P>::Act t1{i1, c1, nullptr}, t2{i2, c2, nullptr};
+        DLV_TRY(net.conv(index, t1, c2 ? &t2 : nullptr, o, Dims{D, H, W}));
+        if (kind == 0) DLV_TRY(net.norm_mish(o, L.cout, Dims{D, H, W}, nullptr, net.ss_of(index), true));
         if (kind == 3) {
-            DLV_HIP(ctx, hipMemcpyAsync(out_dev, net.ss, (size_t)B * L.cout * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+            DLV_HIP(ctx, hipMemcpyAsync(out_dev, net.ss_of(index), (size_t)B * L.cout * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
             return DLV_OK;
         }
         hipLaunchKernelGGL(cp_to_f32_kernel<P>, dim3(g, L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev, L.cout, vox);
@@ -1195,7 +1280,8 @@ int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int 
         uint4 *i1 = (uint4*)base, *o = (uint4*)(base + ((b1 + 255) & ~(size_t)255));
         Net16<P> net{ctx, B, nullptr, 0, nullptr};
         hipLaunchKernelGGL(f32_to_cp_kernel<P>, dim3(net.grid1d(vox), c1 / 8, B), dim3(256), 0, ctx->stream, in1_dev, i1, c1, vox);
-        DLV_TRY(net.deconv(index, i1, o, Dims{D, H, W}));
+        typename Net16<P>::Act t1{i1, c1, nullptr};
+        DLV_TRY(net.deconv(index, t1, o, Dims{D, H, W}));
         hipLaunchKernelGGL(cp_to_f32_kernel<P>, dim3(net.grid1d(vox * 8), L.cout / 8, B), dim3(256), 0, ctx->stream, o, out_dev,
                            L.cout, vox * 8);
         DLV_LAUNCH_CHECK(ctx, "debug deconv");

@@ -60,6 +60,6 @@ for v in variants:
                           "sign_agreement_vs_first": float(((accs[v] >= 0) == (base >= 0)).mean())}
     print(f"variant {v}: wall {out['variants'][v]['wall_ms_med']:.1f} ms  rel rms vs {variants[0]}: {out['variants'][v]['rel_rms_vs_first']:.2e}")
     for k in sorted(ks, key=lambda k: -ks[k]["us_med"]):
-        if "conv3" in k:
+        if True:
             print(f"    {k:32s} {ks[k]['us_med']:9.1f} us  {ks[k]['tflops_med']:7.1f} TFLOP/s")
 print(json.dumps(out))

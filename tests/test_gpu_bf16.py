@@ -266,7 +266,7 @@ def test_sw_pass_fp16_matches_fp32_engine(eng, golden_dir):
 # ---------------------------------------------------------------------------------------------------
 # opt-in builds of the z-march conv (dlv_debug_set_zm_variant): same torch reference, same tolerance
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [6, 20, 24, 40, 50])
+@pytest.mark.parametrize("variant", [6, 20, 24, 40, 50, 51])
 @pytest.mark.parametrize("li,c1,c2,prec", [(1, 32, 0, "fp16"), (16, 32, 32, "fp16"), (1, 32, 0, "bf16"), (16, 32, 32, "bf16")])
 def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     """Streaming-store (6), double-buffered half-plane (20), LDS-DMA (24) and software-pipelined (40) builds of the
@@ -296,4 +296,6 @@ def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     tol_max, tol_mean = (0.01, 1e-3) if prec == "fp16" else (0.06, 6e-3)
     assert err.max() < tol_max, float(err.max())
     assert err.mean() < tol_mean, float(err.mean())
-    assert (out - base).abs().max() < tol_max
+    # the default build carries no conv bias (InstanceNorm removes it), the LDS-weights builds do: the stored raw values
+    # round differently
+    assert (out - base).abs().max() < 2 * tol_max
