@@ -81,8 +81,7 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
     rank = dist.get_rank() if sharded else 0
 
     path_out = settings["postprocessing"]["output_location"]
-    if not os.path.exists(path_out):
-        os.mkdir(path_out)
+    os.makedirs(path_out, exist_ok=True)  # (every rank may get here first)
     len_b = len(os.listdir(path_in))
     start = datetime.datetime.now()
     print(f"{start} Now postprocessing inference for {brain} - {brain_i}/{len_b}")
@@ -108,6 +107,13 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
             print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
         dist.barrier()
         return N
+    if sharded and rank != 0:
+        # a cached labelling exists: rank 0 alone re-uses it (and writes the statistics / CSV), the others wait for N
+        if own:
+            eng.close()
+        box = [None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
     try:
         cached = load_cached_brain(settings, brain)
         if not cached:
@@ -143,4 +149,6 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
         fh.write(cells_csv_text(stats, N))
     end = datetime.datetime.now()
     print(f"{end} {brain} {brain_i} / {len_b} Done; Took {end - start}")
+    if sharded:
+        dist.broadcast_object_list([N], src=0)
     return N

@@ -214,7 +214,9 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     dlv_ctx* ctx = new (std::nothrow) dlv_ctx();
     if (!ctx) return DLV_ENOMEM;
     ctx->device = device_id;
+#ifdef DLV_DIAG  // the product library takes no kernel variant from the environment (diagnostic builds: make diag)
     if (const char* e = getenv("DLV_ZM_VARIANT")) ctx->zm_variant = atoi(e);
+#endif
     ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
@@ -385,6 +387,12 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
 
 int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant) {
     if (!ctx) return DLV_EINVAL;
+#ifndef DLV_DIAG
+    // product library: 0 / 50 = register-resident-weights conv (default), 51 = the LDS-resident-weights kernel for every
+    // z-march layer (A/B); the timing-only, stamped and experimental builds exist in libdelivr_hip_diag.so only
+    if (variant != 0 && variant != 50 && variant != 51)
+        return dlv_fail(ctx, DLV_EUNSUP, "z-march variant %d is a diagnostic build: load libdelivr_hip_diag.so (make -C delivr_cfos_amd/csrc diag)", variant);
+#endif
     ctx->zm_variant = variant;
     return DLV_OK;
 }

@@ -915,7 +915,11 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
     const int ncb = cout / 32;
     const int variant = ctx->zm_variant;  // DLV_ZM_VARIANT at context creation, or dlv_debug_set_zm_variant
     // 16-row tiles (8 waves x 2 rows) only as A/B variant 3: measured equal/slower than 8 rows x 1 (profiles/README.md)
+#ifdef DLV_DIAG
     const int tyt = (cin == 32 && variant == 3) ? 16 : 8;
+#else
+    const int tyt = 8;
+#endif
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, ZM_TX);
     // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
     int zseg = ((D + 15) / 16) * 16;
@@ -948,6 +952,7 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
                            ctx->stream, (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out,      \
                            partials, D, H, W, tilesY, tilesX, zseg, (const uint4*)ctx->zero_page);                       \
     } while (0)
+#ifdef DLV_DIAG  // A/B, stamped and timing-only builds: libdelivr_hip_diag.so only (make diag)
     if (cout == 32 && variant >= 40 && variant <= 45 && H % 8 == 0 && W % 32 == 0 && (long long)4 * D * H * W * 16 < (1ll << 32) &&
         ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
 #define DLV_ZM4_LAUNCH(P_, NSRC_, ST_, ABL_)                                                                                       \
@@ -994,36 +999,49 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
         }
 #undef DLV_ZM2_PICK
     } else
+#endif
     // default (measured fastest on C2, profiles/README.md): one row per wave, 8 waves, 2 waves per SIMD
 #define DLV_ZM_LAUNCH(...) DLV_ZM_LAUNCH_P(PBf16, __VA_ARGS__)
     // the fp16 format runs the default kernel only (the A/B variants below are bf16)
     if (f16) {
         if (cin == 32) {
+#ifdef DLV_DIAG
             if (variant == 6) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 8, false);
             else if (variant == 30) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 16, false);
             else if (variant == 31) DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 19, false);  // stamped, no staging, no epilogue
-            else DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 0, false);
+            else
+#endif
+            DLV_ZM_LAUNCH_P(PF16, 32, 1, 2, 8, true, 1, 0, false);
         } else if (cin == 64) {
+#ifdef DLV_DIAG
             if (variant == 6) DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 8, false);
             else if (variant == 30) DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 16, false);
-            else DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 0, false);
+            else
+#endif
+            DLV_ZM_LAUNCH_P(PF16, 64, 1, 2, 8, true, 1, 0, false);
         }
         else return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     } else
     // variants 11/12/13 are timing-only ablations (no epilogue / no staging / neither): wrong results
     if (cin == 32) {
+#ifdef DLV_DIAG
         if (variant == 11) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 1, false);
         else if (variant == 12) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 2, false);
         else if (variant == 13) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 3, false);
         else if (variant == 3) DLV_ZM_LAUNCH(32, 2, 2, 16, true, 1, 0, false);
         else if (variant == 4) DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0, true);
-        else DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0, false);
+        else
+#endif
+        DLV_ZM_LAUNCH(32, 1, 2, 8, true, 1, 0, false);
     } else if (cin == 64) {
+#ifdef DLV_DIAG
         if (variant == 11) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 1, false);
         else if (variant == 12) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 2, false);
         else if (variant == 13) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 3, false);
         else if (variant == 4) DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0, true);
-        else DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0, false);
+        else
+#endif
+        DLV_ZM_LAUNCH(64, 1, 2, 8, true, 1, 0, false);
     } else {
         return dlv_fail(ctx, DLV_EUNSUP, "z-march conv: Cin must be 32 or 64");
     }

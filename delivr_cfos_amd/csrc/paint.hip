@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(256) paint_small_kernel(const uint8_t* __restr
     for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
         const int* b = boxes + 6 * i;
         const long long vol = (long long)(b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
-        if (vol <= 0 || vol >= PAINT_BIG) continue;
+        // an empty or inverted extent on ANY axis paints nothing (two inverted axes would give a positive volume)
+        if (b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4] || vol >= PAINT_BIG) continue;
         paint_box(bin, owner, Y, X, b, (u32)(i + 1), lane, 64);
     }
 }
@@ -81,6 +82,7 @@ int dlv_paint_owner_dev(dlv_ctx* ctx, const uint8_t* bin_dev, int Z, int Y, int 
     DLV_LAUNCH_CHECK(ctx, "paint_small_kernel");
     for (uint64_t i = 0; i < n_boxes; ++i) {
         const int32_t* b = boxes_host + 6 * i;
+        if (b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4]) continue;  // empty / inverted: nothing to paint
         const long long vol = (long long)(b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
         if (vol < PAINT_BIG) continue;
         const int gb = (int)std::min<long long>((vol + 255) / 256, 256 * 32);

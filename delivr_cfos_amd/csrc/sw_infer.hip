@@ -286,6 +286,26 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     } else if (p->blend_mode != DLV_BLEND_CONSTANT) {
         return dlv_fail(ctx, DLV_EINVAL, "unknown blend_mode %d", p->blend_mode);
     }
+    if (cnt_dev) {
+        // the count map is uint8 (the reference's LOAD_ALL_RAM map, inference.py:241): refuse a geometry whose overlap
+        // multiplicity times `repeat` cannot be held instead of wrapping silently
+        long long mult = 1;
+        for (int k = 0; k < 3; ++k) {
+            std::vector<int> cov((size_t)t.n[k] + 1, 0);
+            for (int st : t.st[k]) {
+                cov[st] += 1;
+                cov[st + t.roi[k]] -= 1;
+            }
+            int run = 0, mx = 0;
+            for (int i = 0; i < t.n[k]; ++i) {
+                run += cov[i];
+                mx = std::max(mx, run);
+            }
+            mult *= mx;
+        }
+        if (mult * rep > 255)
+            return dlv_fail(ctx, DLV_EUNSUP, "uint8 count map would wrap: up to %lld windows cover a voxel, x repeat %d > 255", mult, rep);
+    }
     if (stats) {
         stats->n_windows = std::max<int64_t>(we - wb, 0);
         stats->n_skipped = 0;

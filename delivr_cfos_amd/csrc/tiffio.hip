@@ -461,6 +461,8 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
     if (n_planes <= 0 || height <= 0 || width <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty stack");
     if (row_stride < width || plane_stride < (long long)height * row_stride) return dlv_fail(ctx, DLV_EINVAL, "strides smaller than the plane");
     DLV_HIP(ctx, hipSetDevice(ctx->device));
+    // no exception crosses the C ABI: allocation failures of the vectors / strings / threads below are reported as codes
+    try {
     if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
     const size_t plane_elems = (size_t)height * width;
     // planes per staging chunk: at least one per thread, about 256 MB
@@ -484,7 +486,7 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
     uint16_t** stage = stg.buf;
     hipEvent_t* done = stg.ev;
     std::string err;
-    std::atomic<bool> failed{false};
+    std::atomic<bool> failed{false}, oom{false};
     int rc = DLV_OK;
     for (int c0 = 0, it = 0; c0 < n_planes && !failed; c0 += chunk, ++it) {
         const int b = it & 1;
@@ -495,6 +497,7 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
         std::vector<std::thread> pool;
         for (int t = 0; t < std::min(n_threads, cn); ++t)
             pool.emplace_back([&, t]() {
+                try {  // an exception escaping a thread function would call std::terminate
                 std::vector<uint8_t> buf, scratch;
                 for (;;) {
                     const int i = next.fetch_add(1);
@@ -511,11 +514,16 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
                         failed = true;
                     }
                 }
+                } catch (...) {
+                    failed = true;  // (no allocation here: the message is set by the caller)
+                    oom = true;
+                }
             });
         for (auto& th : pool) th.join();
         if (failed) {
             for (auto& e : errs)
                 if (!e.empty()) err = e;
+            if (err.empty() && oom) err = "out of host memory while decoding";
             break;
         }
         hipError_t he = hipSuccess;
@@ -536,8 +544,15 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
         (void)hipEventRecord(done[b], ctx->stream);
     }
     (void)hipStreamSynchronize(ctx->stream);  // before the staging buffers go away
-    if (failed) rc = dlv_fail(ctx, DLV_EUNSUP, "%s", err.c_str());
+    if (failed) rc = dlv_fail(ctx, oom ? DLV_ENOMEM : DLV_EUNSUP, "%s", err.c_str());
     return rc;
+    } catch (const std::bad_alloc&) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return dlv_fail(ctx, DLV_ENOMEM, "dlv_tiff_stack_to_device: out of host memory");
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return dlv_fail(ctx, DLV_EHIP, "dlv_tiff_stack_to_device: host-side failure (thread creation?)");
+    }
 }
 
 }  // extern "C"

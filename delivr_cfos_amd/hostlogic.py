@@ -83,3 +83,18 @@ def padded_boxes(bounding_boxes: np.ndarray, cc_ids, shape_zyx, times: int = 1) 
         hi = np.where(hi < dims[None, :], hi + 1, hi)
     out[:, 1::2] = hi
     return out.astype(np.int32)
+
+
+def max_window_multiplicity(starts, roi) -> int:
+    """Largest number of windows covering one voxel, for the (n,3) window starts of the reference's enumeration
+    (inference/sliding_window_inferer.py:143-145) and the window size: the peak of the count map after one pass."""
+    import numpy as np
+
+    starts = np.asarray(starts)
+    mult = 1
+    for k in range(3):
+        st = np.unique(starts[:, k])
+        ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([st + int(roi[k]), -np.ones_like(st)], 1)])
+        ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]  # closings (-1) before openings (+1) at equal coordinates
+        mult *= int(np.cumsum(ev[:, 1]).max())
+    return mult

@@ -25,6 +25,10 @@ def create_nifti_seg(threshold, model_output, output_file, network_output_file, 
     blended logits (sum; pass ``count_map`` to divide, or the mean already); ``dataset``: the uint16
     volume in HBM."""
     Z, Y, X = (int(v) for v in original_stack_shape[-3:])
+    if count_map is None and float(threshold) != 0.5:
+        # sigmoid(sum of the window logits) >= t equals the reference's sigmoid(sum / count) >= t (:295) only at t = 0.5
+        raise ValueError(f"threshold {threshold} needs the count map (or mean logits with threshold 0.5 semantics): "
+                         "without it only the sign of the blended sum is known")
     acc = model_output[0, 0] if model_output.dim() == 5 else model_output
     raw = dataset[0, 0] if dataset.dim() == 5 else dataset
     cnt = None if count_map is None else (count_map[0, 0] if count_map.dim() == 5 else count_map)
@@ -123,8 +127,20 @@ def run_inference(
         os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
     save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
     output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
+    # The count map is needed whenever the MEAN logit matters: for network_output.npy and for any threshold other than
+    # 0.5 (reference: mean = sum / count before the sigmoid, inference.py:295); at 0.5 the sign of the sum decides.
+    need_count = save_activated or float(threshold) != 0.5
     count_map = (torch.zeros(pad[2:], dtype=torch.float32 if gaussian else torch.uint8, device=eng.device)
-                 if save_activated else None)
+                 if need_count else None)
+    if count_map is not None and count_map.dtype == torch.uint8:
+        # uint8 like the reference's LOAD_ALL_RAM map (:241): refuse geometries whose multiplicity cannot be held
+        from ..hostlogic import max_window_multiplicity
+
+        p_chk = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
+        mult = max_window_multiplicity(eng.window_starts(p_chk), [int(p_chk.roi[k]) for k in range(3)]) * (13 if tta else 1)
+        if mult > 255:
+            raise NotImplementedError(f"up to {mult} (window, pass) contributions per voxel do not fit the uint8 count map "
+                                      "(overlap too large for this threshold / SAVE_ACTIVATED_OUTPUT setting)")
     print("output_image shape", tuple(output_image.shape))
 
     testing_session_path = os.path.abspath(output_folder + "/" + comment)

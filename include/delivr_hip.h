@@ -157,8 +157,9 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                      uint8_t* cnt_dev, dlv_sw_stats* stats);
 
 /* ---- finalize: divide, threshold, eroded re-mask ------------------------------------------- */
-/* inference/inference.py:285-299 + create_nifti_seg (:31-95).  mean = acc/cnt (cnt may be NULL:
- * the division never changes the decision), fg = sigmoid(mean) >= threshold, keep = raw>0 eroded
+/* inference/inference.py:285-299 + create_nifti_seg (:31-95).  mean = acc/cnt; cnt_dev == NULL: acc_dev already holds
+ * the MEAN logits - or, for threshold == 0.5 ONLY, any positive multiple of them such as the plain sum (the sign decides);
+ * a caller with another threshold must pass the count map (the Python mirror enforces it).  fg = sigmoid(mean) >= threshold, keep = raw>0 eroded
  * by an L1 ball of radius erode_iters evaluated inside z-blocks of zblock planes (0 = whole
  * volume; the reference's Arrayterator rule gives floor(floor(1e9/X)/Y)), out = fg & keep.
  * acc/cnt/raw are (.,Yp,Xp)-strided padded buffers, out_dev is the unpadded (Z,Y,X) uint8

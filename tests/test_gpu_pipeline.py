@@ -499,3 +499,63 @@ def test_run_inference_with_gaussian_blend_option(tmp_path):
     assert np.array_equal(binaries[~margin], ref[~margin])
     want = 1.0 / (1.0 + np.exp(-mean[:Z, :Y, :X].astype(np.float64)))
     assert np.abs(prob - want).max() < 1e-3
+
+
+@pytest.mark.parametrize("threshold", [0.3, 0.7])
+def test_run_inference_threshold_other_than_half_divides_by_the_count_map(tmp_path, threshold):
+    """The reference divides the logit sum by the count map BEFORE the sigmoid (inference.py:295), so a threshold other
+    than 0.5 needs the mean: run_inference then keeps the count map (it does not when the sign of the sum suffices) and
+    the mask equals the oracle's at that threshold; create_nifti_seg refuses the combination it cannot honour."""
+    import torch
+    from delivr_cfos_amd.inference import create_nifti_seg, run_inference
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    crop = (32, 32, 32)
+    vol = synth_volume_np((40, 64, 64), seed=8, dense=True)
+    nifti = os.path.join(str(tmp_path), "masked_nifti.npy")
+    pad = _write_padded_npy(nifti, vol, crop)
+    sd = random_state_dict(3)
+    out = run_inference([nifti], str(tmp_path / "out"), (1, 1) + vol.shape, comment="b", tta=False, threshold=threshold,
+                        crop_size=crop, state_dict={"state_dict": sd}, precision="fp32")
+    binaries = np.load(os.path.join(out, "binary_segmentations", "binaries.npy"))
+    net = orc.build_unet(seed=None)
+    net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+    padded = np.zeros(pad, dtype=np.uint16)
+    padded[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+    acc = np.zeros(pad, dtype=np.float32)
+    cnt = np.zeros(pad, dtype=np.uint8)
+    orc.sliding_window_pass(padded, crop, lambda x: orc.unet_forward(net, x), acc, cnt, 0.5, None, 1, fp16=False)
+    ref = orc.finalize(acc, cnt, padded, vol.shape, threshold, 30)
+    ref_half = orc.finalize(acc, cnt, padded, vol.shape, 0.5, 30)
+    assert ref.sum() != ref_half.sum()  # the threshold really selects another mask
+    sl = np.s_[: vol.shape[0], : vol.shape[1], : vol.shape[2]]
+    mean = acc[sl] / np.maximum(cnt[sl], 1)
+    margin = np.abs(mean - np.log(threshold / (1 - threshold))) < 1e-3
+    assert np.array_equal(binaries[~margin], ref[~margin])
+    with pytest.raises(ValueError):
+        create_nifti_seg(threshold, torch.zeros(pad, device="cuda"), str(tmp_path / "x.npy"), None,
+                         torch.zeros(pad, dtype=torch.uint16, device="cuda"), vol.shape, count_map=None, engine=None)
+
+
+def test_uint8_count_map_refuses_a_multiplicity_it_cannot_hold():
+    """overlap 0.75 on 64^3 / 32^3 windows -> up to 4*4*4 = 64 windows per voxel; x repeat 4 > 255: DLV_EUNSUP instead of
+    a silent wrap."""
+    import torch
+    from delivr_cfos_amd._lib import DelivrHipError
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    eng.load_state_dict({"state_dict": random_state_dict(0)})
+    shape, roi = (64, 64, 64), (32, 32, 32)
+    vol = torch.zeros(shape, dtype=torch.uint16, device="cuda")
+    acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    eng.sw_infer(eng.make_sw_params(shape, roi, 0.75, None, 0, "fp16", repeat=3), vol, acc, cnt)  # 64 * 3 fits
+    eng.sync()
+    assert int(cnt.max()) == 192
+    with pytest.raises(DelivrHipError):
+        eng.sw_infer(eng.make_sw_params(shape, roi, 0.75, None, 0, "fp16", repeat=4), vol, acc, cnt)
+    eng.close()
