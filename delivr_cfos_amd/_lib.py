@@ -99,6 +99,7 @@ SIGNATURES = {
     "dlv_zoom_spline2_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_mask_pad_u16_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_trilinear_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "dlv_affine_warp_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int, C.c_int, C.c_int]),
     "dlv_seam_pairs_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dlv_relabel_u32_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64]),
     "dlv_cc_stats_raw_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint64, _P, _P, _P, _P]),

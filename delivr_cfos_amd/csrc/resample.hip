@@ -115,27 +115,67 @@ __global__ void __launch_bounds__(256) mask_pad_u16_kernel(const uint16_t* __res
     }
 }
 
+// Both resamplers below compute in fp64 with contraction off, operation by operation as oracle/delivr_oracle.py states
+// them: bit-exact against the numpy restatement (they are HBM-bound; the fp64 arithmetic is hidden).
+struct Affine34 {
+    double m[12];  // row-major 3x4: (z,y,x) of the INPUT = m[0:3].(z,y,x of the output) + m[3], ...
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ double lerp3_u16(const uint16_t* __restrict__ in, int iz, int iy, int ix, double fz, double fy,
+                                            double fx, bool zero_outside) {
+    const double z0f = floor(fz), y0f = floor(fy), x0f = floor(fx);
+    const int z0 = (int)z0f, y0 = (int)y0f, x0 = (int)x0f;
+    const double tz = fz - z0f, ty = fy - y0f, tx = fx - x0f;
+    auto at = [&](int a, int b, int c) -> double {
+        if (zero_outside) {
+            if ((unsigned)a >= (unsigned)iz || (unsigned)b >= (unsigned)iy || (unsigned)c >= (unsigned)ix) return 0.0;
+        } else {
+            a = min(max(a, 0), iz - 1);
+            b = min(max(b, 0), iy - 1);
+            c = min(max(c, 0), ix - 1);
+        }
+        return (double)in[((long long)a * iy + b) * ix + c];
+    };
+    const double c00 = at(z0, y0, x0) * (1.0 - tx) + at(z0, y0, x0 + 1) * tx;
+    const double c01 = at(z0, y0 + 1, x0) * (1.0 - tx) + at(z0, y0 + 1, x0 + 1) * tx;
+    const double c10 = at(z0 + 1, y0, x0) * (1.0 - tx) + at(z0 + 1, y0, x0 + 1) * tx;
+    const double c11 = at(z0 + 1, y0 + 1, x0) * (1.0 - tx) + at(z0 + 1, y0 + 1, x0 + 1) * tx;
+    const double c0 = c00 * (1.0 - ty) + c01 * ty, c1 = c10 * (1.0 - ty) + c11 * ty;
+    return c0 * (1.0 - tz) + c1 * tz;
+}
+
+#pragma clang fp contract(off)
 __global__ void __launch_bounds__(256) trilinear_u16_kernel(const uint16_t* __restrict__ in, int iz, int iy, int ix,
                                                             uint16_t* __restrict__ out, int oz, int oy, int ox) {
     const long long n = (long long)oz * oy * ox;
-    const float sz = (float)iz / oz, sy = (float)iy / oy, sx = (float)ix / ox;
+    const double sz = (double)iz / (double)oz, sy = (double)iy / (double)oy, sx = (double)ix / (double)ox;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % ox), y = (int)((i / ox) % oy), z = (int)(i / ((long long)ox * oy));
         // align_corners=False: src = (dst + 0.5) * scale - 0.5, clamped to the edge
-        const float fz = fminf(fmaxf((z + 0.5f) * sz - 0.5f, 0.f), (float)(iz - 1));
-        const float fy = fminf(fmaxf((y + 0.5f) * sy - 0.5f, 0.f), (float)(iy - 1));
-        const float fx = fminf(fmaxf((x + 0.5f) * sx - 0.5f, 0.f), (float)(ix - 1));
-        const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
-        const int z1 = min(z0 + 1, iz - 1), y1 = min(y0 + 1, iy - 1), x1 = min(x0 + 1, ix - 1);
-        const float tz = fz - z0, ty = fy - y0, tx = fx - x0;
-        auto at = [&](int a, int b, int c) { return (float)in[((long long)a * iy + b) * ix + c]; };
-        const float c00 = at(z0, y0, x0) * (1 - tx) + at(z0, y0, x1) * tx;
-        const float c01 = at(z0, y1, x0) * (1 - tx) + at(z0, y1, x1) * tx;
-        const float c10 = at(z1, y0, x0) * (1 - tx) + at(z1, y0, x1) * tx;
-        const float c11 = at(z1, y1, x0) * (1 - tx) + at(z1, y1, x1) * tx;
-        const float c0 = c00 * (1 - ty) + c01 * ty, c1 = c10 * (1 - ty) + c11 * ty;
-        const float v = c0 * (1 - tz) + c1 * tz;
-        out[i] = (uint16_t)fminf(fmaxf(floorf(v + 0.5f), 0.f), 65535.f);
+        const double fz = fmin(fmax(((double)z + 0.5) * sz - 0.5, 0.0), (double)(iz - 1));
+        const double fy = fmin(fmax(((double)y + 0.5) * sy - 0.5, 0.0), (double)(iy - 1));
+        const double fx = fmin(fmax(((double)x + 0.5) * sx - 0.5, 0.0), (double)(ix - 1));
+        const double v = lerp3_u16(in, iz, iy, ix, fz, fy, fx, false);
+        out[i] = (uint16_t)fmin(fmax(floor(v + 0.5), 0.0), 65535.0);
+    }
+}
+
+// out[z,y,x] = trilinear sample of `in` at M.(z,y,x,1) (index space, zero outside the volume), round half up
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) affine_warp_u16_kernel(const uint16_t* __restrict__ in, int iz, int iy, int ix,
+                                                              Affine34 A, uint16_t* __restrict__ out, int oz, int oy, int ox) {
+    const long long n = (long long)oz * oy * ox;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % ox), y = (int)((i / ox) % oy), z = (int)(i / ((long long)ox * oy));
+        const double dz = (double)z, dy = (double)y, dx = (double)x;
+        const double fz = ((A.m[0] * dz + A.m[1] * dy) + A.m[2] * dx) + A.m[3];
+        const double fy = ((A.m[4] * dz + A.m[5] * dy) + A.m[6] * dx) + A.m[7];
+        const double fx = ((A.m[8] * dz + A.m[9] * dy) + A.m[10] * dx) + A.m[11];
+        double v = 0.0;
+        if (fz > -1.0 && fz < (double)iz && fy > -1.0 && fy < (double)iy && fx > -1.0 && fx < (double)ix)
+            v = lerp3_u16(in, iz, iy, ix, fz, fy, fx, true);
+        out[i] = (uint16_t)fmin(fmax(floor(v + 0.5), 0.0), 65535.0);
     }
 }
 
@@ -195,6 +235,27 @@ int dlv_trilinear_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy, 
                        iy, ix, out_dev, oz, oy, ox);
     p.end();
     DLV_LAUNCH_CHECK(ctx, "trilinear_u16_kernel");
+    return DLV_OK;
+}
+
+/* the north-star's "affine atlas-space warp" (BASELINE config 5): the reference itself warps cell coordinates with
+ * external mBrainAligner binaries (automate_mBrainaligner.py:21-72, :292-435) and has no volume warp; this entry point
+ * resamples a volume through a 3x4 affine map given in index space. */
+int dlv_affine_warp_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy, int ix, const double* matrix34, uint16_t* out_dev,
+                            int oz, int oy, int ox) {
+    if (!ctx || !in_dev || !out_dev || !matrix34) return DLV_EINVAL;
+    if (iz <= 0 || iy <= 0 || ix <= 0 || oz <= 0 || oy <= 0 || ox <= 0) return dlv_fail(ctx, DLV_EINVAL, "bad shape");
+    Affine34 A;
+    for (int k = 0; k < 12; ++k) {
+        if (!(matrix34[k] == matrix34[k]) || matrix34[k] > 1e12 || matrix34[k] < -1e12) return dlv_fail(ctx, DLV_EINVAL, "matrix entry %d is not finite", k);
+        A.m[k] = matrix34[k];
+    }
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    DlvProf p(ctx, "affine_warp_u16", 0.0, 2.0 * oz * oy * ox + 2.0 * iz * iy * ix);
+    hipLaunchKernelGGL(affine_warp_u16_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev, iz, iy,
+                       ix, A, out_dev, oz, oy, ox);
+    p.end();
+    DLV_LAUNCH_CHECK(ctx, "affine_warp_u16_kernel");
     return DLV_OK;
 }
 

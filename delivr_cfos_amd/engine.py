@@ -468,6 +468,21 @@ class HipEngine:
         self._leave()
         return out
 
+    def affine_warp_u16(self, vol, matrix34, out_shape):
+        """uint16 (Z,Y,X) in HBM resampled through a 3x4 affine map (output voxel index -> input voxel index, index
+        space, zero outside, trilinear, round half up) - the north-star's atlas-space warp (dlv_affine_warp_u16_dev)."""
+        torch = self.torch
+        iz, iy, ix = (int(v) for v in vol.shape)
+        oz, oy, ox = (int(v) for v in out_shape)
+        m = np.ascontiguousarray(np.asarray(matrix34, dtype=np.float64).reshape(12))
+        out = torch.empty((oz, oy, ox), dtype=torch.uint16, device=self.device)
+        self._enter()
+        self._check(self.lib.dlv_affine_warp_u16_dev(self.ctx, self._dev(vol, torch.uint16, "vol"), iz, iy, ix,
+                                                     m.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     self._dev(out, torch.uint16, "out"), oz, oy, ox))
+        self._leave()
+        return out
+
     # ---- kernel timer ------------------------------------------------------------------------------
     def set_lanes(self, lanes: int):
         self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))

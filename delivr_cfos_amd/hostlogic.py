@@ -98,3 +98,14 @@ def max_window_multiplicity(starts, roi) -> int:
         ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]  # closings (-1) before openings (+1) at equal coordinates
         mult *= int(np.cumsum(ev[:, 1]).max())
     return mult
+
+
+def affine_apply(matrix34, coords_zyx):
+    """Maps (n,3) cell coordinates (z,y,x) found in a volume produced by HipEngine.affine_warp_u16 back into the index
+    space of its input: c_in = M . (c_out, 1) - the coordinate leg of BASELINE config 5 (the reference moves cell
+    coordinates, never volumes: automate_mBrainaligner.py:261-284 scales them, the registration binaries warp them)."""
+    import numpy as np
+
+    m = np.asarray(matrix34, dtype=np.float64).reshape(3, 4)
+    c = np.asarray(coords_zyx, dtype=np.float64).reshape(-1, 3)
+    return c @ m[:, :3].T + m[:, 3]

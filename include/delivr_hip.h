@@ -260,6 +260,13 @@ int dlv_mask_pad_u16_dev(dlv_ctx* ctx, const uint16_t* raw_dev, const uint8_t* m
  * clamp-to-edge, uint16 -> uint16 (round half up). */
 int dlv_trilinear_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy, int ix, uint16_t* out_dev,
                           int oz, int oy, int ox);
+/* north-star extension "affine atlas-space warp" (BASELINE config 5).  The reference has no volume warp: it registers with
+ * the external mBrainAligner binaries and moves cell COORDINATES (automate_mBrainaligner.py:21-72, :292-435).
+ * out[z,y,x] = trilinear sample of `in` at the index-space point matrix34 . (z,y,x,1) (row-major 3x4, host pointer: maps
+ * OUTPUT voxel indices to INPUT voxel indices), zero outside the input, round half up.  fp64 arithmetic, bit-exact
+ * against oracle.affine_warp_u16.  hostlogic.affine_apply maps cell coordinates found in the warped volume back. */
+int dlv_affine_warp_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy, int ix, const double* matrix34,
+                            uint16_t* out_dev, int oz, int oy, int ox);
 
 /* ---- in-library kernel timing (bench.py's roofline leg) ------------------------------------- */
 #define DLV_PROF_MAX_KERNELS 32

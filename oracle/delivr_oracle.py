@@ -552,3 +552,57 @@ def gaussian_importance_map(patch_size: Sequence[int], sigma_scale: float = 0.12
     m = m.float()
     mn = m[m != 0].min().item()
     return torch.clamp(m, min=mn).numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# north-star extensions without a reference counterpart: trilinear resample, affine warp
+# ----------------------------------------------------------------------------------------------
+
+
+def _lerp3(vol: np.ndarray, fz, fy, fx, zero_outside: bool) -> np.ndarray:
+    iz, iy, ix = vol.shape
+    z0f, y0f, x0f = np.floor(fz), np.floor(fy), np.floor(fx)
+    z0, y0, x0 = z0f.astype(np.int64), y0f.astype(np.int64), x0f.astype(np.int64)
+    tz, ty, tx = fz - z0f, fy - y0f, fx - x0f
+    v64 = vol.astype(np.float64)
+
+    def at(a, b, c):
+        if zero_outside:
+            ok = (a >= 0) & (a < iz) & (b >= 0) & (b < iy) & (c >= 0) & (c < ix)
+            return np.where(ok, v64[np.clip(a, 0, iz - 1), np.clip(b, 0, iy - 1), np.clip(c, 0, ix - 1)], 0.0)
+        return v64[np.clip(a, 0, iz - 1), np.clip(b, 0, iy - 1), np.clip(c, 0, ix - 1)]
+
+    c00 = at(z0, y0, x0) * (1.0 - tx) + at(z0, y0, x0 + 1) * tx
+    c01 = at(z0, y0 + 1, x0) * (1.0 - tx) + at(z0, y0 + 1, x0 + 1) * tx
+    c10 = at(z0 + 1, y0, x0) * (1.0 - tx) + at(z0 + 1, y0, x0 + 1) * tx
+    c11 = at(z0 + 1, y0 + 1, x0) * (1.0 - tx) + at(z0 + 1, y0 + 1, x0 + 1) * tx
+    c0 = c00 * (1.0 - ty) + c01 * ty
+    c1 = c10 * (1.0 - ty) + c11 * ty
+    return c0 * (1.0 - tz) + c1 * tz
+
+
+def trilinear_u16(vol: np.ndarray, out_shape: Sequence[int]) -> np.ndarray:
+    """align_corners=False (src = (dst + 0.5) * in/out - 0.5), clamp to edge, fp64, round half up - no reference
+    counterpart (the reference's resamplers are the block mean and the spline-2 zoom above); self-consistency spec."""
+    iz, iy, ix = vol.shape
+    oz, oy, ox = (int(v) for v in out_shape)
+    z, y, x = np.meshgrid(np.arange(oz, dtype=np.float64), np.arange(oy, dtype=np.float64), np.arange(ox, dtype=np.float64), indexing="ij")
+    fz = np.minimum(np.maximum((z + 0.5) * (iz / oz) - 0.5, 0.0), float(iz - 1))
+    fy = np.minimum(np.maximum((y + 0.5) * (iy / oy) - 0.5, 0.0), float(iy - 1))
+    fx = np.minimum(np.maximum((x + 0.5) * (ix / ox) - 0.5, 0.0), float(ix - 1))
+    v = _lerp3(vol, fz, fy, fx, False)
+    return np.minimum(np.maximum(np.floor(v + 0.5), 0.0), 65535.0).astype(np.uint16)
+
+
+def affine_warp_u16(vol: np.ndarray, matrix34, out_shape: Sequence[int]) -> np.ndarray:
+    """out[z,y,x] = trilinear sample of vol at M.(z,y,x,1) (index space), zero outside, round half up (fp64)."""
+    iz, iy, ix = vol.shape
+    oz, oy, ox = (int(v) for v in out_shape)
+    m = np.asarray(matrix34, dtype=np.float64).reshape(12)
+    z, y, x = np.meshgrid(np.arange(oz, dtype=np.float64), np.arange(oy, dtype=np.float64), np.arange(ox, dtype=np.float64), indexing="ij")
+    fz = ((m[0] * z + m[1] * y) + m[2] * x) + m[3]
+    fy = ((m[4] * z + m[5] * y) + m[6] * x) + m[7]
+    fx = ((m[8] * z + m[9] * y) + m[10] * x) + m[11]
+    inside = (fz > -1.0) & (fz < iz) & (fy > -1.0) & (fy < iy) & (fx > -1.0) & (fx < ix)
+    v = np.where(inside, _lerp3(vol, np.where(inside, fz, 0.0), np.where(inside, fy, 0.0), np.where(inside, fx, 0.0), True), 0.0)
+    return np.minimum(np.maximum(np.floor(v + 0.5), 0.0), 65535.0).astype(np.uint16)

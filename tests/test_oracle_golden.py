@@ -199,3 +199,23 @@ def test_unet_c1_64cube_reproduces_the_committed_samples(golden_dir):
     lg = orc.unet_forward(net, x.numpy())[0, 0]
     np.testing.assert_allclose(lg[::4, ::4, ::4], g["logits_s4"], atol=2e-5, rtol=0)
     assert abs(float(lg.astype(np.float64).std()) - float(g["std"])) < 1e-5
+
+
+def test_trilinear_and_affine_restatements_properties():
+    """North-star extensions without a reference counterpart: self-consistency of the fp64 restatements the
+    HIP kernels are held to - identity, integer translation with zero fill, constant volumes, 2x of a linear ramp."""
+    rng = np.random.default_rng(0)
+    v = rng.integers(0, 65535, size=(6, 7, 8)).astype(np.uint16)
+    assert np.array_equal(orc.trilinear_u16(v, v.shape), v)
+    ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+    assert np.array_equal(orc.affine_warp_u16(v, ident, v.shape), v)
+    w = orc.affine_warp_u16(v, [1, 0, 0, 1, 0, 1, 0, -2, 0, 0, 1, 0], v.shape)
+    assert np.array_equal(w[:5, 2:, :], v[1:, :5, :]) and w[5].sum() == 0 and w[:, :2].sum() == 0
+    c = np.full((4, 5, 6), 1234, dtype=np.uint16)
+    assert (orc.trilinear_u16(c, (9, 11, 13)) == 1234).all()
+    ramp = (np.arange(8, dtype=np.uint16) * 100)[None, None, :].repeat(2, 0).repeat(2, 1)
+    up = orc.trilinear_u16(ramp, (2, 2, 16))[0, 0]
+    assert list(up[1:15]) == [25 + 50 * i for i in range(14)] and up[0] == 0 and up[15] == 700  # clamp to edge
+    # half-voxel shift: the average of two neighbours, rounded half up
+    h = orc.affine_warp_u16(ramp, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.5], ramp.shape)[0, 0]
+    assert list(h[:7]) == [50 + 100 * i for i in range(7)] and h[7] == 350  # last: (700 + 0) / 2
