@@ -128,8 +128,8 @@ def main():
 
     from delivr_cfos_amd.engine import HipEngine
     from delivr_cfos_amd.hostlogic import arrayterator_zblock
-    from delivr_cfos_amd.parallel import broadcast_weights, exchange_seams, finalize_owned, gather_slabs, make_plan
-    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, gather_slabs, plan_from_params
+    from delivr_cfos_amd.synth import synth_planes_torch, synth_volume_torch
     from delivr_cfos_amd.weights import random_state_dict
 
     shape, roi, seed = WORKLOADS[args.workload]
@@ -141,22 +141,25 @@ def main():
     if world > 1:
         broadcast_weights(eng, dist, rank)
 
-    vol = synth_volume_torch(shape, seed, eng.device, dense=args.dense)
-    torch.cuda.synchronize()
     params_all = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch)
-    starts = eng.window_starts(params_all)
-    # shards balanced by the windows that actually run the network (a brain fills the central Z-slabs, not the
-    # outer ones); every rank holds the whole volume, so every rank derives the same plan
-    weights = None
-    if world > 1:
-        wmax = eng.window_max(params_all, vol)
-        weights = np.where(wmax > 0, 1.0, 0.02)
-    plan = make_plan(starts, roi[0], Z, world, weights)
+    nb = arrayterator_zblock((Z, Y, X))
+    if world == 1:
+        vol = synth_volume_torch(shape, seed, eng.device, dense=args.dense)
+        torch.cuda.synchronize()
+        plan = plan_from_params(params_all, 1, None)
+        slo, shi = 0, Z
+    else:
+        # slab-resident: every rank generates (a real run: reads) and holds only the planes of ITS Z-slab; the shards are
+        # balanced by the windows that actually run the network (a brain fills the central slabs, not the outer ones)
+        plan, slo, shi, vol = balanced_plan(
+            eng, params_all, lambda lo, hi: synth_planes_torch(shape, seed, eng.device, lo, hi, dense=args.dense), world, rank,
+            dist, Z, 30, nb)
     wb, we = plan.win_ranges[rank]
-    params = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, win_range=(wb, we))
+    params = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, win_range=(wb, we),
+                                slab=(slo, shi - slo))
     if we <= wb:  # a rank without windows still takes part in the exchange
         params = None
-    acc = torch.zeros(shape, dtype=torch.float32, device=eng.device)
+    acc = torch.zeros((shi - slo, Y, X), dtype=torch.float32, device=eng.device)
     mask_full = torch.empty(shape, dtype=torch.uint8, device=eng.device) if (world > 1 and rank == 0) else None
 
     stats_last = {}
@@ -167,8 +170,8 @@ def main():
             stats_last.update(eng.sw_infer(params, vol, acc))
         if world > 1:
             eng.sync()
-            exchange_seams(acc, plan, rank, dist)
-        slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30)
+            exchange_seams(acc, plan, rank, dist, z0=slo)
+        slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30, z0=slo)
         if slab is None:
             slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
         if world > 1:

@@ -63,6 +63,16 @@ class SwStats(C.Structure):
     _fields_ = [("n_windows", C.c_int64), ("n_skipped", C.c_int64), ("n_forward_launches", C.c_int64)]
 
 
+MAX_RANKS = 16
+
+
+class ShardPlanC(C.Structure):
+    _fields_ = [("world", C.c_int), ("n_windows", C.c_int64),
+                ("win_begin", C.c_int64 * MAX_RANKS), ("win_end", C.c_int64 * MAX_RANKS),
+                ("z_comp_lo", C.c_int * MAX_RANKS), ("z_comp_hi", C.c_int * MAX_RANKS),
+                ("z_own_lo", C.c_int * MAX_RANKS), ("z_own_hi", C.c_int * MAX_RANKS)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -91,6 +101,18 @@ SIGNATURES = {
     "dlv_sw_window_starts": (C.c_int, [C.POINTER(SwParams), C.POINTER(C.c_int64), C.c_int64]),
     "dlv_sw_window_max_dev": (C.c_int, [_P, C.POINTER(SwParams), _P, C.POINTER(C.c_int32), C.c_int64]),
     "dlv_sw_infer_dev": (C.c_int, [_P, C.POINTER(SwParams), _P, _P, _P, C.POINTER(SwStats)]),
+    "dlv_shard_plan_make": (C.c_int, [C.POINTER(SwParams), C.c_int, C.POINTER(C.c_float), C.POINTER(ShardPlanC)]),
+    "dlv_shard_slab": (C.c_int, [C.POINTER(ShardPlanC), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dlv_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "dlv_comm_destroy": (C.c_int, [_P]),
+    "dlv_comm_size": (C.c_int, [_P]),
+    "dlv_comm_ctx": (_P, [_P, C.c_int]),
+    "dlv_comm_last_error": (C.c_char_p, [_P]),
+    "dlv_bcast_weights": (C.c_int, [_P, C.c_int]),
+    "dlv_sw_infer_sharded": (C.c_int, [_P, C.POINTER(SwParams), C.POINTER(ShardPlanC), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(SwStats)]),
+    "dlv_finalize_slab_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                        C.c_int, _P, _P]),
     "dlv_finalize_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                    C.c_int, _P, _P]),
     "dlv_ccl26_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]),

@@ -89,17 +89,18 @@ __global__ void __launch_bounds__(256) erode_y_kernel(uint8_t* __restrict__ dist
 template <int V>
 __global__ void __launch_bounds__(256) erode_z_final_kernel(uint8_t* __restrict__ dist, const float* __restrict__ acc,
                                                             const uint8_t* __restrict__ cnt, int Yp, int Xp, int Z,
-                                                            int Y, int X, int zblock, int radius, float threshold,
+                                                            int Y, int X, int zblock, int zphase, int radius, float threshold,
                                                             uint8_t* __restrict__ out, float* __restrict__ prob) {
     const int xv = X / V;
     const long long per_block = (long long)Y * xv;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nblk = (Z + zblock - 1) / zblock;
+    // z-blocks at absolute multiples of zblock; local plane z is absolute plane z + zphase (mod zblock)
+    const int nblk = (Z + zphase + zblock - 1) / zblock;
     if (t >= per_block * nblk) return;
     const int blk = (int)(t / per_block);
     const long long r = t % per_block;
     const int x = (int)(r % xv) * V, y = (int)(r / xv);
-    const int zb0 = blk * zblock, zb1 = min(zb0 + zblock, Z);
+    const int zb0 = max(blk * zblock - zphase, 0), zb1 = min((blk + 1) * zblock - zphase, Z);
     const long long plane = (long long)Y * X;
     uint8_t* col = dist + (long long)y * X + x;
     unsigned prev = U8V<V>::ld(col + zb0 * plane);
@@ -129,15 +130,33 @@ __global__ void __launch_bounds__(256) erode_z_final_kernel(uint8_t* __restrict_
 
 }  // namespace
 
+static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev, int Yp, int Xp, int Z,
+                         int Y, int X, float threshold, int erode_iters, int zblock, int zphase, uint8_t* out_dev, float* prob_dev);
+
 extern "C" int dlv_finalize_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev,
                                 int Yp, int Xp, int Z, int Y, int X, float threshold, int erode_iters, int zblock,
                                 uint8_t* out_dev, float* prob_dev) {
+    if (Z > 0 && (zblock <= 0 || zblock > Z)) zblock = Z;
+    return finalize_impl(ctx, acc_dev, cnt_dev, raw_dev, Yp, Xp, Z, Y, X, threshold, erode_iters, zblock, 0, out_dev, prob_dev);
+}
+
+extern "C" int dlv_finalize_slab_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev, int Yp,
+                                     int Xp, int z_abs0, int nz, int Y, int X, float threshold, int erode_iters, int zblock,
+                                     uint8_t* out_dev, float* prob_dev) {
+    if (z_abs0 < 0) return DLV_EINVAL;
+    if (zblock <= 0) zblock = 0x3fffffff;  // one block: the whole stack
+    return finalize_impl(ctx, acc_dev, cnt_dev, raw_dev, Yp, Xp, nz, Y, X, threshold, erode_iters, zblock, z_abs0 % zblock, out_dev,
+                         prob_dev);
+}
+
+static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev, int Yp, int Xp, int Z,
+                         int Y, int X, float threshold, int erode_iters, int zblock, int zphase, uint8_t* out_dev, float* prob_dev) {
     if (!ctx || !acc_dev || !raw_dev || !out_dev) return DLV_EINVAL;
     if (Z <= 0 || Y <= 0 || X <= 0 || Y > Yp || X > Xp) return dlv_fail(ctx, DLV_EINVAL, "bad shapes");
     if (erode_iters < 0 || erode_iters > 253) return dlv_fail(ctx, DLV_EUNSUP, "erode_iters must be in [0,253]");
     if (2 * (size_t)X > 160 * 1024) return dlv_fail(ctx, DLV_EUNSUP, "X=%d exceeds the LDS row buffer", X);
     DLV_HIP(ctx, hipSetDevice(ctx->device));
-    if (zblock <= 0 || zblock > Z) zblock = Z;
+    if (zblock <= 0) zblock = Z;
     const int cap = erode_iters + 1;
     uint8_t* dist;
     const long long nvox = (long long)Z * Y * X;
@@ -162,15 +181,15 @@ extern "C" int dlv_finalize_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_
         DLV_LAUNCH_CHECK(ctx, "erode_y_kernel");
     }
     {
-        const int nblk = (Z + zblock - 1) / zblock;
+        const int nblk = (int)(((long long)Z + zphase + zblock - 1) / zblock);
         DlvProf p(ctx, "erode_z_final", 0.0, (4.0 + 4.0 + 1.0) * nvox);
         if (v4)
             hipLaunchKernelGGL(erode_z_final_kernel<4>, dim3(dlv_cdiv((long long)nblk * Y * (X / 4), 256)), dim3(256), 0,
-                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, erode_iters, threshold,
+                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
                                out_dev, prob_dev);
         else
             hipLaunchKernelGGL(erode_z_final_kernel<1>, dim3(dlv_cdiv((long long)nblk * Y * X, 256)), dim3(256), 0,
-                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, erode_iters, threshold,
+                               ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
                                out_dev, prob_dev);
         p.end();
         DLV_LAUNCH_CHECK(ctx, "erode_z_final_kernel");

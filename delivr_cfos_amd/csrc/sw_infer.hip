@@ -194,21 +194,27 @@ int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* 
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     Tiler t;
     DLV_TRY(build_tiler(ctx, p, t));
-    const int64_t n = t.count();
+    const int64_t total = t.count();
+    // the shard of the window list (win_begin/win_end) and the slab of the volume (z0/nz) are honoured: a rank of a
+    // sharded run computes the maxima of its own windows from the planes it holds; wmax[i] belongs to window win_begin + i
+    const int64_t wb = std::max<int64_t>(p->win_begin, 0);
+    const int64_t we = p->win_end > 0 ? std::min<int64_t>(p->win_end, total) : total;
+    const int64_t n = std::max<int64_t>(we - wb, 0);
     if (capacity < n) return dlv_fail(ctx, DLV_EINVAL, "wmax capacity %lld < %lld windows", (long long)capacity, (long long)n);
+    if (n == 0) return DLV_OK;
     if (n > (int64_t)1 << 30) return dlv_fail(ctx, DLV_EUNSUP, "too many windows");
     const int z0 = p->nz > 0 ? p->z0 : 0, nz = p->nz > 0 ? p->nz : p->Zp;
+    const int ny = (int)t.st[1].size(), nx = (int)t.st[2].size();
     std::vector<int> starts((size_t)n * 3);
-    int64_t i = 0;
-    for (int z : t.st[0])
-        for (int y : t.st[1])
-            for (int x : t.st[2]) {
-                if (z < z0 || z + t.roi[0] > z0 + nz) return dlv_fail(ctx, DLV_EINVAL, "window outside the slab");
-                starts[3 * i] = z - z0;
-                starts[3 * i + 1] = y;
-                starts[3 * i + 2] = x;
-                ++i;
-            }
+    for (int64_t g = wb; g < we; ++g) {
+        const int iz = (int)(g / ((int64_t)ny * nx)), iy = (int)((g / nx) % ny), ix = (int)(g % nx);
+        const int z = t.st[0][iz];
+        if (z < z0 || z + t.roi[0] > z0 + nz) return dlv_fail(ctx, DLV_EINVAL, "window %lld outside the slab", (long long)g);
+        const int64_t i = g - wb;
+        starts[3 * i] = z - z0;
+        starts[3 * i + 1] = t.st[1][iy];
+        starts[3 * i + 2] = t.st[2][ix];
+    }
     int* meta;
     DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, (size_t)n * 4 * sizeof(int), (void**)&meta));
     DLV_HIP(ctx, hipMemcpyAsync(meta, starts.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));

@@ -43,8 +43,73 @@ def strip_state_dict(checkpoint) -> Dict[str, "np.ndarray"]:
     return out
 
 
+class HipComm:
+    """One process, N devices: dlv_comm_init_all / dlv_bcast_weights / dlv_sw_infer_sharded (the C-ABI form of the
+    DataParallel replacement; the multi-process form lives in parallel.py).  `engines[r]` drives rank r's context."""
+
+    def __init__(self, devices: Sequence[int]):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("delivr_cfos_amd needs an MI355X: there is no CPU fallback for the HIP path")
+        self.torch = torch
+        self.lib = _lib.load()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = self.lib.dlv_comm_init_all(len(self.devices), arr, C.byref(h))
+        if rc != 0:
+            raise DelivrHipError(rc, "dlv_comm_init_all failed (several devices need librccl.so)")
+        self.handle = h
+        self.engines = [HipEngine(d, _ctx=C.c_void_p(self.lib.dlv_comm_ctx(h, r))) for r, d in enumerate(self.devices)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dlv_comm_destroy(self.handle)
+            self.handle = None
+            for e in self.engines:
+                e.ctx = None
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DelivrHipError(rc, self.lib.dlv_comm_last_error(self.handle).decode(errors="replace"))
+
+    def bcast_weights(self, root: int = 0):
+        self._check(self.lib.dlv_bcast_weights(self.handle, int(root)))
+        for e in self.engines:
+            e.features = self.engines[root].features
+
+    def make_plan(self, params, weights=None):
+        from .parallel import plan_from_params
+
+        return plan_from_params(params, len(self.devices), weights)
+
+    def sw_infer_sharded(self, params, plan, slabs, vols, accs, cnts=None):
+        """slabs[r] = (z0, nz); vols / accs / cnts: per-rank tensors on devices[r] holding those planes."""
+        n = len(self.devices)
+        pc = _lib.ShardPlanC()
+        pc.world, pc.n_windows = n, plan.n_windows
+        for r in range(n):
+            pc.win_begin[r], pc.win_end[r] = plan.win_ranges[r]
+            pc.z_comp_lo[r], pc.z_comp_hi[r] = plan.z_computed[r]
+            pc.z_own_lo[r], pc.z_own_hi[r] = plan.z_owned[r]
+        z0 = (C.c_int * n)(*[int(s[0]) for s in slabs])
+        nz = (C.c_int * n)(*[int(s[1]) for s in slabs])
+        torch = self.torch
+        vp = (C.c_void_p * n)(*[self.engines[r]._dev(vols[r], torch.uint16, "vol").value for r in range(n)])
+        ap = (C.c_void_p * n)(*[self.engines[r]._dev(accs[r], torch.float32, "acc").value for r in range(n)])
+        cp = None
+        if cnts is not None:
+            cp = (C.c_void_p * n)(*[self.engines[r]._dev(cnts[r], torch.uint8, "cnt").value for r in range(n)])
+        st = (_lib.SwStats * n)()
+        for d in set(self.devices):
+            torch.cuda.synchronize(d)
+        self._check(self.lib.dlv_sw_infer_sharded(self.handle, C.byref(params), C.byref(pc), z0, nz, vp, ap, cp, st))
+        return [{"n_windows": s.n_windows, "n_skipped": s.n_skipped, "n_forward_launches": s.n_forward_launches} for s in st]
+
+
 class HipEngine:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _ctx=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -54,20 +119,27 @@ class HipEngine:
         self.lib = _lib.load()
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
+        self.features: Optional[Tuple[int, ...]] = None
+        self._keep = []
+        self._owns_ctx = _ctx is None
+        if _ctx is not None:
+            # a context owned by a HipComm: it runs on its own stream (dlv_stream); torch work is ordered against it by
+            # device-wide synchronisation in _enter/_leave
+            self.ctx = _ctx
+            self.tstream = torch.cuda.ExternalStream(self.lib.dlv_stream(_ctx), device=self.device)
+            return
         self.tstream = torch.cuda.Stream(device=self.device)
         ctx = C.c_void_p()
         rc = self.lib.dlv_ctx_create(self.device_index, C.c_void_p(self.tstream.cuda_stream), C.byref(ctx))
         if rc != 0:
             raise DelivrHipError(rc, "dlv_ctx_create failed")
         self.ctx = ctx
-        self.features: Optional[Tuple[int, ...]] = None
-        self._keep = []
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def close(self):
-        if getattr(self, "ctx", None):
+        if getattr(self, "ctx", None) and getattr(self, "_owns_ctx", True):
             self.lib.dlv_ctx_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def __del__(self):
         try:
@@ -111,6 +183,35 @@ class HipEngine:
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)
         return t.to(self.device).contiguous()
+
+    def upload_volume(self, arr, z_lo: int = 0, z_hi: Optional[int] = None, chunk_bytes: int = 256 << 20):
+        """Host uint16 volume (numpy array or memmap, (..., Z, Y, X)) -> planes [z_lo, z_hi) in HBM, streamed through two
+        pinned staging buffers in z-chunks: no whole-volume pageable copy is made of a memmapped .npy (the reference
+        memmaps the file too, inference/inference.py:234) and a rank of a sharded run reads only the planes of its slab."""
+        torch = self.torch
+        a = arr
+        lead = a.shape[:-3]
+        if any(int(v) != 1 for v in lead):
+            raise ValueError("one volume, one channel expected")
+        view = a.reshape(a.shape[-3:]) if isinstance(a, np.ndarray) else np.asarray(a).reshape(a.shape[-3:])
+        Z, Y, X = (int(v) for v in view.shape)
+        z_hi = Z if z_hi is None else int(z_hi)
+        out = torch.empty(tuple(int(v) for v in lead) + (z_hi - z_lo, Y, X), dtype=torch.uint16, device=self.device)
+        flat = out.reshape(z_hi - z_lo, Y, X)
+        per = max(1, int(chunk_bytes // max(Y * X * 2, 1)))
+        stage = [torch.empty((per, Y, X), dtype=torch.uint16).pin_memory() for _ in range(2)]
+        evs = [torch.cuda.Event(), torch.cuda.Event()]
+        with torch.cuda.device(self.device):
+            for i, z0 in enumerate(range(z_lo, z_hi, per)):
+                z1 = min(z0 + per, z_hi)
+                b = i & 1
+                if i >= 2:
+                    evs[b].synchronize()  # the copy that read this staging buffer has finished
+                np.copyto(stage[b][: z1 - z0].numpy(), view[z0:z1], casting="no")
+                flat[z0 - z_lo: z1 - z_lo].copy_(stage[b][: z1 - z0], non_blocking=True)
+                evs[b].record()
+            torch.cuda.synchronize(self.device)
+        return out
 
     # ---- weights -----------------------------------------------------------------------------------
     def load_state_dict(self, checkpoint) -> None:
@@ -255,7 +356,11 @@ class HipEngine:
     def window_max(self, params, vol) -> np.ndarray:
         """Per-window maximum (int32, reference window order): windows with max <= skip_threshold are background."""
         n = self.num_windows(params)
+        if params.win_end > 0 or params.win_begin > 0:  # a shard of the window list: out[i] = window win_begin + i
+            n = max(min(int(params.win_end) if params.win_end > 0 else n, n) - max(int(params.win_begin), 0), 0)
         out = np.zeros(n, dtype=np.int32)
+        if n == 0:
+            return out
         self._enter()
         self._check(self.lib.dlv_sw_window_max_dev(self.ctx, C.byref(params), self._dev(vol, self.torch.uint16, "vol"),
                                                    out.ctypes.data_as(C.POINTER(C.c_int32)), n))
@@ -291,6 +396,26 @@ class HipEngine:
             self.ctx, self._dev(acc, torch.float32, "acc"),
             self._dev(cnt, torch.uint8, "cnt") if cnt is not None else None, self._dev(raw, torch.uint16, "raw"),
             Yp, Xp, Z, Y, X, float(threshold), int(erode_iters), int(zblock),
+            self._dev(out, torch.uint8, "out"), self._dev(prob, torch.float32, "prob") if want_prob else None))
+        self._leave()
+        return (out, prob) if want_prob else out
+
+    def finalize_slab(self, acc, cnt, raw, z_abs0: int, stack_yx, threshold=0.5, erode_iters=30, zblock=0, want_prob=False):
+        """finalize on a Z-slab: acc / cnt / raw hold planes [z_abs0, z_abs0 + nz) (nz = acc.shape[0]); the erosion's z-blocks
+        sit at absolute multiples of zblock (dlv_finalize_slab_dev).  -> uint8 (nz, Y, X) [, fp32 sigmoid]."""
+        torch = self.torch
+        nz = int(acc.shape[0])
+        Y, X = (int(v) for v in stack_yx)
+        Yp, Xp = int(acc.shape[-2]), int(acc.shape[-1])
+        if cnt is not None and cnt.dtype == torch.float32:
+            acc = acc / cnt.clamp_min(torch.finfo(torch.float32).tiny)
+            cnt = None
+        out = torch.empty((nz, Y, X), dtype=torch.uint8, device=self.device)
+        prob = torch.empty((nz, Y, X), dtype=torch.float32, device=self.device) if want_prob else None
+        self._enter()
+        self._check(self.lib.dlv_finalize_slab_dev(
+            self.ctx, self._dev(acc, torch.float32, "acc"), self._dev(cnt, torch.uint8, "cnt") if cnt is not None else None,
+            self._dev(raw, torch.uint16, "raw"), Yp, Xp, int(z_abs0), nz, Y, X, float(threshold), int(erode_iters), int(zblock),
             self._dev(out, torch.uint8, "out"), self._dev(prob, torch.float32, "prob") if want_prob else None))
         self._leave()
         return (out, prob) if want_prob else out

@@ -122,17 +122,19 @@ def run_inference(
     stack_shape = tuple(int(v) for v in stack_shape)
     pad = (1, 1) + padded_shape(stack_shape[2:], crop_size)
     dataset_host = np.memmap(niftis[0], dtype=np.uint16, mode="r", shape=pad, offset=128)
-    dataset = eng.to_device(np.ascontiguousarray(dataset_host[0, 0]))
+    if not sharded:
+        dataset = eng.upload_volume(dataset_host[0, 0])  # chunked through pinned staging buffers
     if rank == 0:
         os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
     save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
-    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
+    # (one process per GPU: the buffers below are allocated per slab further down)
     # The count map is needed whenever the MEAN logit matters: for network_output.npy and for any threshold other than
     # 0.5 (reference: mean = sum / count before the sigmoid, inference.py:295); at 0.5 the sign of the sum decides.
     need_count = save_activated or float(threshold) != 0.5
-    count_map = (torch.zeros(pad[2:], dtype=torch.float32 if gaussian else torch.uint8, device=eng.device)
-                 if need_count else None)
-    if count_map is not None and count_map.dtype == torch.uint8:
+    cm_dtype = torch.float32 if gaussian else torch.uint8
+    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device) if not sharded else None
+    count_map = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device) if (need_count and not sharded) else None
+    if need_count and cm_dtype == torch.uint8:
         # uint8 like the reference's LOAD_ALL_RAM map (:241): refuse geometries whose multiplicity cannot be held
         from ..hostlogic import max_window_multiplicity
 
@@ -141,7 +143,7 @@ def run_inference(
         if mult > 255:
             raise NotImplementedError(f"up to {mult} (window, pass) contributions per voxel do not fit the uint8 count map "
                                       "(overlap too large for this threshold / SAVE_ACTIVATED_OUTPUT setting)")
-    print("output_image shape", tuple(output_image.shape))
+    print("output_image shape", tuple(pad[2:]))
 
     testing_session_path = os.path.abspath(output_folder + "/" + comment)
     binaries_path = testing_session_path + "/binary_segmentations/"
@@ -166,28 +168,34 @@ def run_inference(
                          network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
                          count_map=count_map, engine=eng)
     else:
-        from ..parallel import exchange_seams, finalize_owned, gather_slabs, make_plan
+        from ..hostlogic import arrayterator_zblock
+        from ..parallel import balanced_plan, exchange_seams, finalize_owned, gather_slabs
 
-        Zp = pad[2]
+        # Slab-resident: every rank reads, uploads and accumulates only the planes of ITS Z-slab (its windows' planes and
+        # the erosion margin of the planes it owns); the plan is balanced by the windows that run the network.
+        Z, Y, X = stack_shape[2:]
         p_all = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
-        wmax = eng.window_max(p_all, dataset)
-        plan = make_plan(eng.window_starts(p_all), int(p_all.roi[0]), Zp, world, np.where(wmax > 0, 1.0, 0.02))
+        plan, slo, shi, dataset = balanced_plan(
+            eng, p_all, lambda lo, hi: eng.upload_volume(dataset_host[0, 0], lo, hi), world, rank, dist, Z, 30,
+            arrayterator_zblock((Z, Y, X)))
+        output_image = torch.zeros((shi - slo,) + tuple(pad[3:]), dtype=torch.float32, device=eng.device)
+        count_map = torch.zeros((shi - slo,) + tuple(pad[3:]), dtype=cm_dtype, device=eng.device) if need_count else None
         for flip_dim, repeat in pass_schedule(bool(tta)):
             wb, we = plan.win_ranges[rank]
             if we > wb:
                 if gaussian:
                     eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
-                                                    repeat=repeat, blend="gaussian", wsum=count_map), dataset, output_image)
+                                                    slab=(slo, shi - slo), repeat=repeat, blend="gaussian", wsum=count_map),
+                                 dataset, output_image)
                 else:
                     eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
-                                                    repeat=repeat), dataset, output_image, count_map)
+                                                    slab=(slo, shi - slo), repeat=repeat), dataset, output_image, count_map)
         eng.sync()
-        exchange_seams(output_image, plan, rank, dist)
+        exchange_seams(output_image, plan, rank, dist, z0=slo)
         if count_map is not None:
-            exchange_seams(count_map, plan, rank, dist)
-        Z, Y, X = stack_shape[2:]
+            exchange_seams(count_map, plan, rank, dist, z0=slo)
         slab, prob, _ = finalize_owned(eng, plan, rank, output_image, count_map, dataset, (Z, Y, X), threshold, 30,
-                                       want_prob=save_activated)
+                                       want_prob=save_activated, z0=slo)
         eng.sync()
         if slab is None:
             slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)

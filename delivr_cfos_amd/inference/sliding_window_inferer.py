@@ -22,7 +22,9 @@ from ..model import HipBasicUNet
 
 __all__ = ["sliding_window_inference", "SlidingWindowInferer"]
 
-_upload_cache = {}
+# one uploaded host volume: (the host object itself, device index, tensor).  The OBJECT is kept, not its id(): while it is
+# referenced here its id cannot be handed to another array, so a stale volume can never be returned for a new input.
+_upload_cache = []
 
 
 def _device_volume(inputs, engine):
@@ -33,12 +35,13 @@ def _device_volume(inputs, engine):
     if isinstance(inputs, torch.Tensor) and inputs.is_cuda:
         t = inputs
     else:
-        key = (id(inputs), engine.device_index)
-        t = _upload_cache.get(key)
+        t = None
+        if _upload_cache and _upload_cache[0][0] is inputs and _upload_cache[0][1] == engine.device_index:
+            t = _upload_cache[0][2]
         if t is None or tuple(t.shape) != tuple(inputs.shape):
             _upload_cache.clear()
-            t = engine.to_device(np.asarray(inputs))
-            _upload_cache[key] = t
+            t = engine.upload_volume(inputs)
+            _upload_cache.append((inputs, engine.device_index, t))
     if t.dim() == 5:
         if t.shape[0] != 1 or t.shape[1] != 1:
             raise ValueError("inputs must be (1,1,Z,Y,X) (one volume, one channel)")

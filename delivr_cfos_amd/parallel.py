@@ -38,6 +38,19 @@ class ShardPlan:
     z_computed: List[Tuple[int, int]]      # planes [lo, hi) a rank's windows touch (empty: (0, 0))
     z_owned: List[Tuple[int, int]]         # planes [lo, hi) a rank finalizes (partition of [0, Zp))
 
+    def slab(self, rank: int, Z: int, erode_iters: int = 30, zblock: int = 0) -> Tuple[int, int]:
+        """Planes [lo, hi) `rank` must hold: its windows' planes and the planes it owns, extended by `erode_iters`
+        planes inside their z-blocks (what the eroded re-mask of the owned planes looks at) - dlv_shard_slab."""
+        lo, hi = self.z_computed[rank]
+        olo, ohi = self.z_owned[rank]
+        ohi = min(ohi, Z)
+        if ohi > olo:
+            nb = zblock if zblock > 0 else Z
+            elo = max(olo - erode_iters, (olo // nb) * nb)
+            ehi = min(ohi + erode_iters, min(((ohi - 1) // nb + 1) * nb, Z))
+            lo, hi = (elo, ehi) if hi <= lo else (min(lo, elo), max(hi, ehi))
+        return lo, max(hi, lo)
+
     def sends(self, rank: int) -> List[Tuple[int, int, int]]:
         """(dst, lo, hi): plane ranges `rank` computed that another rank owns."""
         out = []
@@ -120,6 +133,67 @@ def make_plan(starts: np.ndarray, roi_z: int, Zp: int, world: int, weights: Opti
     return ShardPlan(world, n, win_ranges, z_computed, owned)
 
 
+def plan_from_params(params, world: int, weights: Optional[np.ndarray] = None) -> ShardPlan:
+    """The same plan from the C ABI (dlv_shard_plan_make: what a host without Python uses); `params`: _lib.SwParams."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    out = _lib.ShardPlanC()
+    wp = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    rc = lib.dlv_shard_plan_make(C.byref(params), int(world), wp, C.byref(out))
+    if rc != 0:
+        raise _lib.DelivrHipError(rc, "dlv_shard_plan_make: bad geometry or world size")
+    return ShardPlan(int(world), int(out.n_windows), [(int(out.win_begin[r]), int(out.win_end[r])) for r in range(world)],
+                     [(int(out.z_comp_lo[r]), int(out.z_comp_hi[r])) for r in range(world)],
+                     [(int(out.z_own_lo[r]), int(out.z_own_hi[r])) for r in range(world)])
+
+
+def balanced_plan(engine, params, fetch_planes, world: int, rank: int, dist, Z: int, erode_iters: int = 30, zblock: int = 0):
+    """Slab-resident sharding of one volume: no rank ever holds (or reads) the whole volume.
+      1. unweighted plan -> every rank fetches the planes of ITS window range (`fetch_planes(lo, hi)` -> uint16 tensor
+         (hi-lo, Yp, Xp) in HBM: a slice of the host memmap, or a generated chunk) and computes the maxima of its windows,
+      2. one small all_gather of the maxima -> plan balanced by the windows that actually run the network,
+      3. every rank completes its final slab (planes it already holds are re-used).
+    Returns (plan, slab_lo, slab_hi, vol_slab)."""
+    import torch
+
+    from . import _lib
+
+    plan0 = plan_from_params(params, world, None)
+    wb, we = plan0.win_ranges[rank]
+    lo0, hi0 = plan0.z_computed[rank]
+    vol0 = fetch_planes(lo0, hi0) if hi0 > lo0 else None
+    if we > wb:
+        q = _lib.SwParams.from_buffer_copy(params)
+        q.win_begin, q.win_end, q.z0, q.nz = wb, we, lo0, hi0 - lo0
+        mine = engine.window_max(q, vol0)
+    else:
+        mine = np.zeros(0, dtype=np.int32)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    wmax = np.concatenate([np.asarray(x, dtype=np.int32) for x in parts])
+    plan = plan_from_params(params, world, np.where(wmax > params.skip_threshold, 1.0, 0.02).astype(np.float32))
+    lo, hi = plan.slab(rank, Z, erode_iters, zblock)
+    if hi <= lo:
+        return plan, lo, lo, torch.empty((0, int(params.Yp), int(params.Xp)), dtype=torch.uint16, device=engine.device)
+    vol = torch.empty((hi - lo, int(params.Yp), int(params.Xp)), dtype=torch.uint16, device=engine.device)
+    have_lo, have_hi = (max(lo, lo0), min(hi, hi0)) if vol0 is not None else (lo, lo)
+    if have_hi > have_lo:
+        vol[have_lo - lo: have_hi - lo] = vol0[have_lo - lo0: have_hi - lo0]
+        if lo < have_lo:
+            vol[: have_lo - lo] = fetch_planes(lo, have_lo)
+        if have_hi < hi:
+            vol[have_hi - lo:] = fetch_planes(have_hi, hi)
+    else:
+        vol[:] = fetch_planes(lo, hi)
+    return plan, lo, hi, vol
+
+
 def _needs_host_staging(t, dist) -> bool:
     """gloo moves CPU tensors only for point-to-point; RCCL ("nccl") moves HBM directly over xGMI."""
     try:
@@ -128,10 +202,10 @@ def _needs_host_staging(t, dist) -> bool:
         return False
 
 
-def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None) -> None:
-    """acc: (Zp, Yp, Xp) fp32 tensor (full padded extent on every rank; only the computed planes are
-    non-zero).  After the call the planes owned by `rank` hold the complete sum.  Contributions are
-    added in increasing source-rank order so that the result does not depend on arrival order."""
+def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None, z0: int = 0) -> None:
+    """acc: fp32 (or uint8 count) tensor holding planes [z0, z0 + acc.shape[0]) of the padded volume - the rank's slab
+    (z0 = 0 with the full extent also works).  After the call the planes owned by `rank` hold the complete sum.
+    Contributions are added in increasing source-rank order so that the result does not depend on arrival order."""
     import torch
 
     stage = _needs_host_staging(acc, dist)
@@ -139,17 +213,17 @@ def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None) -> None:
     recvs = plan.recvs(rank)
     ops, bufs = [], []
     for dst, lo, hi in sends:
-        t = acc[lo:hi].contiguous()
+        t = acc[lo - z0:hi - z0].contiguous()
         ops.append(dist.P2POp(dist.isend, t.cpu() if stage else t, dst, group=group))
     for src, lo, hi in recvs:
-        buf = torch.empty_like(acc[lo:hi], device="cpu") if stage else torch.empty_like(acc[lo:hi])
+        buf = torch.empty_like(acc[lo - z0:hi - z0], device="cpu") if stage else torch.empty_like(acc[lo - z0:hi - z0])
         bufs.append((src, lo, hi, buf))
         ops.append(dist.P2POp(dist.irecv, buf, src, group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for src, lo, hi, buf in sorted(bufs, key=lambda t: t[0]):
-        acc[lo:hi] += buf.to(acc.device) if stage else buf
+        acc[lo - z0:hi - z0] += buf.to(acc.device) if stage else buf
 
 
 def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]] = None, src: int = 0, group=None) -> None:
@@ -202,11 +276,12 @@ def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0,
 
 
 def finalize_owned(engine, plan: ShardPlan, rank: int, acc, cnt, vol, stack_shape, threshold=0.5, erode_iters=30,
-                   want_prob=False):
-    """Threshold + eroded re-mask of the planes `rank` owns.  The erosion is evaluated on the reference's
-    Arrayterator z-block grid (inference/inference.py:53), so the sub-volume handed to the kernel starts and
-    ends on block boundaries; every rank holds the whole raw volume, only the accumulator is sharded.
-    Returns (slab uint8 (n_owned, Y, X), prob or None, (lo, hi))."""
+                   want_prob=False, z0: int = 0):
+    """Threshold + eroded re-mask of the planes `rank` owns.  acc / cnt / vol hold planes [z0, z0 + n) of the padded
+    volume (the rank's slab, ShardPlan.slab; z0 = 0 with full-extent buffers).  The erosion is evaluated on the
+    reference's Arrayterator z-block grid (inference/inference.py:53) at ABSOLUTE plane indices
+    (dlv_finalize_slab_dev), on the owned planes plus `erode_iters` planes of margin inside their blocks, so the result
+    equals the single-volume one.  Returns (slab uint8 (n_owned, Y, X), prob or None, (lo, hi))."""
     from .hostlogic import arrayterator_zblock
 
     Z, Y, X = (int(v) for v in stack_shape)
@@ -215,11 +290,14 @@ def finalize_owned(engine, plan: ShardPlan, rank: int, acc, cnt, vol, stack_shap
     hi = min(hi, Z)
     if hi <= lo:
         return None, None, (lo, lo)
-    blo, bhi = (lo // nb) * nb, min(-(-hi // nb) * nb, Z)
-    res = engine.finalize(acc[blo:bhi], None if cnt is None else cnt[blo:bhi], vol[blo:bhi], (bhi - blo, Y, X),
-                          threshold, erode_iters, nb, want_prob=want_prob)
+    elo = max(lo - erode_iters, (lo // nb) * nb, z0)
+    ehi = min(hi + erode_iters, min(((hi - 1) // nb + 1) * nb, Z), z0 + int(acc.shape[0]))
+    if elo > max(lo - erode_iters, (lo // nb) * nb) or ehi < min(hi + erode_iters, min(((hi - 1) // nb + 1) * nb, Z)):
+        raise ValueError(f"rank {rank}: the slab [{z0}, {z0 + int(acc.shape[0])}) lacks the erosion margin of its owned planes [{lo}, {hi})")
+    res = engine.finalize_slab(acc[elo - z0:ehi - z0], None if cnt is None else cnt[elo - z0:ehi - z0], vol[elo - z0:ehi - z0], elo,
+                               (Y, X), threshold, erode_iters, nb, want_prob=want_prob)
     mask, prob = res if want_prob else (res, None)
-    return mask[lo - blo: hi - blo], (None if prob is None else prob[lo - blo: hi - blo]), (lo, hi)
+    return mask[lo - elo: hi - elo], (None if prob is None else prob[lo - elo: hi - elo]), (lo, hi)
 
 
 # ---------------------------------------------------------------------------------------------------------------

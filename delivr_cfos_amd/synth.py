@@ -44,16 +44,22 @@ def synth_volume_torch(shape: Sequence[int], seed: int, device, dense: bool = Fa
     """Device-side generator for the bench volumes (up to 1024x2048x2048): built z-chunk by
     z-chunk so that the fp32 temporaries stay ~1 GB.  Returns a uint16 torch tensor (Z,Y,X) on
     ``device`` (torch is the memory container here, not the product)."""
+    return synth_planes_torch(shape, seed, device, 0, int(shape[0]), dense=dense, chunk=chunk)
+
+
+def synth_planes_torch(shape: Sequence[int], seed: int, device, z_lo: int, z_hi: int, dense: bool = False, chunk: int = 64):
+    """Planes [z_lo, z_hi) of the same volume.  Every z-chunk has its own generator seed, so a rank of a sharded run
+    generates exactly its slab (cells are blurred inside a chunk: a blob never crosses a chunk boundary)."""
     import torch
     Z, Y, X = shape
-    g = torch.Generator(device=device).manual_seed(seed)
-    out = torch.empty((Z, Y, X), dtype=torch.uint16, device=device)
+    out = torch.empty((z_hi - z_lo, Y, X), dtype=torch.uint16, device=device)
     k1 = torch.tensor(np.exp(-(np.arange(-2, 3) ** 2) / (2 * 0.9**2)), dtype=torch.float32, device=device)
     yy = ((torch.arange(Y, device=device) - (Y - 1) / 2) / (0.45 * Y)) ** 2
     xx = ((torch.arange(X, device=device) - (X - 1) / 2) / (0.45 * X)) ** 2
-    for z0 in range(0, Z, chunk):
+    for z0 in range((z_lo // chunk) * chunk, z_hi, chunk):
         z1 = min(z0 + chunk, Z)
         n = z1 - z0
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + z0 // chunk)
         t = torch.randn((n, Y, X), generator=g, device=device).mul_(600.0).add_(2500.0).clamp_(200.0, 20000.0)
         imp = (torch.rand((n, Y, X), generator=g, device=device) < CELL_DENSITY).float()
         imp.mul_(torch.rand((n, Y, X), generator=g, device=device).mul_(27000.0).add_(3000.0))
@@ -76,6 +82,7 @@ def synth_volume_torch(shape: Sequence[int], seed: int, device, dense: bool = Fa
             zz = ((torch.arange(z0, z1, device=device) - (Z - 1) / 2) / (0.45 * Z)) ** 2
             inside = (zz[:, None, None] + yy[None, :, None] + xx[None, None, :]) <= 1.0
             t.mul_(inside)
-        out[z0:z1] = t.to(torch.int32).to(torch.uint16)
+        a, b = max(z0, z_lo), min(z1, z_hi)
+        out[a - z_lo:b - z_lo] = t[a - z0:b - z0].to(torch.int32).to(torch.uint16)
         del t, imp, c
     return out

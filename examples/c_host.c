@@ -4,12 +4,16 @@
  *   gcc -std=c99 -Iinclude examples/c_host.c -o c_host -Ldelivr_cfos_amd/lib -ldelivr_hip \
  *       -Wl,-rpath,$PWD/delivr_cfos_amd/lib -Wl,--allow-shlib-undefined -lm
  *   ./c_host            # needs an MI355X; prints the number of mask voxels and components
+ *   ./c_host --gpus N [--same-device]   # the same pass sharded over N devices (dlv_comm_init_all, ONE weight broadcast,
+ *                       # per-rank Z-slabs, one seam exchange); --same-device puts every rank on device 0 (a one-GPU box)
+ *   ./c_host --plan N   # prints the shard plan only (host logic, no GPU needed)
  *
  * Weights: a deterministic LCG stands in for a checkpoint (same topology as MONAI BasicUNet(3,1,1,
  * (32,32,64,128,256,32), act=mish, norm=instance-affine); a real host passes the arrays of its state_dict). */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "delivr_hip.h"
 
@@ -35,7 +39,88 @@ static float* filled(size_t n, float scale, float offset) {
         }                                                                               \
     } while (0)
 
-int main(void) {
+static void set_params(dlv_sw_params* p, int Z, int Y, int X, int roi) {
+    memset(p, 0, sizeof(*p));
+    p->Zp = Z; p->Yp = Y; p->Xp = X;
+    p->roi[0] = p->roi[1] = p->roi[2] = roi;
+    p->overlap = 0.5f;
+    p->flip_dim = -1;
+    p->skip_threshold = 0;
+    p->precision = DLV_PREC_F16;
+    p->repeat = 1;
+    p->blend_mode = DLV_BLEND_CONSTANT;
+}
+
+/* the pass of main() sharded over n devices: every rank holds only its Z-slab of the volume and of the accumulator */
+static int run_sharded(int n, int same_device, const dlv_unet_weights* w, const uint16_t* vol, int Z, int Y, int X, int roi,
+                       int erode, uint8_t* mask) {
+    dlv_comm* comm = NULL;
+    dlv_ctx* ctx = NULL; /* for CHECK's message */
+    dlv_shard_plan plan;
+    dlv_sw_params p;
+    dlv_sw_stats st[DLV_MAX_RANKS];
+    int devs[DLV_MAX_RANKS], z0[DLV_MAX_RANKS], nz[DLV_MAX_RANKS], r;
+    const uint16_t* vslab[DLV_MAX_RANKS];
+    float* aslab[DLV_MAX_RANKS];
+    const size_t plane = (size_t)Y * X;
+    long long nw = 0, nsk = 0;
+    for (r = 0; r < n; ++r) devs[r] = same_device ? 0 : r;
+    if (dlv_comm_init_all(n, devs, &comm) != DLV_OK) {
+        fprintf(stderr, "dlv_comm_init_all(%d) failed: needs %d MI355X (or --same-device) and librccl.so\n", n, n);
+        return 2;
+    }
+#define CCHECK(call)                                                                              \
+    do {                                                                                          \
+        int rc_ = (call);                                                                         \
+        if (rc_ != DLV_OK) {                                                                      \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, dlv_comm_last_error(comm));             \
+            return 2;                                                                             \
+        }                                                                                         \
+    } while (0)
+    ctx = dlv_comm_ctx(comm, 0);
+    CHECK(dlv_unet_load(ctx, w));      /* rank 0 reads the checkpoint ... */
+    CCHECK(dlv_bcast_weights(comm, 0)); /* ... the others receive the packed blob with ONE broadcast */
+    set_params(&p, Z, Y, X, roi);
+    CCHECK(dlv_shard_plan_make(&p, n, NULL, &plan));
+    for (r = 0; r < n; ++r) {
+        void *v = NULL, *a = NULL;
+        ctx = dlv_comm_ctx(comm, r);
+        CCHECK(dlv_shard_slab(&plan, r, Z, erode, 0, &z0[r], &nz[r]));
+        CHECK(dlv_malloc(ctx, (size_t)(nz[r] > 0 ? nz[r] : 1) * plane * 2, &v));
+        CHECK(dlv_malloc(ctx, (size_t)(nz[r] > 0 ? nz[r] : 1) * plane * 4, &a));
+        if (nz[r] > 0) {
+            CHECK(dlv_copy_h2d(ctx, v, vol + (size_t)z0[r] * plane, (size_t)nz[r] * plane * 2)); /* only ITS planes */
+            CHECK(dlv_memset_dev(ctx, a, 0, (size_t)nz[r] * plane * 4));
+            CHECK(dlv_sync(ctx));
+        }
+        vslab[r] = (const uint16_t*)v;
+        aslab[r] = (float*)a;
+        printf("rank %d: windows [%lld,%lld), holds planes [%d,%d), owns [%d,%d)\n", r, (long long)plan.win_begin[r],
+               (long long)plan.win_end[r], z0[r], z0[r] + nz[r], plan.z_own_lo[r], plan.z_own_hi[r]);
+    }
+    CCHECK(dlv_sw_infer_sharded(comm, &p, &plan, z0, nz, vslab, aslab, NULL, st));
+    for (r = 0; r < n; ++r) {
+        const int olo = plan.z_own_lo[r], ohi = plan.z_own_hi[r] < Z ? plan.z_own_hi[r] : Z;
+        void* m = NULL;
+        nw += st[r].n_windows;
+        nsk += st[r].n_skipped;
+        ctx = dlv_comm_ctx(comm, r);
+        if (ohi > olo) { /* threshold + eroded re-mask of the slab; the owned planes go to the host */
+            CHECK(dlv_malloc(ctx, (size_t)nz[r] * plane, &m));
+            CHECK(dlv_finalize_slab_dev(ctx, aslab[r], NULL, vslab[r], Y, X, z0[r], nz[r], Y, X, 0.5f, erode, 0, (uint8_t*)m, NULL));
+            CHECK(dlv_copy_d2h(ctx, mask + (size_t)olo * plane, (const uint8_t*)m + (size_t)(olo - z0[r]) * plane,
+                               (size_t)(ohi - olo) * plane));
+            CHECK(dlv_free(ctx, m));
+        }
+        CHECK(dlv_free(ctx, (void*)vslab[r]));
+        CHECK(dlv_free(ctx, aslab[r]));
+    }
+    printf("sharded over %d ranks: windows %lld (skipped %lld)\n", n, nw, nsk);
+    dlv_comm_destroy(comm);
+    return nsk > 0 ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
     dlv_ctx* ctx = NULL;
     const int f[6] = {32, 32, 64, 128, 256, 32};
     /* channels per conv in forward order (see the header comment of dlv_unet_weights) */
@@ -53,8 +138,27 @@ int main(void) {
     dlv_sw_stats st;
     uint64_t ncomp = 0;
     size_t fg = 0;
+    int gpus = 1, same_device = 0, plan_only = 0;
 
-    if (dlv_ctx_create(0, NULL, &ctx) != DLV_OK) {
+    for (i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--plan") && i + 1 < argc) { gpus = atoi(argv[++i]); plan_only = 1; }
+        else if (!strcmp(argv[i], "--same-device")) same_device = 1;
+    }
+    if (gpus < 1 || gpus > DLV_MAX_RANKS) return 3;
+    if (plan_only) { /* pure host logic: no device is touched */
+        dlv_shard_plan plan;
+        set_params(&p, Z, Y, X, roi);
+        if (dlv_shard_plan_make(&p, gpus, NULL, &plan) != DLV_OK) return 2;
+        for (i = 0; i < gpus; ++i) {
+            int z0 = 0, nz = 0;
+            dlv_shard_slab(&plan, i, Z, 3, 0, &z0, &nz);
+            printf("rank %d: windows [%lld,%lld) computes [%d,%d) owns [%d,%d) holds [%d,%d)\n", i, (long long)plan.win_begin[i],
+                   (long long)plan.win_end[i], plan.z_comp_lo[i], plan.z_comp_hi[i], plan.z_own_lo[i], plan.z_own_hi[i], z0, z0 + nz);
+        }
+        return 0;
+    }
+    if (gpus == 1 && dlv_ctx_create(0, NULL, &ctx) != DLV_OK) {
         fprintf(stderr, "dlv_ctx_create failed: this program needs an MI355X (there is no CPU fallback)\n");
         return 2;
     }
@@ -72,10 +176,16 @@ int main(void) {
     }
     w.final_w = filled(32, 0.3f, 0.f);
     w.final_b = filled(1, 0.1f, 0.f);
-    CHECK(dlv_unet_load(ctx, &w));
-
     /* a synthetic volume: tissue everywhere but a background margin in x (those windows are skipped) */
     for (i = 0; i < (int)nvox; ++i) vol[i] = (i % X) < 30 ? (uint16_t)(2000 + 1500 * lcg_uniform()) : 0;
+    if (gpus > 1) {
+        const int rc = run_sharded(gpus, same_device, &w, vol, Z, Y, X, roi, 3, mask);
+        for (i = 0; i < (int)nvox; ++i) fg += mask[i] != 0;
+        printf("mask voxels %zu of %zu\n", fg, nvox);
+        return rc;
+    }
+    CHECK(dlv_unet_load(ctx, &w));
+
     CHECK(dlv_malloc(ctx, nvox * 2, &vol_dev));
     CHECK(dlv_malloc(ctx, nvox * 4, &acc_dev));
     CHECK(dlv_malloc(ctx, nvox, &mask_dev));
@@ -83,19 +193,7 @@ int main(void) {
     CHECK(dlv_copy_h2d(ctx, vol_dev, vol, nvox * 2));
     CHECK(dlv_memset_dev(ctx, acc_dev, 0, nvox * 4));
 
-    p.Zp = Z; p.Yp = Y; p.Xp = X;
-    p.roi[0] = p.roi[1] = p.roi[2] = roi;
-    p.overlap = 0.5f;
-    p.flip_dim = -1;
-    p.skip_threshold = 0;
-    p.precision = DLV_PREC_F16;
-    p.sw_batch = 0;
-    p.win_begin = p.win_end = 0;
-    p.z0 = p.nz = 0;
-    p.repeat = 1;
-    p.blend_mode = DLV_BLEND_CONSTANT;
-    p.sigma_scale = 0.f;
-    p.wsum_dev = NULL;
+    set_params(&p, Z, Y, X, roi);
     CHECK(dlv_sw_infer_dev(ctx, &p, (const uint16_t*)vol_dev, (float*)acc_dev, NULL, &st));
     CHECK(dlv_finalize_dev(ctx, (const float*)acc_dev, NULL, (const uint16_t*)vol_dev, Y, X, Z, Y, X, 0.5f, 3, 0,
                            (uint8_t*)mask_dev, NULL));

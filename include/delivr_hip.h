@@ -145,7 +145,8 @@ int dlv_sw_window_starts(const dlv_sw_params* p, int64_t* starts, int64_t capaci
 
 /* Per-window maximum of the uint16 volume, in the reference's window order (the quantity the skip test of
  * sliding_window_inferer.py:198 looks at): wmax[n_windows] on the host.  Lets a multi-rank host balance its
- * shards by NON-background windows before calling dlv_sw_infer_dev.  Synchronous. */
+ * shards by NON-background windows before calling dlv_sw_infer_dev.  p->win_begin/win_end and p->z0/nz are honoured
+ * (wmax[i] = window win_begin + i, from a slab of the volume): the ranks of a sharded run each compute a part.  Synchronous. */
 int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, int32_t* wmax, int64_t capacity);
 
 /* One pass of sliding_window_inference (inference/sliding_window_inferer.py:161-251) with the
@@ -155,6 +156,50 @@ int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* 
  * NULL.  Synchronous with respect to the host only for the small skip-list read-back. */
 int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev,
                      uint8_t* cnt_dev, dlv_sw_stats* stats);
+
+/* ---- one process, N devices (replaces torch.nn.DataParallel, inference/inference.py:217-219) ------------------------
+ * The reference scatters every sw-batch over the visible GPUs, re-broadcasts all parameters per forward and gathers the
+ * logits through GPU 0.  Here: a static partition of the reference's window list (Z slowest) into contiguous ranges - a
+ * rank's windows form a Z-slab of tile rows -, ONE broadcast of the packed weights, and ONE point-to-point exchange per
+ * seam and pass (the planes a rank computed but another rank owns).  Every rank holds only ITS slab of the volume and of
+ * the accumulator.  RCCL (ncclBroadcast, grouped ncclSend/ncclRecv over xGMI) is loaded at dlv_comm_init_all; there is
+ * no all-reduce on this path.  The multi-process form of the same plan (one process per GPU, torch.distributed) lives in
+ * delivr_cfos_amd/parallel.py. */
+#define DLV_MAX_RANKS 16
+typedef struct dlv_comm dlv_comm;
+typedef struct dlv_shard_plan {
+    int world;
+    int64_t n_windows;
+    int64_t win_begin[DLV_MAX_RANKS], win_end[DLV_MAX_RANKS]; /* [begin, end) of the reference's window enumeration */
+    int z_comp_lo[DLV_MAX_RANKS], z_comp_hi[DLV_MAX_RANKS];   /* planes [lo, hi) the rank's windows touch ((0,0): none) */
+    int z_own_lo[DLV_MAX_RANKS], z_own_hi[DLV_MAX_RANKS];     /* planes [lo, hi) the rank finalizes: a partition of [0, Zp) */
+} dlv_shard_plan;
+/* Host-only integer logic.  weights == NULL: equal windows, cuts snap to Z tile-row boundaries; otherwise weights[n_windows]
+ * (e.g. 1 for a window that runs the network, 0.02 for a background-skipped one, from dlv_sw_window_max_dev) balance the
+ * cumulative work.  Ownership: [0, Zp) split at the midpoints of the seams between consecutive non-empty ranks. */
+int dlv_shard_plan_make(const dlv_sw_params* p, int world, const float* weights, dlv_shard_plan* out);
+/* planes [*z0, *z0 + *nz) a rank must hold: its windows' planes and the planes it owns extended by erode_iters planes
+ * inside their z-blocks (zblock <= 0: one block; Z = unpadded stack depth) - what dlv_finalize_slab_dev needs */
+int dlv_shard_slab(const dlv_shard_plan* plan, int rank, int Z, int erode_iters, int zblock, int* z0, int* nz);
+/* one context per entry of devs (rank r <-> devs[r]) and one RCCL communicator per device (ncclCommInitAll); ranks that
+ * share a device (a test on a one-GPU box) exchange with device copies instead.  DLV_EUNSUP: several devices, no librccl. */
+int dlv_comm_init_all(int n, const int* devs, dlv_comm** out);
+int dlv_comm_destroy(dlv_comm* c);
+int dlv_comm_size(dlv_comm* c);
+dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank); /* owned by the communicator */
+const char* dlv_comm_last_error(dlv_comm* c);
+/* dlv_unet_load was called on rank `root`: every other rank allocates the blob and receives it with ONE ncclBroadcast */
+int dlv_bcast_weights(dlv_comm* c, int root);
+/* One sliding-window pass sharded over the communicator.  Rank r's buffers hold planes [slab_z0[r], slab_z0[r]+slab_nz[r])
+ * of the padded volume (vol: uint16, acc: fp32 in/out, cnt: uint8 in/out or cnt_slab_dev == NULL), on device devs[r]; they
+ * must cover the rank's z_comp and z_own ranges.  p->win_begin/win_end/z0/nz are ignored (taken from the plan).  After the
+ * call the planes a rank OWNS hold the complete sums: a neighbour's partial sum is added as one term, in increasing
+ * source-rank order - the result is fixed by the plan and does not depend on arrival order; against the single-device
+ * pass it is the same terms in another association (fp32 rounding; the count map is exact).  stats: [world] or NULL.
+ * Synchronous. */
+int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_plan* plan, const int* slab_z0, const int* slab_nz,
+                         const uint16_t* const* vol_slab_dev, float* const* acc_slab_dev, uint8_t* const* cnt_slab_dev,
+                         dlv_sw_stats* stats);
 
 /* ---- finalize: divide, threshold, eroded re-mask ------------------------------------------- */
 /* inference/inference.py:285-299 + create_nifti_seg (:31-95).  mean = acc/cnt; cnt_dev == NULL: acc_dev already holds
@@ -168,6 +213,13 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
 int dlv_finalize_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev,
                      int Yp, int Xp, int Z, int Y, int X, float threshold, int erode_iters, int zblock,
                      uint8_t* out_dev, float* prob_dev);
+/* the same on a Z-slab: the buffers hold planes [z_abs0, z_abs0 + nz) of the stack and the erosion's z-blocks sit at
+ * absolute multiples of zblock (the reference's Arrayterator grid), so that a rank of a sharded run reproduces the
+ * single-volume result on the planes it owns.  Planes beyond the slab count as foreground: the caller includes
+ * erode_iters planes of margin unless the slab ends on a block boundary (dlv_shard_slab).  out/prob: (nz, Y, X). */
+int dlv_finalize_slab_dev(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev, int Yp, int Xp,
+                          int z_abs0, int nz, int Y, int X, float threshold, int erode_iters, int zblock, uint8_t* out_dev,
+                          float* prob_dev);
 
 /* ---- connected components + statistics ------------------------------------------------------ */
 /* cc3d.connected_components(bin_img, return_N=True), connectivity 26 (count_blobs.py:61): labels

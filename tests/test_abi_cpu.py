@@ -85,6 +85,21 @@ def test_plain_c_host_compiles_links_and_fails_loudly_without_gpu(tmp_path):
                            "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-lm"])
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
                            os.path.join(ROOT, "include", "delivr_hip.h")])
+    # `--plan N` is host logic only (dlv_shard_plan_make / dlv_shard_slab): it must agree with the Python planner
+    from delivr_cfos_amd import parallel
+    from oracle import delivr_oracle as orc
+    r = subprocess.run([exe, "--plan", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    starts = orc.window_list((48, 64, 64), (32, 32, 32), 0.5)
+    plan = parallel.make_plan(starts, 32, 48, 3)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 3
+    for rank, line in enumerate(lines):
+        (wb, we), (cl, ch), (ol, oh) = plan.win_ranges[rank], plan.z_computed[rank], plan.z_owned[rank]
+        z0, z1 = plan.slab(rank, 48, erode_iters=3)
+        assert line == (f"rank {rank}: windows [{wb},{we}) computes [{cl},{ch}) owns [{ol},{oh}) holds [{z0},{z1})"), line
     if torch.cuda.device_count() == 0:
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 2 and "needs an MI355X" in r.stderr
+        r = subprocess.run([exe, "--gpus", "2", "--same-device"], capture_output=True, text=True)
+        assert r.returncode == 2 and "dlv_comm_init_all" in r.stderr

@@ -559,3 +559,97 @@ def test_uint8_count_map_refuses_a_multiplicity_it_cannot_hold():
     with pytest.raises(DelivrHipError):
         eng.sw_infer(eng.make_sw_params(shape, roi, 0.75, None, 0, "fp16", repeat=4), vol, acc, cnt)
     eng.close()
+
+
+@pytest.mark.parametrize("world,weighted", [(2, False), (3, True), (5, True)])
+def test_c_abi_sharded_pass_on_slabs_equals_the_single_device_pass(world, weighted):
+    """dlv_comm_init_all / dlv_bcast_weights / dlv_sw_infer_sharded / dlv_finalize_slab_dev with every rank on device 0 (the
+    seam exchange then uses device copies; RCCL needs distinct devices): each rank holds only ITS slab of the volume and of
+    the accumulator.  On the planes a rank owns: the count map equals the single-device pass exactly; the sums agree to
+    fp32 rounding (a seam voxel adds the neighbour's partial sum as ONE term, the single pass adds its windows one by one:
+    another association of the same terms, fixed for a given plan and independent of arrival order); the eroded mask is
+    identical wherever the mean logit is not within 1e-5 of the threshold (z-blocks of 24 planes, so that block boundaries
+    fall inside and between slabs)."""
+    import torch
+    from delivr_cfos_amd.engine import HipComm, HipEngine
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    shape, roi, nb, er = (160, 64, 64), (32, 32, 32), 24, 7
+    vol = synth_volume_np(shape, seed=31, dense=True)
+    vol[:, :12] = 0
+    vol[70:110, 20:40, 30:50] = 0  # zeros inside: the erosion has work across the seams
+    vol[100:] = 0                  # background windows: the weighted plan differs from the equal one
+    sd = random_state_dict(2)
+    one = HipEngine(0)
+    one.load_state_dict({"state_dict": sd})
+    v = one.to_device(vol)
+    acc1 = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    cnt1 = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    p = one.make_sw_params(shape, roi, 0.5, None, 0, "fp16")
+    st1 = one.sw_infer(p, v, acc1, cnt1)
+    mask1 = one.finalize(acc1, cnt1, v, shape, 0.5, er, nb)
+    wmax = one.window_max(p, v)
+    one.sync()
+
+    comm = HipComm([0] * world)
+    comm.engines[0].load_state_dict({"state_dict": sd})
+    comm.bcast_weights(0)
+    plan = comm.make_plan(p, np.where(wmax > 0, 1.0, 0.02).astype(np.float32) if weighted else None)
+    slabs, vols, accs, cnts = [], [], [], []
+    for r in range(world):
+        lo, hi = plan.slab(r, shape[0], er, nb)
+        slabs.append((lo, hi - lo))
+        vols.append(v[lo:hi].clone())
+        accs.append(torch.zeros((hi - lo,) + shape[1:], dtype=torch.float32, device="cuda"))
+        cnts.append(torch.zeros((hi - lo,) + shape[1:], dtype=torch.uint8, device="cuda"))
+        assert hi - lo < shape[0] or world == 1  # a slab, not the volume
+    stats = comm.sw_infer_sharded(p, plan, slabs, vols, accs, cnts)
+    assert sum(s["n_windows"] for s in stats) == st1["n_windows"] and sum(s["n_skipped"] for s in stats) == st1["n_skipped"]
+    torch.cuda.synchronize()
+    covered = 0
+    for r in range(world):
+        olo, ohi = plan.z_owned[r]
+        if ohi <= olo:
+            continue
+        lo = slabs[r][0]
+        d = (accs[r][olo - lo:ohi - lo] - acc1[olo:ohi]).abs()
+        assert float(d.max()) <= 1e-5 * max(float(acc1[olo:ohi].abs().max()), 1.0), (r, float(d.max()))
+        assert torch.equal(cnts[r][olo - lo:ohi - lo], cnt1[olo:ohi]), r
+        eng = comm.engines[r]
+        elo, ehi = max(olo - er, (olo // nb) * nb), min(ohi + er, ((ohi - 1) // nb + 1) * nb, shape[0])
+        m = eng.finalize_slab(accs[r][elo - lo:ehi - lo], cnts[r][elo - lo:ehi - lo], vols[r][elo - lo:ehi - lo], elo, shape[1:],
+                              0.5, er, nb)
+        sure = (acc1[olo:ohi] / cnt1[olo:ohi].clamp_min(1)).abs() > 1e-5
+        assert torch.equal(m[olo - elo:ohi - elo][sure], mask1[olo:ohi][sure]), r
+        covered += ohi - olo
+    assert covered == shape[0]
+    comm.close()
+    one.close()
+
+
+def test_plain_c_host_runs_the_pass_single_and_sharded(tmp_path):
+    """examples/c_host.c on the GPU box: the single-device pass and `--gpus N --same-device` (every rank on device 0:
+    loopback seam copies, the same plan / slab / staging code the N-GPU run takes) paint the same mask."""
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "delivr_cfos_amd", "lib")
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_host.c"), "-o", exe, "-L" + lib_dir, "-ldelivr_hip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-lm"])
+    single = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0, single.stdout + single.stderr
+    fg1 = int(re.search(r"mask voxels (\d+)", single.stdout).group(1))
+    assert fg1 > 0
+    for n in (2, 3):
+        r = subprocess.run([exe, "--gpus", str(n), "--same-device"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        fg = int(re.search(r"mask voxels (\d+)", r.stdout).group(1))
+        # sums associate differently across the seam (fp32): a voxel whose mean logit is within rounding of 0 may flip
+        assert abs(fg - fg1) <= 2, (fg, fg1)

@@ -87,6 +87,57 @@ def test_shard_plan_is_a_partition():
                 assert np.all(covered[lo:hi] == 1)
 
 
+def test_shard_plan_of_the_c_abi_equals_the_python_plan_and_slabs_cover_what_a_rank_needs():
+    """dlv_shard_plan_make / dlv_shard_slab (host-only entry points of the C ABI: what examples/c_host.c --gpus N uses)
+    against parallel.make_plan / ShardPlan.slab, for equal and weighted windows, clamped last windows, more ranks than
+    tile rows and empty ranks."""
+    import ctypes as C
+
+    from delivr_cfos_amd import _lib
+    from delivr_cfos_amd.parallel import plan_from_params
+
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    cases = (((1024, 2048, 2048), (128, 128, 128), 0.5, 8), ((512, 512, 512), (128, 128, 128), 0.5, 4), ((64, 64, 32), (32, 32, 16), 0.5, 2),
+             ((128, 64, 64), (64, 64, 64), 0.5, 3), ((64, 64, 64), (64, 64, 64), 0.5, 2), ((100, 70, 50), (32, 32, 16), 0.25, 5),
+             ((96, 96, 128), (96, 96, 64), 0.5, 4), ((256, 64, 64), (32, 32, 32), 0.6, 16), ((40, 48, 56), (32, 32, 32), 0.5, 7))
+    for shape, roi, ov, world in cases:
+        p = _lib.SwParams()
+        p.Zp, p.Yp, p.Xp = shape
+        for k in range(3):
+            p.roi[k] = roi[k]
+        p.overlap = ov
+        p.flip_dim = -1
+        n = C.c_int64()
+        assert lib.dlv_sw_num_windows(C.byref(p), C.byref(n)) == 0
+        starts = np.zeros((n.value, 3), dtype=np.int64)
+        assert lib.dlv_sw_window_starts(C.byref(p), starts.ctypes.data_as(C.POINTER(C.c_int64)), n.value) == 0
+        np.testing.assert_array_equal(starts, orc.window_list(shape, roi, ov))
+        for weights in (None, rng.choice([1.0, 0.02], size=n.value, p=[0.6, 0.4]).astype(np.float32), np.zeros(n.value, dtype=np.float32)):
+            a = plan_from_params(p, world, weights)
+            b = make_plan(starts, roi[0], shape[0], world, None if weights is None else weights.astype(np.float64))
+            assert a.win_ranges == b.win_ranges and a.z_computed == b.z_computed and a.z_owned == b.z_owned, (shape, roi, world)
+            plan_c = _lib.ShardPlanC()
+            wp = None if weights is None else weights.ctypes.data_as(C.POINTER(C.c_float))
+            assert lib.dlv_shard_plan_make(C.byref(p), world, wp, C.byref(plan_c)) == 0
+            for Z, er, nb in ((shape[0], 30, 0), (shape[0] - 3, 30, 17), (shape[0], 5, 40)):
+                for r in range(world):
+                    z0, nz = C.c_int(), C.c_int()
+                    assert lib.dlv_shard_slab(C.byref(plan_c), r, Z, er, nb, C.byref(z0), C.byref(nz)) == 0
+                    lo, hi = a.slab(r, Z, er, nb)
+                    assert (z0.value, z0.value + nz.value) == (lo, hi)
+                    clo, chi = a.z_computed[r]
+                    olo, ohi = a.z_owned[r][0], min(a.z_owned[r][1], Z)
+                    if chi > clo:
+                        assert lo <= clo and hi >= chi
+                    if ohi > olo:  # owned planes + erosion margin inside their z-blocks
+                        blk = nb if nb > 0 else Z
+                        assert lo <= max(olo - er, (olo // blk) * blk) and hi >= min(ohi + er, ((ohi - 1) // blk + 1) * blk, Z)
+    bad = _lib.SwParams()
+    assert lib.dlv_shard_plan_make(C.byref(bad), 2, None, C.byref(_lib.ShardPlanC())) != 0  # empty volume
+    assert lib.dlv_shard_plan_make(C.byref(p), 99, None, C.byref(_lib.ShardPlanC())) != 0  # too many ranks
+
+
 def _gloo_worker(rank, world, port, tmp):
     import torch
     import torch.distributed as dist
@@ -106,20 +157,22 @@ def _gloo_worker(rank, world, port, tmp):
     wts = np.array([1.0 if vol[z:z + 32, y:y + 32, x:x + 16].max() > 0 else 0.02 for z, y, x in starts])
     plan = make_plan(starts, roi[0], vol.shape[0], world, wts)
     det = lambda x: (x - 2000.0) / 1000.0  # noqa: E731
-    acc = np.zeros(vol.shape, dtype=np.float32)
+    # slab-resident: this rank holds only the planes [slo, shi) of the accumulator (and would of the volume)
+    slo, shi = plan.slab(rank, vol.shape[0], 0, 0)
+    acc = np.zeros((shi - slo,) + vol.shape[1:], dtype=np.float32)
     wb, we = plan.win_ranges[rank]
     for z, y, x in starts[wb:we]:
         win = vol[z:z + 32, y:y + 32, x:x + 16].astype(np.float32)
-        acc[z:z + 32, y:y + 32, x:x + 16] += det(win) if win.max() > 0 else -1000.0
+        acc[z - slo:z - slo + 32, y:y + 32, x:x + 16] += det(win) if win.max() > 0 else -1000.0
     t = torch.from_numpy(acc)
-    exchange_seams(t, plan, rank, dist)
+    exchange_seams(t, plan, rank, dist, z0=slo)
     lo, hi = plan.z_owned[rank]
-    slab = (t[lo:hi] >= 0).to(torch.uint8)
+    slab = (t[lo - slo:hi - slo] >= 0).to(torch.uint8)
     out = torch.zeros(vol.shape, dtype=torch.uint8) if rank == 0 else None
     gather_slabs(slab, plan, rank, dist, out=out)
     if rank == 0:
         np.save(os.path.join(tmp, "mask.npy"), out.numpy())
-        np.save(os.path.join(tmp, "acc0.npy"), t[lo:hi].numpy())
+        np.save(os.path.join(tmp, "acc0.npy"), t[lo - slo:hi - slo].numpy())
     dist.barrier()
     dist.destroy_process_group()
 
