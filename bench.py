@@ -11,9 +11,11 @@ uint16: tiler -> per-window background skip -> U-Net forward (16-bit MFMA operan
 That is BASELINE.json's metric ("voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @
 1/2/4/8 GPU"); the volume and its window list are the same at every N, so scaling is "strong".
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the engine's stream
-(dlv_prof_*), `cpu_baseline` times the CPU oracle (oracle/, a port of the reference's algorithm) on
-a bounded sample of the same workload on the host cores of this box.
+Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps passes with no per-kernel instrumentation; the same
+passes are then repeated with every launch bracketed by HIP events on the engine's stream (dlv_prof_*) for `kernels`
+and `roofline`, once more with the background skip disabled for `value_dense`, and `cpu_baseline` times the CPU oracle
+(oracle/, a port of the reference's algorithm) on BASELINE.md section 3's bounded samples on the host cores of this
+box and checks that the HIP path gives the same result on that sample.
 """
 from __future__ import annotations
 
@@ -41,9 +43,14 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_PATCH_VOXEL = 285104.0
 
 
-def cpu_baseline(sd, vol_crop_u16, roi, n_active_full, vol_voxels_full, threads):
-    """The oracle (CPU port) on a bounded sample: whole windows of the benchmark's size through
-    U-Net (torch fp32 CPU) + blend, then the time is extrapolated by the number of active windows."""
+def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, crop_edge, precision):
+    """BASELINE.md section 3's CPU legs on the host cores of this box, with the oracle (the CPU port of the reference's
+    algorithm; tests and this leg are its only callers):
+      (i)  one 64^3 patch forward, fp32 (BASELINE config 1): 1 warm-up, median of 3;
+      (ii) a `crop_edge`^3 crop of the benchmark volume (centre: tissue) with the benchmark's windows / 50 % overlap
+           through tiler -> U-Net -> blend -> finalize (threshold + 30x erosion) -> 26-connected labels.
+    The HIP path then runs the SAME crop and the two results must agree (logit sums, mask, component count): a
+    baseline that computes something else than the thing measured is not a baseline."""
     import torch
 
     from oracle import delivr_oracle as orc
@@ -53,7 +60,7 @@ def cpu_baseline(sd, vol_crop_u16, roi, n_active_full, vol_voxels_full, threads)
     net.eval()
     # pick the thread count that serves the CPU best (oversubscribing a many-core host slows oneDNN down):
     # one 64^3 forward per candidate, keep the fastest
-    probe = np.zeros((1, 1, 64, 64, 64), dtype=np.float32)
+    probe = np.random.default_rng(0).integers(0, 4000, size=(1, 1, 64, 64, 64)).astype(np.float32)
     best_t, best_dt = threads, float("inf")
     for cand in sorted({c for c in (8, 16, 32, 64, 128, threads) if c <= threads}):
         torch.set_num_threads(cand)
@@ -65,23 +72,62 @@ def cpu_baseline(sd, vol_crop_u16, roi, n_active_full, vol_voxels_full, threads)
             best_t, best_dt = cand, dt
     threads = best_t
     torch.set_num_threads(threads)
-    acc = np.zeros(vol_crop_u16.shape, dtype=np.float32)
+    # (i) config 1
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.unet_forward(net, probe)
+        reps.append(time.perf_counter() - t0)
+    fwd64 = sorted(reps)[1]
+    # (ii) the crop
+    Z, Y, X = shape
+    ce = [min(crop_edge, n) for n in (Z, Y, X)]
+    z0, y0, x0 = (Z - ce[0]) // 2, (Y - ce[1]) // 2, (X - ce[2]) // 2
+    crop_dev = vol[z0:z0 + ce[0], y0:y0 + ce[1], x0:x0 + ce[2]].contiguous()
+    crop = crop_dev.cpu().numpy()
+    if crop.dtype != np.uint16:
+        crop = crop.view(np.uint16)
+    acc = np.zeros(crop.shape, dtype=np.float32)
     t0 = time.perf_counter()
-    info = orc.sliding_window_pass(vol_crop_u16, roi, lambda x: orc.unet_forward(net, x), acc, None, 0.5, None, 1,
-                                   fp16=False)
+    info = orc.sliding_window_pass(crop, roi, lambda x: orc.unet_forward(net, x), acc, None, 0.5, None, 1, fp16=False)
     t1 = time.perf_counter()
+    mask = orc.finalize(acc, None, crop, crop.shape, 0.5, 30)
+    t2 = time.perf_counter()
+    _, ncomp = orc.ccl26(mask)
+    t3 = time.perf_counter()
     n_done = info["n_windows"] - info["n_skipped"]
     per_window = (t1 - t0) / max(n_done, 1)
-    projected = per_window * n_active_full
+    fin_per_voxel = (t2 - t1) / crop.size
+    projected = per_window * n_active_full + fin_per_voxel * vox_full  # the timed region of `value`: volume -> eroded mask
+    # the HIP path on the same crop
+    g_acc = torch.zeros(crop.shape, dtype=torch.float32, device=eng.device)
+    eng.sw_infer(eng.make_sw_params(crop.shape, roi, 0.5, None, 0, precision), crop_dev, g_acc)
+    g_mask = eng.finalize(g_acc, None, crop_dev, crop.shape, 0.5, 30, 0)
+    _, g_ncomp = eng.ccl26(g_mask.contiguous())
+    ga, gm = g_acc.cpu().numpy(), g_mask.cpu().numpy()
+    rel = float(np.linalg.norm(ga - acc) / max(np.linalg.norm(acc), 1e-30))
+    inter, union = int(np.logical_and(gm, mask).sum()), int(np.logical_or(gm, mask).sum())
+    iou = inter / union if union else 1.0
+    sign = float(((ga > 0) == (acc > 0)).mean())
+    # tolerances of tests/test_gpu_production_shapes.py for the format measured
+    tol_rel, tol_iou = {"fp32": (1e-3, 0.9999), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.995)}[precision]
+    ok = bool(rel <= tol_rel and iou >= tol_iou)
     return {
-        "value": vol_voxels_full / projected if projected > 0 else None,
+        "value": vox_full / projected if projected > 0 else None,
         "unit": "voxels/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{n_done} windows of {roi[0]}x{roi[1]}x{roi[2]} (crop {vol_crop_u16.shape}) through the oracle's "
-                  f"tiler+U-Net(fp32, torch CPU)+blend in {t1 - t0:.1f} s; extrapolated to the {n_active_full} "
-                  f"non-background windows of the benchmark volume",
+        "sample": f"{n_done} windows of {roi[0]}x{roi[1]}x{roi[2]} (centre crop {crop.shape} of the benchmark volume) through the "
+                  f"oracle's tiler+U-Net(fp32, torch CPU)+blend in {t1 - t0:.1f} s, finalize+30x erosion in {t2 - t1:.1f} s; "
+                  f"extrapolated by window count to the {n_active_full} non-background windows and by voxel count to the "
+                  f"finalize of the benchmark volume",
         "seconds_per_window": per_window,
+        "forward_64cube_fp32_s": fwd64,
+        "forward_64cube_voxels_per_s": 64.0**3 / fwd64,
+        "crop": {"shape": list(crop.shape), "windows": info["n_windows"], "pass_s": t1 - t0, "finalize_erosion_s": t2 - t1,
+                 "labels_s": t3 - t2, "voxels_per_s_end_to_end": crop.size / (t3 - t0), "components": int(ncomp)},
+        "agreement": {"ok": ok, "precision": precision, "logit_sum_rel_l2": rel, "sign_agreement": sign, "mask_iou": iou,
+                      "components_hip": int(g_ncomp), "components_cpu": int(ncomp), "tol_rel_l2": tol_rel, "tol_iou": tol_iou},
     }
 
 
@@ -96,7 +142,8 @@ def main():
                     help="fp16 (default): IEEE-half MFMA operands, mask IoU 0.9997 vs the fp32 path; bf16: 2.7 %% faster, IoU 0.998")
     ap.add_argument("--sw-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=2, help="windows in the CPU-baseline sample")
+    ap.add_argument("--cpu-crop", type=int, default=256, help="edge of the centre crop the CPU baseline runs (256: 27 windows of 128^3)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the extra pass with the background skip disabled (`value_dense`)")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time CCL-26 + statistics and the resamplers on this volume (configs 4/5)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
@@ -163,11 +210,12 @@ def main():
     mask_full = torch.empty(shape, dtype=torch.uint8, device=eng.device) if (world > 1 and rank == 0) else None
 
     stats_last = {}
+    cur = {"params": params}
 
     def step():
         acc.zero_()
-        if params is not None:
-            stats_last.update(eng.sw_infer(params, vol, acc))
+        if cur["params"] is not None:
+            stats_last.update(eng.sw_infer(cur["params"], vol, acc))
         if world > 1:
             eng.sync()
             exchange_seams(acc, plan, rank, dist, z0=slo)
@@ -185,25 +233,46 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed_steps(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(args.warmup):
         step()
-    fence()
+    # the timed region: EXACTLY `steps` passes, no per-kernel event bracketing inside it
+    elapsed, slab = timed_steps(args.steps)
+    stats_timed = dict(stats_last)
+    # the same passes again with the HIP-event bracketing of every launch switched on (dlv_prof_*): the per-kernel view
+    prof, elapsed_prof = {}, None
     if not args.no_prof:
         eng.prof_reset()
         eng.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        slab = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = {}
-    if not args.no_prof:
+        elapsed_prof, _ = timed_steps(args.steps)
         prof = eng.prof_report()
         eng.prof_enable(False)
+    # every window through the network (background skip disabled): the number the MFMA ceiling is quoted against
+    elapsed_dense, stats_dense = None, {}
+    if not args.no_dense and not args.dense:
+        if params is not None:  # skip_threshold -1: no window's maximum is <= -1
+            cur["params"] = eng.make_sw_params(shape, roi, 0.5, None, -1, args.precision, sw_batch=args.sw_batch,
+                                               win_range=(wb, we), slab=(slo, shi - slo))
+        elapsed_dense, _ = timed_steps(1)
+        stats_dense = dict(stats_last)
+        cur["params"] = params
+        slab = step()  # leave acc / slab holding the benchmark's own pass (the extras and the CPU leg read them)
+        fence()
+    stats_last.clear()
+    stats_last.update(stats_timed)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         st = torch.tensor([stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)], dtype=torch.int64,
                           device=eng.device)
         dist.all_reduce(st)
@@ -241,24 +310,26 @@ def main():
             ach = e["bytes"] / max(e["launches"], 1) / avg_s / 1e9
             r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                  "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": e["launches"]}
-        # HBM traffic per launch of that kernel from the committed PMC passes (profiles/run_pmc_traffic.sh; FETCH_SIZE
-        # doubled as the gfx950 guide prescribes).  PMC passes exist for the 512^3 workload (25k launches at C3 exceed the
-        # time limit): same kernels, same batch of 16 -> scaled by algorithmic bytes per launch.
+        # HBM traffic per launch of that kernel from the committed PMC passes of THIS build and format
+        # (profiles/run_pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950
+        # guide prescribes).  The passes ran the 512^3 workload (25k launches of C3 under PMC exceed the time limit): same
+        # kernels, same batch of 16 windows per launch; a launch of another batch is scaled by algorithmic bytes.
         try:
-            tfile = os.path.join(ROOT, "profiles", f"traffic_r01_{args.workload}.json")
+            tfile = os.path.join(ROOT, "profiles", f"traffic_r02_{args.workload}.json")
             scaled = False
             if not os.path.isfile(tfile):
-                tfile = os.path.join(ROOT, "profiles", "traffic_r01_c2.json")
+                tfile = os.path.join(ROOT, "profiles", "traffic_r02_c2.json")
                 scaled = True
-            if os.path.isfile(tfile) and not args.dense and args.sw_batch == 0:
+            if os.path.isfile(tfile) and args.sw_batch == 0:
                 tj = json.load(open(tfile))
-                tname = name.replace("_f16_", "_bf16_")  # the PMC passes ran the bf16 build: same bytes per launch
-                if tname in tj["kernels"]:
+                if name in tj["kernels"] and tj.get("precision") == args.precision:
+                    k = tj["kernels"][name]
                     r["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
-                    t = tj["kernels"][tname]["traffic_bytes"]
-                    if scaled and "algorithmic_bytes" in tj["kernels"][tname]:
-                        t *= r["algorithmic_bytes"] / tj["kernels"][tname]["algorithmic_bytes"]
+                    t = k["traffic_bytes"]
+                    if scaled and k.get("algorithmic_bytes"):
+                        t *= r["algorithmic_bytes"] / k["algorithmic_bytes"]
                     r["traffic"] = t
+                    r["traffic_over_algorithmic"] = t / r["algorithmic_bytes"] if r["algorithmic_bytes"] else None
                     r["traffic_source"] = os.path.relpath(tfile, ROOT) + (
                         " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "")
         except Exception:
@@ -333,12 +404,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only (bench contract)
         try:
             threads = os.cpu_count() or 1
-            # crop: the central region (tissue), cpu_windows windows stacked along z with 50 % overlap
-            k = max(args.cpu_windows, 1)
-            cz = roi[0] + (k - 1) * (roi[0] // 2)
-            z0, y0, x0 = (Z - cz) // 2, (Y - roi[1]) // 2, (X - roi[2]) // 2
-            crop = vol[z0:z0 + cz, y0:y0 + roi[1], x0:x0 + roi[2]].cpu().numpy()
-            cpu = cpu_baseline(sd, crop, roi, n_active, vox, threads)
+            cpu = cpu_baseline(eng, sd, vol, shape, roi, n_active, vox, threads, args.cpu_crop, args.precision)
         except Exception as exc:  # the baseline is reported, never fatal
             cpu = {"value": None, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc}"}
 
@@ -350,6 +416,12 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        # the same volume with the background skip disabled: every one of the `windows` runs the network
+        "value_dense": (vox / elapsed_dense) if elapsed_dense else None,
+        "windows_run_dense": (stats_dense.get("n_windows", 0) - stats_dense.get("n_skipped", 0)) if (elapsed_dense and world == 1) else None,
+        "ms_per_step_dense": 1e3 * elapsed_dense if elapsed_dense else None,
+        # the same `steps` passes with every launch bracketed by HIP events (what `kernels` / `roofline_timed_region` saw)
+        "ms_per_step_profiled": 1e3 * elapsed_prof / args.steps if elapsed_prof else None,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -380,6 +452,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if cpu and cpu.get("agreement") and not cpu["agreement"]["ok"]:
+        raise SystemExit(f"bench.py: the HIP path and the CPU oracle disagree on the baseline crop: {cpu['agreement']}")
 
 
 if __name__ == "__main__":

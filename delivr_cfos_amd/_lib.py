@@ -17,7 +17,7 @@ if os.environ.get("DLV_LIB"):
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 N_CONV, N_DECONV = 18, 4
-PROF_MAX = 32
+PROF_MAX = 64
 
 
 class DelivrHipError(RuntimeError):

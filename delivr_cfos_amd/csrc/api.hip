@@ -42,7 +42,22 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
 }
 
 // ---- kernel timer ------------------------------------------------------------------------------
+// DLV_LAUNCH_LOG=<file>: one line per bracketed launch (label, algorithmic flops and bytes), in launch order.  The PMC
+// passes (profiles/run_pmc_traffic.sh) read it next to rocprofv3's dispatch table to attribute the counters of a
+// kernel template that serves several layers to the layer's label.
+static FILE* launch_log() {
+    static FILE* f = [] {
+        const char* path = getenv("DLV_LAUNCH_LOG");
+        return path && *path ? fopen(path, "w") : (FILE*)nullptr;
+    }();
+    return f;
+}
+
 DlvProf::DlvProf(dlv_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+    if (FILE* f = launch_log()) {
+        fprintf(f, "%s\t%.0f\t%.0f\n", name, flops, bytes);
+        fflush(f);
+    }
     if (!c->prof_on) return;
     int slot = -1;
     for (size_t i = 0; i < c->prof_slots.size(); ++i)

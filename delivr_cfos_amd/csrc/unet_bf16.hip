@@ -959,7 +959,7 @@ struct Net16 {
         const uint4* in2 = a2 ? a2->p : nullptr;
         if (zreg_runs(li, c1, c2, d)) {
             char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d%s", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, a1.ss ? "_act" : "");
+            snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d_d%d%s", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D, a1.ss ? "_act" : "");
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
             int np = 0;
             if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
@@ -971,7 +971,7 @@ struct Net16 {
         }
         if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {  // LDS-weights z-march (conv_zmarch.hip)
             char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
+            snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
             int np = 0;
             if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
@@ -1003,7 +1003,7 @@ struct Net16 {
         const double flops = 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B;
         const double bytes = 2.0 * (double)d.vox() * B * (L.cin + L.cout);
         char name[48];
-        snprintf(name, sizeof(name), "conv3_mfma_%s_c%dx%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout);
+        snprintf(name, sizeof(name), "conv3_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
         DlvProf pr(ctx, name, flops, bytes);
 #define DLV_CONV_LAUNCH(NCB_, TX_, WLDS_)                                                                                \
     do {                                                                                                                 \
@@ -1045,7 +1045,8 @@ struct Net16 {
     int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
         const long long work = pooled ? d.vox() / 8 : d.vox();
         dim3 grid(std::max(1, std::min(grid1d(work), 2048)), C / 8, B);
-        DlvProf pr(ctx, pooled ? (writeback ? "norm_mish_pool_bf16" : "pool_act_bf16") : "norm_mish_bf16", 0.0,
+        DlvProf pr(ctx, pooled ? (writeback ? (P::IS_F16 ? "norm_mish_pool_f16" : "norm_mish_pool_bf16") : (P::IS_F16 ? "pool_act_f16" : "pool_act_bf16"))
+                               : (P::IS_F16 ? "norm_mish_f16" : "norm_mish_bf16"), 0.0,
                    (double)d.vox() * B * C * 2 * (writeback ? 2 : 1) + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
         if (pooled && writeback)
             hipLaunchKernelGGL((norm_mish_kernel<P, true, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
@@ -1067,7 +1068,9 @@ struct Net16 {
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
-        DlvProf pr(ctx, "deconv2_mfma_bf16", 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
+        char dname[48];
+        snprintf(dname, sizeof(dname), "deconv2_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
+        DlvProf pr(ctx, dname, 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
                    2.0 * (double)din.vox() * B * (L.cin + 8.0 * L.cout));
 #define DLV_DECONV(KP_)                                                                                                  \
     do {                                                                                                                 \

@@ -321,7 +321,7 @@ int dlv_affine_warp_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int iz, int iy
                             uint16_t* out_dev, int oz, int oy, int ox);
 
 /* ---- in-library kernel timing (bench.py's roofline leg) ------------------------------------- */
-#define DLV_PROF_MAX_KERNELS 32
+#define DLV_PROF_MAX_KERNELS 64
 typedef struct dlv_prof_entry {
     char name[48];
     int64_t launches;

@@ -1,39 +1,81 @@
 """HBM traffic per launch from rocprofv3 PMC passes: (2 x FETCH_SIZE + WRITE_SIZE) KB -> bytes.
-FETCH_SIZE is doubled as MI355X_MICROARCH.md (section HBM) prescribes for wide (16 B/lane) coalesced
-reads on gfx950; WRITE_SIZE is exact for 8/16-byte-per-lane streaming stores."""
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md (section HBM) prescribes for wide (16 B/lane) coalesced reads on gfx950;
+WRITE_SIZE is exact for 8/16-byte-per-lane streaming stores.
+
+A kernel template serves several layers (conv3_mfma_kernel<PF16,2,16,false> is four different conv layers), so the
+counters are attributed to the library's own labels (the names in bench.py's `kernels`) by walking rocprofv3's dispatch
+table in dispatch order next to the launch log the library wrote in the same run (DLV_LAUNCH_LOG: label, algorithmic
+flops, algorithmic bytes per bracketed launch, one lane so the order is the stream order).
+
+    python make_traffic.py <dir with fetch/ write/ fetch.launches write.launches> <workload> <precision>
+"""
 import collections
 import csv
 import glob
+import gzip
 import json
 import os
 import sys
 
-root, wl = sys.argv[1], sys.argv[2]
-NAMES = {"conv3_zmarch_kernel<32": "conv3_zmarch_bf16_c32x32", "conv3_zmarch_kernel<64": "conv3_zmarch_bf16_c64x32",
-         "norm_mish_kernel<false>": "norm_mish_bf16", "norm_mish_kernel<true>": "norm_mish_pool_bf16",
-         "stem_mfma_kernel": "stem_mfma_u16", "final_conv_kernel<true>": "final_conv_blend",
-         "deconv2_mfma_kernel": "deconv2_mfma_bf16"}
+root, wl, precision = sys.argv[1], sys.argv[2], sys.argv[3]
+# label prefix -> the kernel(s) a bracketed launch of that label dispatches, in order
+# (the stem is two launches of one template under one bracket: statistics pass, then the pass that writes)
+FAMILY = [("conv3_zreg_", ["conv3_zreg_kernel"]), ("conv3_zmarch_", ["conv3_zmarch_kernel"]), ("conv3_mfma_", ["conv3_mfma_kernel"]),
+          ("norm_mish_", ["norm_mish_kernel"]), ("pool_act_", ["norm_mish_kernel"]), ("deconv2_mfma_", ["deconv2_rows_kernel"]),
+          ("stem_mfma_", ["stem_mfma_kernel", "stem_mfma_kernel"]), ("final_conv_", ["final_conv_kernel"]), ("erode_x_", ["erode_x_kernel"]),
+          ("erode_y_", ["erode_y_kernel"]), ("erode_z_", ["erode_z_final_kernel"]), ("window_max_", ["window_max_kernel"]),
+          ("skip_fill_", ["fill_add_kernel"])]
+
+
+def family(label):
+    for pre, ks in FAMILY:
+        if label.startswith(pre):
+            return ks
+    return None
+
+
+def base(kernel_name):
+    k = kernel_name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return k.split("<")[0].split("(")[0].strip()
 
 
 def load(sub, counter):
-    f = glob.glob(os.path.join(root, sub, "*", "*counter_collection.csv"))
-    tot, cnt = collections.Counter(), collections.Counter()
-    for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] != counter:
+    f = glob.glob(os.path.join(root, sub, "*", "*counter_collection.csv*"))
+    fh = gzip.open(f[0], "rt") if f[0].endswith(".gz") else open(f[0])
+    rows = [r for r in csv.DictReader(fh) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    log = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(root, sub + ".launches"))]
+    tot, cnt, alg = collections.Counter(), collections.Counter(), collections.Counter()
+    i = 0
+    unmatched = 0
+    for label, _flops, nbytes in log:
+        ks = family(label)
+        if ks is None:
             continue
-        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-        for pre, name in NAMES.items():
-            if k.startswith(pre):
-                tot[name] += float(r["Counter_Value"])
-                cnt[name] += 1
-    return tot, cnt
+        for want in ks:
+            while i < len(rows) and base(rows[i]["Kernel_Name"]) != want:
+                i += 1
+            if i == len(rows):
+                unmatched += 1
+                break
+            tot[label] += float(rows[i]["Counter_Value"])
+            i += 1
+        cnt[label] += 1
+        alg[label] += float(nbytes)
+    return tot, cnt, alg, unmatched
 
 
-ft, fc = load("fetch", "FETCH_SIZE")
-wt, wc = load("write", "WRITE_SIZE")
-out = {"workload": wl, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged over launches", "kernels": {}}
-for k in ft:
-    out["kernels"][k] = {"launches": fc[k], "fetch_bytes_corrected": 2 * 1024 * ft[k] / fc[k],
-                         "write_bytes": 1024 * wt[k] / max(wc[k], 1),
-                         "traffic_bytes": (2 * 1024 * ft[k] / fc[k]) + 1024 * wt[k] / max(wc[k], 1)}
-print(json.dumps(out))
+ft, fc, fa, fu = load("fetch", "FETCH_SIZE")
+wt, wc, _, wu = load("write", "WRITE_SIZE")
+out = {"workload": wl, "precision": precision, "build": "r02",
+       "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged over the launches of one label; "
+               "algorithmic_bytes = the figure the library's DlvProf bracket declares for that launch (DESIGN.md)",
+       "unmatched_launches": fu + wu, "kernels": {}}
+for k in sorted(ft, key=lambda k: -(2 * ft[k] + wt[k])):
+    fetch = 2 * 1024 * ft[k] / fc[k]
+    write = 1024 * wt[k] / max(wc[k], 1)
+    a = fa[k] / fc[k]
+    out["kernels"][k] = {"launches": fc[k], "fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
+                         "algorithmic_bytes": a, "traffic_over_algorithmic": (fetch + write) / a if a else None}
+print(json.dumps(out, indent=1))
