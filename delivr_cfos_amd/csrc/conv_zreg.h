@@ -11,15 +11,17 @@ struct ZrArgs {
     int c1_8, c2_8, D, H, W, tilesX, zseg, nseg, cout8, dbg;
     unsigned gx, gy, gz;
 };
-// tile rows per configuration (launcher and instances must agree)
-#define ZR_TYT_CIN32 8
-#define ZR_TYT_CIN64 8
+// entry points dlv_zr_<format>_c<Cin>_t<tile rows>_a<activate the first input while staging>; the launcher
+// (conv_zreg.hip) picks the tile height: 16 rows for 32-channel inputs whenever the launch still fills the chip with
+// long z-columns (twice the MFMAs per staged plane and per barrier, 1.20x instead of 1.33x halo re-reads), else 8
 #define ZR_DECLARE(name) int name(dlv_ctx* ctx, const ZrArgs& a)
-ZR_DECLARE(dlv_zr_f16_c32_a0);
-ZR_DECLARE(dlv_zr_f16_c32_a1);
-ZR_DECLARE(dlv_zr_f16_c64_a0);
-ZR_DECLARE(dlv_zr_f16_c64_a1);
-ZR_DECLARE(dlv_zr_bf16_c32_a0);
-ZR_DECLARE(dlv_zr_bf16_c32_a1);
-ZR_DECLARE(dlv_zr_bf16_c64_a0);
-ZR_DECLARE(dlv_zr_bf16_c64_a1);
+ZR_DECLARE(dlv_zr_f16_c32_t8_a0);
+ZR_DECLARE(dlv_zr_f16_c32_t8_a1);
+ZR_DECLARE(dlv_zr_f16_c32_t16_a0);
+ZR_DECLARE(dlv_zr_f16_c64_t8_a0);
+ZR_DECLARE(dlv_zr_f16_c64_t8_a1);
+ZR_DECLARE(dlv_zr_bf16_c32_t8_a0);
+ZR_DECLARE(dlv_zr_bf16_c32_t8_a1);
+ZR_DECLARE(dlv_zr_bf16_c32_t16_a0);
+ZR_DECLARE(dlv_zr_bf16_c64_t8_a0);
+ZR_DECLARE(dlv_zr_bf16_c64_t8_a1);

@@ -58,7 +58,12 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: only a 32-channel first input can be activated while staging");
     if ((long long)D * H * W >= (1ll << 27)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets");
     const int ncb = cout / 32;
-    const int tyt = cin == 32 ? ZR_TYT_CIN32 : ZR_TYT_CIN64;
+    const bool act = ss1 != nullptr || ss2 != nullptr;
+    // tile height: 16 rows (Cin = 32 only) when that still gives >= 512 workgroups without cutting the z-columns below 64 planes
+    int tyt = 8;
+    if (cin == 32 && !act && H % 16 == 0 && (long long)B * (H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 512) tyt = 16;
+    static const int force_tyt = getenv("DLV_ZREG_TYT") ? atoi(getenv("DLV_ZREG_TYT")) : 0;  // development A/B
+    if (force_tyt == 8 || (force_tyt == 16 && cin == 32 && !act)) tyt = force_tyt;
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, 32);
     // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
     int zseg = ((D + 15) / 16) * 16;
@@ -74,11 +79,10 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     a.c1_8 = c1 / 8; a.c2_8 = c2 / 8; a.D = D; a.H = H; a.W = W; a.tilesX = tilesX; a.zseg = zseg; a.nseg = nseg; a.cout8 = cout / 8;
     a.dbg = dbg;
     a.gx = (unsigned)(tilesY * tilesX); a.gy = (unsigned)(nseg * ncb); a.gz = (unsigned)B;
-    const bool act = ss1 != nullptr || ss2 != nullptr;
     if (f16) {
-        if (cin == 32) return act ? dlv_zr_f16_c32_a1(ctx, a) : dlv_zr_f16_c32_a0(ctx, a);
-        return act ? dlv_zr_f16_c64_a1(ctx, a) : dlv_zr_f16_c64_a0(ctx, a);
+        if (cin == 32) return act ? dlv_zr_f16_c32_t8_a1(ctx, a) : (tyt == 16 ? dlv_zr_f16_c32_t16_a0(ctx, a) : dlv_zr_f16_c32_t8_a0(ctx, a));
+        return act ? dlv_zr_f16_c64_t8_a1(ctx, a) : dlv_zr_f16_c64_t8_a0(ctx, a);
     }
-    if (cin == 32) return act ? dlv_zr_bf16_c32_a1(ctx, a) : dlv_zr_bf16_c32_a0(ctx, a);
-    return act ? dlv_zr_bf16_c64_a1(ctx, a) : dlv_zr_bf16_c64_a0(ctx, a);
+    if (cin == 32) return act ? dlv_zr_bf16_c32_t8_a1(ctx, a) : (tyt == 16 ? dlv_zr_bf16_c32_t16_a0(ctx, a) : dlv_zr_bf16_c32_t8_a0(ctx, a));
+    return act ? dlv_zr_bf16_c64_t8_a1(ctx, a) : dlv_zr_bf16_c64_t8_a0(ctx, a);
 }

@@ -1,11 +1,6 @@
 // conv_zreg_inst.hip - one instantiation of conv3_zreg_kernel per object file: compiled with
-//   -DZR_INST_NAME=<entry point> -DZR_INST_P=<PF16|PBf16> -DZR_INST_CIN=<32|64> -DZR_INST_ACT=<0|1>   (see the Makefile)
+//   -DZR_INST_NAME=<entry point> -DZR_INST_P=<PF16|PBf16> -DZR_INST_CIN=<32|64> -DZR_INST_TYT=<8|16> -DZR_INST_ACT=<0|1>
+// (see the Makefile)
 #include "conv_zreg_kernel.h"
-
-#if ZR_INST_CIN == 32
-#define ZR_INST_TYT ZR_TYT_CIN32
-#else
-#define ZR_INST_TYT ZR_TYT_CIN64
-#endif
 
 int ZR_INST_NAME(dlv_ctx* ctx, const ZrArgs& a) { return zr_launch<ZR_INST_P, ZR_INST_CIN, ZR_INST_TYT, (ZR_INST_ACT != 0)>(ctx, a); }

@@ -41,6 +41,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;  // native vector: usable with inline-asm register constraints
 
 constexpr int ZR_HX = 34;
+#ifndef ZR_RA16
+#define ZR_RA16 4
+#endif
 #ifndef ZR_RA8
 #define ZR_RA8 2
 #endif
@@ -62,7 +65,7 @@ struct ZrCfg {
     static constexpr int NIT = (PL + 63) / 64;        // 64-lane pieces of one chunk plane
     static constexpr int BUF = NCH * CS;              // uint4 per plane buffer
     static constexpr int RW = TYT / 2;                // output rows per wave
-    static constexpr int RA = CIN == 32 ? (RW <= 4 ? ZR_RA8 : 5) : 1;  // of which accumulate in AGPRs (the rest in VGPRs):
+    static constexpr int RA = CIN == 32 ? (RW <= 4 ? ZR_RA8 : ZR_RA16) : 1;  // of which accumulate in AGPRs (the rest in VGPRs):
                                                       // Cin 32: 108 weights + 120 = 228 AGPR; Cin 64: 216 + 24 = 240 AGPR
     static constexpr int NG = (RW + 2) * KS;          // MFMA groups per step: (input row, k-step)
     static constexpr int NPIECE = SPW * NIT;          // staged pieces per step (<= NG: one per group)

@@ -795,6 +795,106 @@ __global__ void __launch_bounds__(256) deconv2_rows_kernel(const uint4* __restri
     }
 }
 
+// The same op for the two large levels (Cout = 32, Cin <= 64: 2.1 GB of output per 16 windows at the top level, an
+// HBM-write-bound kernel): all 8 taps' weights stay in registers (32 x KP VGPRs), every wave walks DC_IPW consecutive
+// row segments and fetches the next segment's input while the MFMAs and stores of the current one are in flight - the
+// per-segment kernel above re-reads 16 KB of weights through L1 for 8 KB of output and exposes every load latency.
+constexpr int DC_IPW = 8;  // row segments (16 input voxels -> 4 x 32 output voxels x 32 channels = 8 KB) per wave
+
+template <class P, int KP>
+__global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
+                                                           const float* __restrict__ bias, uint4* __restrict__ out, int D,
+                                                           int H, int W, int segs, const float2* __restrict__ ss) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long vox = (long long)D * H * W;
+    const long long nitems = (long long)D * H * segs;
+    const long long item0 = ((long long)blockIdx.x * 4 + wave) * DC_IPW;
+    if (item0 >= nitems) return;
+    const bool odd = col & 1;
+    uint4 w0[4][KP], w1[4][KP];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            w0[ab][kp] = wpk[((long long)(ab * 2 + 0) * KP + kp) * 64 + lane];
+            w1[ab][kp] = wpk[((long long)(ab * 2 + 1) * KP + kp) * 64 + lane];
+        }
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+    float sc[KP][8], sh[KP][8];
+    if (ss) {
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 v = ss[n * (16 * KP) + (2 * kp + h) * 8 + k];
+                sc[kp][k] = v.x;
+                sh[kp][k] = v.y;
+            }
+    }
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int OH = 2 * H, OW = 2 * W;
+    const long long ovox = vox * 8;
+    const uint4* inb = in + ((long long)n * (2 * KP) + h) * vox;
+    auto fetch = [&](long long item, uint4 (&u)[KP]) __attribute__((always_inline)) {
+        const int sg = (int)(item % segs);
+        const long long zy = item / segs;  // z * H + y
+        const int xi = sg * 16 + (col >> 1);
+        const long long vin = zy * W + (xi < W ? xi : 0);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) u[kp] = inb[(long long)(2 * kp) * vox + vin];
+    };
+    uint4 cur[KP], nxt[KP];
+    fetch(item0, cur);
+#pragma unroll 1
+    for (int it = 0; it < DC_IPW; ++it) {
+        const long long item = item0 + it;
+        if (item >= nitems) break;
+        if (item + 1 < nitems && it + 1 < DC_IPW) fetch(item + 1, nxt);
+        const int sg = (int)(item % segs), y = (int)((item / segs) % H), z = (int)(item / ((long long)segs * H));
+        const bool ok = sg * 16 + (col >> 1) < W;
+        uint4 b0[KP], b1[KP];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            uint4 u = cur[kp];
+            if (ss) u = norm_mish8<P>(u, sc[kp], sh[kp], nullptr);  // the input is a raw conv output (wave-uniform branch)
+            b0[kp] = AS_FRAG((ok && !odd) ? u : zero4);
+            b1[kp] = AS_FRAG((ok && odd) ? u : zero4);
+        }
+        const int ox = 2 * sg * 16 + col;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const long long o = ((long long)(2 * z + (ab >> 1)) * OH + (2 * y + (ab & 1))) * OW + ox;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bs[r];
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                acc = P::mfma(AS_FRAG(w0[ab][kp]), b0[kp], acc, 0, 0, 0);
+                acc = P::mfma(AS_FRAG(w1[ab][kp]), b1[kp], acc, 0, 0, 0);
+            }
+            unsigned px[4], py[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                px[g] = P::pack2(acc[4 * g + 0], acc[4 * g + 1]);
+                py[g] = P::pack2(acc[4 * g + 2], acc[4 * g + 3]);
+            }
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                // lanes 0-31 end up with all 8 channels of chunk gp, lanes 32-63 with chunk gp+1
+                const auto sx = __builtin_amdgcn_permlane32_swap(px[gp], px[gp + 1], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(py[gp], py[gp + 1], false, false);
+                if (ok) out[((long long)n * 4 + gp + h) * ovox + o] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) cur[kp] = nxt[kp];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // final: InstanceNorm + Mish of the last block, Conv3d(C5 -> 1, k1), then either plain logits or
 // the blend accumulate of inference/sliding_window_inferer.py:232-251 (acc[window] += logit, un-flipped)
@@ -1068,6 +1168,9 @@ struct Net16 {
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
+        // register-resident weights + segment pipeline where the weights fit (Cout = 32, Cin <= 64) and there is enough work
+        const bool regw = rows && L.cout == 32 && L.cin <= 64 && (long long)din.D * din.H * segs * B >= 4 * DC_IPW * 1024;
+        if (regw) grid.x = dlv_cdiv((long long)din.D * din.H * segs, 4 * DC_IPW);
         char dname[48];
         snprintf(dname, sizeof(dname), "deconv2_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
         DlvProf pr(ctx, dname, 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
@@ -1082,8 +1185,14 @@ struct Net16 {
                                din.D, din.H, din.W);                                                                     \
     } while (0)
         switch (L.cin / 16) {
-            case 2: DLV_DECONV(2); break;
-            case 4: DLV_DECONV(4); break;
+            case 2:
+                if (regw) hipLaunchKernelGGL((deconv2_regw_kernel<P, 2>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, din.D, din.H, din.W, segs, ssin);
+                else DLV_DECONV(2);
+                break;
+            case 4:
+                if (regw) hipLaunchKernelGGL((deconv2_regw_kernel<P, 4>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, din.D, din.H, din.W, segs, ssin);
+                else DLV_DECONV(4);
+                break;
             case 8: DLV_DECONV(8); break;
             case 16: DLV_DECONV(16); break;
             default: return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: Cin=%d not in {32,64,128,256}", j, L.cin);
