@@ -60,7 +60,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __rest
 }
 // stem (Cin = 1, Cout = 32): K = 64 = {hi byte, lo byte} x 32 tap slots (27 used).  The uint16 input is split
 // exactly into x = 256*hi + lo (both exact in bf16), the weights carry the factor 256 for the hi half:
-//   out[(s*64 + lane)*8 + j]: k = 16 s + 8 (lane>>5) + j, part = k>>5, tap = k&31, cout = lane&31
+//   out[(s*64 + lane)*8 + j]: tap = 8 s + 4 (lane>>5) + (j>>1), part = j&1 (0: lo byte, 1: hi byte), cout = lane&31
 template <class P>
 __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,16 +68,10 @@ __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __rest
     const int j = i & 7, lane = (i >> 3) & 63, s = i >> 9;
     const int co = lane & 31;
     float v = 0.f;
-    if (P::IS_F16) {
-        // k-step s, lane half h: taps 8s + 4h + (j >> 1), low byte (j even) then high byte (j odd) of the same tap -
-        // the order in which stem_mfma_kernel builds its operand (one v_perm_b32 per tap)
-        const int tap = 8 * s + 4 * (lane >> 5) + (j >> 1);
-        if (tap < 27) v = w[co * 27 + tap] * ((j & 1) ? 256.f : 1.f) * P::STEM_SCALE;
-    } else {
-        const int k = 16 * s + 8 * (lane >> 5) + j;
-        const int part = k >> 5, tap = k & 31;
-        if (tap < 27) v = w[co * 27 + tap] * (part == 0 ? 256.f : 1.f) * P::STEM_SCALE;
-    }
+    // k-step s, lane half h: taps 8s + 4h + (j >> 1), low byte (j even) then high byte (j odd) of the same tap - the
+    // (lo, hi) pair of one tap is one 32-bit word of the staged tile, i.e. one register of the MFMA operand
+    const int tap = 8 * s + 4 * (lane >> 5) + (j >> 1);
+    if (tap < 27) v = w[co * 27 + tap] * ((j & 1) ? 256.f : 1.f) * P::STEM_SCALE;
     out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
 }
 // deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
@@ -215,15 +209,22 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // MFMA stem for the fused sliding-window path: the uint16 window is staged (with flip and the
-// zero padding of the window border) as a halo tile in LDS; every lane gathers the taps of its voxel,
-// splits them into hi/lo bytes (exact in bf16) and feeds 4 MFMAs (K = 64) per 32-voxel block.
+// zero padding of the window border) as a halo tile in LDS, every voxel already split into its (lo, hi) bytes as a
+// pair of 16-bit floats (exact in bf16 and fp16); every lane gathers the taps of its voxel - one ds_read_b32 per tap
+// is one register of the operand, no VALU - and feeds 4 MFMAs (K = 64) per 32-voxel block.
 //   workgroup: 4 (z) x 8 (y) x 32 (x) output voxels; wave w = z-slice w, 8 row blocks
 // ---------------------------------------------------------------------------------------------------
 constexpr int SM_TZ = 4, SM_TY = 8, SM_TX = 32, SM_HZ = 6, SM_HY = 10, SM_HX = 34;
+constexpr int SM_ZC = 8;                                   // z-chunks of SM_TZ planes one workgroup walks
+constexpr int SM_NT = SM_HZ * SM_HY * SM_HX;               // halo tile voxels
+constexpr int SM_NS = (SM_NT + 255) / 256;                 // staged voxels per thread
 
 // MODE 0: store raw + statistics; MODE 1: statistics only (first pass of the two-pass stem); MODE 2: recompute,
 // apply InstanceNorm scale/shift + Mish and store the ACTIVATED tensor (no raw tensor, no separate norm pass:
-// the K = 64 MFMA work is cheap next to 268 MB of avoided traffic per 128^3 window)
+// the K = 64 MFMA work is cheap next to 268 MB of avoided traffic per 128^3 window).
+// A workgroup owns an 8 x 32 (y, x) column and walks SM_ZC chunks of 4 planes: the per-thread staging addresses, the
+// weights and the statistics registers are set up once per 8192 voxels, the halo tile is double-buffered (the loads of
+// the next chunk fly during the MFMAs of this one, one barrier per chunk), one reduction at the end.
 template <class P, int MODE>
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
                                                         const int* __restrict__ starts, int flip_dim,
@@ -231,34 +232,58 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
                                                         uint4* __restrict__ out, float* __restrict__ partials,
                                                         const float2* __restrict__ ss, int D, int H, int W, int tilesY,
                                                         int tilesX) {
-    __shared__ unsigned short tile_u16[SM_HZ * SM_HY * SM_HX + 2];
+    // the halo tile, already split: word = (lo byte, hi byte) of the voxel as two 16-bit floats (exact in bf16 and fp16)
+    __shared__ unsigned tile[2][SM_NT];
     __shared__ float red[4 * 64];
     const int n = blockIdx.z;
     const int t = blockIdx.x;
-    const int tx = t % tilesX, ty = (t / tilesX) % tilesY, tz = t / (tilesX * tilesY);
-    const int z0 = tz * SM_TZ, y0 = ty * SM_TY, x0 = tx * SM_TX;
+    const int tx = t % tilesX, ty = (t / tilesX) % tilesY, tg = t / (tilesX * tilesY);
+    const int zbase = tg * (SM_ZC * SM_TZ), y0 = ty * SM_TY, x0 = tx * SM_TX;
+    const int nzc = min(SM_ZC, (D - zbase + SM_TZ - 1) / SM_TZ);
     const int wz = starts[3 * n], wy = starts[3 * n + 1], wx = starts[3 * n + 2];
-    for (int i = threadIdx.x; i < SM_HZ * SM_HY * SM_HX; i += 256) {
+    // this thread's staged voxels: in-plane offset into the volume (window origin, flip and y/x validity folded in) and
+    // the halo plane; only the z coordinate moves from chunk to chunk
+    int soff[SM_NS], szh[SM_NS];
+#pragma unroll
+    for (int k = 0; k < SM_NS; ++k) {
+        const int i = threadIdx.x + 256 * k;
         const int xh = i % SM_HX, yh = (i / SM_HX) % SM_HY, zh = i / (SM_HX * SM_HY);
-        int gz = z0 + zh - 1, gy = y0 + yh - 1, gx = x0 + xh - 1;
-        unsigned short v = 0;
-        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-            if (flip_dim == 2) gz = D - 1 - gz;
-            if (flip_dim == 3) gy = H - 1 - gy;
-            if (flip_dim == 4) gx = W - 1 - gx;
-            v = vol[((long long)(wz + gz) * Yp + (wy + gy)) * Xp + (wx + gx)];
-        }
-        tile_u16[i] = v;
+        int gy = y0 + yh - 1, gx = x0 + xh - 1;
+        const bool ok = i < SM_NT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        if (flip_dim == 3) gy = H - 1 - gy;
+        if (flip_dim == 4) gx = W - 1 - gx;
+        soff[k] = ok ? (wy + gy) * Xp + (wx + gx) : -1;
+        szh[k] = zh - 1;
     }
+    const long long plane = (long long)Yp * Xp;
+    unsigned sv[SM_NS];
+    auto stage_load = [&](int zc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < SM_NS; ++k) {
+            int gz = zbase + zc * SM_TZ + szh[k];
+            const bool ok = soff[k] >= 0 && (unsigned)gz < (unsigned)D;
+            if (flip_dim == 2) gz = D - 1 - gz;
+            sv[k] = ok ? (unsigned)vol[(long long)(wz + gz) * plane + soff[k]] : 0u;
+        }
+    };
+    auto stage_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < SM_NS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < SM_NT) tile[buf][i] = P::pack2((float)(sv[k] & 255u), (float)(sv[k] >> 8));
+        }
+    };
+    stage_load(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, col = lane & 31;
     uint4 a[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a[s] = AS_FRAG(wpk[s * 64 + lane]);
-    float bs[16], ssum[16], ssq[16];
+    f32x16 bsv;  // the bias is the C operand of the first MFMA of every row
+    float ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h] * P::STEM_SCALE;
+        bsv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h] * P::STEM_SCALE;
         ssum[r] = ssq[r] = 0.f;
     }
     float nsc[16], nsh[16];
@@ -270,94 +295,62 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
             nsh[r] = v.y;
         }
     }
+    stage_store(0);
     __syncthreads();
     const long long vox = (long long)D * H * W;
-    const int oz = z0 + wave;
-    // fp16: per-lane LDS byte addresses of this lane's 16 taps (k-step s, slot q: tap 8s + 4h + q), row 0; the row
-    // loop is unrolled so that the row offset is an immediate of the ds_read
-    unsigned short const* tap_ptr[16];
-    if (P::IS_F16) {
+    // per-lane LDS offsets of this lane's 16 taps (k-step s, register q: tap 8s + 4h + q), row 0 of buffer 0; the row
+    // loop is unrolled so that the row offset is an immediate of the ds_read_b32
+    int tap_off[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = 8 * (i >> 2) + 4 * h + (i & 3);
-            const int tt = t < 27 ? t : 0;  // padding slots: any finite value (their weights are 0)
-            tap_ptr[i] = tile_u16 + (wave * SM_HY * SM_HX + col) + ((tt / 9) * SM_HY + (tt / 3) % 3) * SM_HX + tt % 3;
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int tp = 8 * (i >> 2) + 4 * h + (i & 3);
+        const int tt = tp < 27 ? tp : 0;  // padding slots: any finite value (their weights are 0)
+        tap_off[i] = (wave * SM_HY * SM_HX + col) + ((tt / 9) * SM_HY + (tt / 3) % 3) * SM_HX + tt % 3;
     }
+#pragma unroll 1
+    for (int zc = 0; zc < nzc; ++zc) {
+        if (zc + 1 < nzc) stage_load(zc + 1);
+        const unsigned* tl = tile[zc & 1];
+        const int oz = zbase + zc * SM_TZ + wave;
 #pragma unroll
-    for (int row = 0; row < SM_TY; ++row) {
-        unsigned hi0[4], lo0[4], hi1[4], lo1[4];
-        if (P::IS_F16) {
-            // x = 256*hi + lo.  (0x6400 | byte) is the fp16 number 1024 + byte: one v_perm_b32 puts both bytes of a tap
-            // into the two halves of a register, one v_pk_add_f16 subtracts the 1024s - exact, 2 VALU ops per tap
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+        for (int row = 0; row < SM_TY; ++row) {
+            unsigned b[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const unsigned u = tap_ptr[i][row * SM_HX];
-                const unsigned m = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
-                const unsigned v = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, m) - k1024);
-                (i < 4 ? hi0 : i < 8 ? hi1 : i < 12 ? lo0 : lo1)[i & 3] = v;  // k-steps 0..3 in MFMA order below
+            for (int i = 0; i < 16; ++i) b[i] = tl[tap_off[i] + row * SM_HX];
+            f32x16 acc = P::mfma(a[0], AS_FRAG(make_uint4(b[0], b[1], b[2], b[3])), bsv, 0, 0, 0);
+            acc = P::mfma(a[1], AS_FRAG(make_uint4(b[4], b[5], b[6], b[7])), acc, 0, 0, 0);
+            acc = P::mfma(a[2], AS_FRAG(make_uint4(b[8], b[9], b[10], b[11])), acc, 0, 0, 0);
+            acc = P::mfma(a[3], AS_FRAG(make_uint4(b[12], b[13], b[14], b[15])), acc, 0, 0, 0);
+            const int oy = y0 + row, ox = x0 + col;
+            const bool ok = oz < D && oy < H && ox < W;
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = acc[r];
+            if (MODE != 2 && ok) {  // one exec-masked block (per-element selects cost two v_cndmask per value)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ssum[r] += val[r];
+                    ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                }
             }
-        } else {
-        // taps of this lane: slots 8h..8h+7 (k-steps 0 and 2) and 16+8h..16+8h+7 (k-steps 1 and 3)
-        const int base = (wave * SM_HY + row) * SM_HX + col;
+            if (MODE == 2) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            float fh[2], fl[2], gh[2], gl[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int j = 2 * jj + e;
-                const int t0 = 8 * h + j, t1 = 16 + 8 * h + j;  // tap slots (h is wave-half uniform per lane)
-                const int o0 = ((t0 / 9) * SM_HY + (t0 / 3) % 3) * SM_HX + t0 % 3;
-                const int o1 = ((t1 / 9) * SM_HY + (t1 / 3) % 3) * SM_HX + t1 % 3;
-                const unsigned u0 = tile_u16[base + o0];
-                const unsigned u1 = t1 < 27 ? tile_u16[base + o1] : 0u;
-                fh[e] = (float)(u0 >> 8);
-                fl[e] = (float)(u0 & 255u);
-                gh[e] = (float)(u1 >> 8);
-                gl[e] = (float)(u1 & 255u);
+                for (int r = 0; r < 16; ++r) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
             }
-            hi0[jj] = P::pack2(fh[0], fh[1]);
-            lo0[jj] = P::pack2(fl[0], fl[1]);
-            hi1[jj] = P::pack2(gh[0], gh[1]);
-            lo1[jj] = P::pack2(gl[0], gl[1]);
-        }
-        }
-        f32x16 acc;
+            if (MODE != 1 && ok) {
+                const long long o = ((long long)oz * H + oy) * W + ox;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = P::mfma(a[0], AS_FRAG(make_uint4(hi0[0], hi0[1], hi0[2], hi0[3])), acc, 0, 0, 0);
-        acc = P::mfma(a[1], AS_FRAG(make_uint4(hi1[0], hi1[1], hi1[2], hi1[3])), acc, 0, 0, 0);
-        acc = P::mfma(a[2], AS_FRAG(make_uint4(lo0[0], lo0[1], lo0[2], lo0[3])), acc, 0, 0, 0);
-        acc = P::mfma(a[3], AS_FRAG(make_uint4(lo1[0], lo1[1], lo1[2], lo1[3])), acc, 0, 0, 0);
-        const int oy = y0 + row, ox = x0 + col;
-        const bool ok = oz < D && oy < H && ox < W;
-        float val[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) val[r] = acc[r] + bs[r];
-        if (MODE != 2 && ok) {  // one exec-masked block (per-element selects cost two v_cndmask per value)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ssum[r] += val[r];
-                ssq[r] = fmaf(val[r], val[r], ssq[r]);
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
+                    u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
+                    uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
+                    dst[h] = u;
+                }
             }
         }
-        if (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
-        }
-        if (MODE != 1 && ok) {
-            const long long o = ((long long)oz * H + oy) * W + ox;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 u;
-                u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
-                u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
-                uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
-                dst[h] = u;
-            }
-        }
+        if (zc + 1 < nzc) stage_store((zc + 1) & 1);
+        __syncthreads();
     }
     if (MODE == 2) return;
 #pragma unroll
@@ -1244,7 +1237,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         const DlvConvLayer& L = ctx->conv[0];
         DlvProf pr(ctx, (vol && !ctx->no_zmarch) ? "stem_mfma_u16" : "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
         if (vol && !ctx->no_zmarch) {
-            const int tY = dlv_cdiv(h, SM_TY), tX = dlv_cdiv(w, SM_TX), tZ = dlv_cdiv(d, SM_TZ);
+            const int tY = dlv_cdiv(h, SM_TY), tX = dlv_cdiv(w, SM_TX), tZ = dlv_cdiv(d, SM_TZ * SM_ZC);
             grid = dim3(tZ * tY * tX, 1, B);
             nblk = grid.x;
             if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");

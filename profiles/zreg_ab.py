@@ -7,7 +7,8 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from delivr_cfos_amd.engine import HipEngine  # noqa: E402
 from delivr_cfos_amd.synth import synth_volume_torch  # noqa: E402
 from delivr_cfos_amd.weights import random_state_dict  # noqa: E402
