@@ -59,15 +59,21 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     if ((long long)D * H * W >= (1ll << 27)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets");
     const int ncb = cout / 32;
     const bool act = ss1 != nullptr || ss2 != nullptr;
-    // tile height: 16 rows (Cin = 32 only) when that still gives >= 512 workgroups without cutting the z-columns below 64 planes
+    // tile height: 16 rows (Cin = 32 only) when that still gives >= 256 workgroups without cutting the z-columns below 64 planes
     int tyt = 8;
-    if (cin == 32 && !act && H % 16 == 0 && (long long)B * (H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 512) tyt = 16;
-    static const int force_tyt = getenv("DLV_ZREG_TYT") ? atoi(getenv("DLV_ZREG_TYT")) : 0;  // development A/B
+    if (cin == 32 && !act && H % 16 == 0 && (long long)B * (H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 256) tyt = 16;
+#ifdef DLV_DIAG  // A/B switches of the diagnostic library (profiles/tools/tyt_ab.sh, minwg_ab.sh)
+    static const int force_tyt = getenv("DLV_ZREG_TYT") ? atoi(getenv("DLV_ZREG_TYT")) : 0;
     if (force_tyt == 8 || (force_tyt == 16 && cin == 32 && !act)) tyt = force_tyt;
+    static const int min_wg = getenv("DLV_ZREG_MINWG") ? atoi(getenv("DLV_ZREG_MINWG")) : 256;
+#else
+    const int min_wg = 256;
+#endif
     const int tilesY = dlv_cdiv(H, tyt), tilesX = dlv_cdiv(W, 32);
-    // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs
+    // split long columns (in multiples of 16 planes) so that small batches still fill 256 CUs; one full-length column per
+    // CU beats two half-length ones (16 windows of 64^3: 395 -> 361 us for 64->32, 247 -> 220 us for 32->32)
     int zseg = ((D + 15) / 16) * 16;
-    while ((long long)B * tilesY * tilesX * ncb * dlv_cdiv(D, zseg) < 512 && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
+    while ((long long)B * tilesY * tilesX * ncb * dlv_cdiv(D, zseg) < min_wg && zseg > 16) zseg = std::max(16, ((zseg / 2 + 15) / 16) * 16);
     const int nseg = dlv_cdiv(D, zseg);
     *nparts = tilesY * tilesX * ((D + 15) / 16);
     char* trash;  // target of the masked-out stores of edge steps / partial tiles

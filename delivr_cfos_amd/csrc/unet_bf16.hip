@@ -36,6 +36,19 @@ __device__ __forceinline__ float mish_fast(float y) {
     return y * (t * __builtin_amdgcn_rcpf(t + 2.f));
 }
 
+// two values at once: the plain operations become packed-f32 instructions (v_pk_mul/add/fma_f32, two lanes' worth of
+// work per issue slot); element for element the same operations as mish_fast, i.e. the same bits
+__device__ __forceinline__ f32x2_t mish_fast2(f32x2_t y) {
+    const f32x2_t c20 = {20.f, 20.f}, l2e = {1.44269504f, 1.44269504f}, two = {2.f, 2.f};
+    const f32x2_t e = __builtin_elementwise_min(y, c20) * l2e;
+    const f32x2_t n = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const f32x2_t t = n * (n + two);
+    const f32x2_t d = t + two;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return y * (t * r);
+}
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ---------------------------------------------------------------------------------------------------
 // weight packing (device side, once per dlv_unet_load)
 // ---------------------------------------------------------------------------------------------------
@@ -335,7 +348,11 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
             }
             if (MODE == 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) val[r] = mish_fast(fmaf(val[r], nsc[r], nsh[r]));
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t m = mish_fast2(fma2(f32x2_t{val[r], val[r + 1]}, f32x2_t{nsc[r], nsc[r + 1]}, f32x2_t{nsh[r], nsh[r + 1]}));
+                    val[r] = m.x;
+                    val[r + 1] = m.y;
+                }
             }
             if (MODE != 1 && ok) {
                 const long long o = ((long long)oz * H + oy) * W + ox;
@@ -600,9 +617,14 @@ template <class P>
 __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const float* sh, float* mx) {
     float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        v[k] = mish_fast(fmaf(v[k], sc[k], sh[k]));
-        if (mx) mx[k] = fmaxf(mx[k], v[k]);
+    for (int k = 0; k < 8; k += 2) {
+        const f32x2_t m = mish_fast2(fma2(f32x2_t{v[k], v[k + 1]}, f32x2_t{sc[k], sc[k + 1]}, f32x2_t{sh[k], sh[k + 1]}));
+        v[k] = m.x;
+        v[k + 1] = m.y;
+        if (mx) {
+            mx[k] = fmaxf(mx[k], v[k]);
+            mx[k + 1] = fmaxf(mx[k + 1], v[k + 1]);
+        }
     }
     uint4 r;
     r.x = P::pack2(v[0], v[1]);
@@ -899,15 +921,18 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
                                                          int flip_dim, int Yp, int Xp, float scale, float* __restrict__ acc,
                                                          int D, int H, int W, const float* __restrict__ bw, float bmin,
                                                          float* __restrict__ wsum) {
-    __shared__ float sc[32], sh[32], ww[32];
     const int n = blockIdx.y;
-    if (threadIdx.x < 32) {
-        const float2 v = ss[n * 32 + threadIdx.x];
-        sc[threadIdx.x] = v.x;
-        sh[threadIdx.x] = v.y;
-        ww[threadIdx.x] = wf[threadIdx.x];
+    // per-sample scale/shift and the 32 weights are uniform over the workgroup: scalar loads, SGPR operands
+    f32x2_t sc[16], sh[16], ww[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float2 v0 = ss[n * 32 + 2 * c], v1 = ss[n * 32 + 2 * c + 1];
+        sc[c] = f32x2_t{v0.x, v1.x};
+        sh[c] = f32x2_t{v0.y, v1.y};
+        float w0 = wf[2 * c], w1 = wf[2 * c + 1];
+        asm volatile("" : "+v"(w0), "+v"(w1));  // 96 uniform values exceed the SGPR file: the weights live in VGPRs
+        ww[c] = f32x2_t{w0, w1};
     }
-    __syncthreads();
     const long long vox = (long long)D * H * W;
     const float b0 = bf[0];
     int z0 = 0, y0 = 0, x0 = 0;
@@ -917,14 +942,18 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
         x0 = starts[3 * n + 2];
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
-        float a = b0;
+        f32x2_t a2 = {b0, 0.f};
 #pragma unroll
         for (int c8 = 0; c8 < 4; ++c8) {
             const uint4 u = x[((long long)n * 4 + c8) * vox + i];
-            const float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
+            const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a = fmaf(mish_fast(fmaf(v[k], sc[8 * c8 + k], sh[8 * c8 + k])), ww[8 * c8 + k], a);
+            for (int k = 0; k < 4; ++k) {
+                const f32x2_t v = {P::lo(uu[k]), P::hi(uu[k])};
+                a2 = fma2(mish_fast2(fma2(v, sc[4 * c8 + k], sh[4 * c8 + k])), ww[4 * c8 + k], a2);
+            }
         }
+        const float a = a2.x + a2.y;
         if (!BLEND) {
             logits[(long long)n * vox + i] = a;
         } else {
