@@ -59,9 +59,11 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     if ((long long)D * H * W >= (1ll << 27)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets");
     const int ncb = cout / 32;
     const bool act = ss1 != nullptr || ss2 != nullptr;
-    // tile height: 16 rows (Cin = 32 only) when that still gives >= 256 workgroups without cutting the z-columns below 64 planes
+    // tile height: 16 rows (Cin = 32 only) for windows large enough that 16 of them fill the chip with z-columns of at
+    // least 64 planes.  The choice depends on the window shape only, never on the batch size: the InstanceNorm partial
+    // sums are per tile, so a window's result must not depend on how many windows share its launch
     int tyt = 8;
-    if (cin == 32 && !act && H % 16 == 0 && (long long)B * (H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 256) tyt = 16;
+    if (cin == 32 && !act && H % 16 == 0 && (long long)(H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 16) tyt = 16;
 #ifdef DLV_DIAG  // A/B switches of the diagnostic library (profiles/tools/tyt_ab.sh, minwg_ab.sh)
     static const int force_tyt = getenv("DLV_ZREG_TYT") ? atoi(getenv("DLV_ZREG_TYT")) : 0;
     if (force_tyt == 8 || (force_tyt == 16 && cin == 32 && !act)) tyt = force_tyt;

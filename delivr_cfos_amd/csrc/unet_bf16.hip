@@ -1190,8 +1190,9 @@ struct Net16 {
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
-        // register-resident weights + segment pipeline where the weights fit (Cout = 32, Cin <= 64) and there is enough work
-        const bool regw = rows && L.cout == 32 && L.cin <= 64 && (long long)din.D * din.H * segs * B >= 4 * DC_IPW * 1024;
+        // register-resident weights + segment pipeline where the weights fit (Cout = 32, Cin <= 64) and a window has enough
+        // row segments (a property of the window shape, not of the batch)
+        const bool regw = rows && L.cout == 32 && L.cin <= 64 && (long long)din.D * din.H * segs >= 4 * DC_IPW * 64;
         if (regw) grid.x = dlv_cdiv((long long)din.D * din.H * segs, 4 * DC_IPW);
         char dname[48];
         snprintf(dname, sizeof(dname), "deconv2_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
