@@ -142,8 +142,11 @@ def test_erosion_random_vs_scipy(eng):
     from oracle import delivr_oracle as orc
 
     rng = np.random.default_rng(4)
-    for shape, r in (((33, 47, 52), 3), ((20, 64, 75), 30), ((5, 9, 13), 1)):
-        raw = (rng.random(shape) > 0.003).astype(np.uint16) * 77
+    # radius 56 is the last one the bit-mask x-distance kernel takes (cap 57), 57 the first on the log-step kernel;
+    # the 300-wide rows with few zeros hold distances beyond both
+    for shape, r, p0 in (((33, 47, 52), 3, 0.003), ((20, 64, 75), 30, 0.003), ((5, 9, 13), 1, 0.003), ((6, 10, 300), 56, 0.0008),
+                         ((6, 10, 300), 57, 0.0008), ((3, 5, 2051), 30, 0.002)):
+        raw = (rng.random(shape) > p0).astype(np.uint16) * 77
         acc = torch.ones(shape, dtype=torch.float32, device="cuda")
         out = eng.finalize(acc, None, eng.to_device(raw), shape, 0.5, r, 0).cpu().numpy()
         np.testing.assert_array_equal(out, orc.erode_l1((raw > 0).astype(np.uint8), r))
