@@ -340,7 +340,7 @@ def main():
                                if net_ms > 0 and world == 1 and lanes == 1 else None)
         return r, kernels
 
-    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else int(os.environ.get("DLV_LANES", "4"))
+    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else int(os.environ.get("DLV_LANES", "3"))
     roofline, kernels = roofline_of(prof, lanes_used, args.steps)
     # the timed region runs two overlapping lanes, which stretches every kernel's event-to-event time; one extra,
     # untimed step on a single lane gives the dominant kernel's own efficiency
@@ -440,7 +440,7 @@ def main():
         },
         # `roofline` describes the dominant kernel itself: measured with HIP events in one extra step on a single lane
         # (DLV_LANES=1 reproduces it over the timed region; profiles/*_1lane_kernel_stats.csv is rocprofv3's view).
-        # In the timed region 4 lanes overlap, which stretches every kernel's event-to-event time: that view is kept
+        # In the timed region the lanes (default 3) overlap, which stretches every kernel's event-to-event time: that view is kept
         # as `roofline_timed_region`.
         "roofline": roofline_isolated if roofline_isolated is not None else roofline,
         "roofline_timed_region": roofline if roofline_isolated is not None else None,

@@ -74,7 +74,7 @@ struct dlv_ctx {
                                         // HBM-bound kernels of one batch overlap the MFMA kernels of another
     hipEvent_t ev_lane[4] = {nullptr, nullptr, nullptr, nullptr};
     int lane = 0;
-    int lanes_wanted = 4;
+    int lanes_wanted = 3;  // C3: 1 lane 6.86 s, 2: 6.58, 3: 6.56, 4: 6.63 per pass (profiles/lanes_sweep.sh, r02)
     hipEvent_t ev_main = nullptr, ev_aux = nullptr;  // lane joins
     bool own_stream = false;
     std::string err;

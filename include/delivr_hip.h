@@ -329,7 +329,7 @@ typedef struct dlv_prof_entry {
     double flops;        /* algorithmic FLOPs summed over those launches */
     double bytes;        /* algorithmic HBM bytes summed over those launches */
 } dlv_prof_entry;
-/* 1 = run batches back to back on the ctx stream; 2 .. 4 (default 4) = rotate consecutive batches over that many HIP
+/* 1 = run batches back to back on the ctx stream; 2 .. 4 (default 3) = rotate consecutive batches over that many HIP
  * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
 int dlv_set_lanes(dlv_ctx* ctx, int lanes);
 int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
