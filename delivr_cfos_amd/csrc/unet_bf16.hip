@@ -471,6 +471,24 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
         for (int j = 0; j < NPF; ++j) pf[j] = src[poff[j]];
     };
     fetch_slab(0);
+    // weight fragments straight from L2 (!WLDS) run through a rolling queue PD k-steps deep that continues across slab
+    // boundaries: the load of step g + PD is issued when step g's fragments are consumed, so an L2 round trip is covered
+    // by PD groups of MFMAs instead of sitting in front of each group (128^3 windows, 16 per launch: 128+128->64 at 32^3
+    // 357 -> 296 us, 256->128 at 16^3 196 -> 166 us).  The same queue for the LDS operand made it slower (registers).
+    constexpr int PD = WLDS ? 1 : (NCB >= 4 ? 2 : 6);  // 54 k-steps per slab: PD divides 54 (NCB 4: 256 VGPRs allow no more)
+    uint4 aq[PD][NCB];
+    const long long nsteps = (long long)nslab * 54;
+    auto wfetch = [&](long long g, uint4 (&dst)[NCB]) __attribute__((always_inline)) {
+        const int sl2 = (int)(g / 54), st = (int)(g % 54);
+        const int t = st >> 1, kp = sl2 * 2 + (st & 1);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) dst[cb] = wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
+    };
+    if (!WLDS) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+            if (q < nsteps) wfetch(q, aq[q]);
+    }
     for (int sl = 0; sl < nslab; ++sl) {
         __syncthreads();  // previous slab fully consumed
 #pragma unroll
@@ -499,13 +517,14 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
                     const int toff = (kz * T::HY + ky) * T::HX + kx;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const int kp = sl * 2 + ks;
+                        const int st = t * 2 + ks;
                         uint4 a[NCB];
 #pragma unroll
-                        for (int cb = 0; cb < NCB; ++cb) {
-                            const uint4 u = WLDS ? wlds[((cb * 27 + t) * 2 + ks) * 64 + lane]
-                                                 : wpk[(((long long)(cbg0 + cb) * 27 + t) * KP + kp) * 64 + lane];
-                            a[cb] = AS_FRAG(u);
+                        for (int cb = 0; cb < NCB; ++cb)
+                            a[cb] = AS_FRAG(WLDS ? wlds[((cb * 27 + t) * 2 + ks) * 64 + lane] : aq[st % PD][cb]);
+                        if (!WLDS) {
+                            const long long g = (long long)sl * 54 + st + PD;
+                            if (g < nsteps) wfetch(g, aq[st % PD]);
                         }
                         uint4 b[2];
 #pragma unroll
