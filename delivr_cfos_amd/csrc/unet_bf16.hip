@@ -929,6 +929,81 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
     }
 }
 
+// The deep levels (Cin >= 128): few voxels, many weights - the per-segment kernel re-reads all 8 x Cin x Cout weights for
+// every 16 input voxels (524 KB per wave at 256 -> 128).  Here a wave keeps the fragments of ONE (output parity pair ab,
+// 32-channel output block cb) in registers (2 x KP) and walks DW_IPW row segments with them; grid.y enumerates (ab, cb).
+constexpr int DW_IPW = 4;
+
+template <class P, int KP>
+__global__ void __launch_bounds__(256) deconv2_wst_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
+                                                          const float* __restrict__ bias, uint4* __restrict__ out, int cout,
+                                                          int D, int H, int W, int segs, const float2* __restrict__ ss) {
+    const int n = blockIdx.z;
+    const int CB = cout / 32, cout8 = cout / 8;
+    const int ab = blockIdx.y / CB, cb = blockIdx.y % CB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const long long vox = (long long)D * H * W;
+    const long long nitems = (long long)D * H * segs;
+    const long long item0 = ((long long)blockIdx.x * 4 + wave) * DW_IPW;
+    if (item0 >= nitems) return;
+    const bool odd = col & 1;
+    uint4 w0[KP], w1[KP];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        w0[kp] = wpk[(((long long)(ab * 2 + 0) * CB + cb) * KP + kp) * 64 + lane];
+        w1[kp] = wpk[(((long long)(ab * 2 + 1) * CB + cb) * KP + kp) * 64 + lane];
+    }
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bs[r] = bias[cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int OH = 2 * H, OW = 2 * W;
+    const long long ovox = vox * 8;
+    const uint4* inb = in + ((long long)n * (2 * KP) + h) * vox;
+#pragma unroll 1
+    for (int it = 0; it < DW_IPW; ++it) {
+        const long long item = item0 + it;
+        if (item >= nitems) break;
+        const int sg = (int)(item % segs), y = (int)((item / segs) % H), z = (int)(item / ((long long)segs * H));
+        const int xi = sg * 16 + (col >> 1);
+        const bool ok = xi < W;
+        const long long vin = ((long long)z * H + y) * W + (ok ? xi : 0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bs[r];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            uint4 u = inb[(long long)(2 * kp) * vox + vin];
+            if (ss) {  // the input is the raw output of a conv: its InstanceNorm + Mish are applied here (wave-uniform branch)
+                float sc[8], sh[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float2 v = ss[n * (16 * KP) + (2 * kp + h) * 8 + k];
+                    sc[k] = v.x;
+                    sh[k] = v.y;
+                }
+                u = norm_mish8<P>(u, sc, sh, nullptr);
+            }
+            acc = P::mfma(AS_FRAG(w0[kp]), AS_FRAG((ok && !odd) ? u : zero4), acc, 0, 0, 0);
+            acc = P::mfma(AS_FRAG(w1[kp]), AS_FRAG((ok && odd) ? u : zero4), acc, 0, 0, 0);
+        }
+        const long long o = ((long long)(2 * z + (ab >> 1)) * OH + (2 * y + (ab & 1))) * OW + 2 * sg * 16 + col;
+        unsigned px[4], py[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            px[g] = P::pack2(acc[4 * g + 0], acc[4 * g + 1]);
+            py[g] = P::pack2(acc[4 * g + 2], acc[4 * g + 3]);
+        }
+#pragma unroll
+        for (int gp = 0; gp < 4; gp += 2) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(px[gp], px[gp + 1], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(py[gp], py[gp + 1], false, false);
+            if (ok) out[((long long)n * cout8 + cb * 4 + gp + h) * ovox + o] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // final: InstanceNorm + Mish of the last block, Conv3d(C5 -> 1, k1), then either plain logits or
 // the blend accumulate of inference/sliding_window_inferer.py:232-251 (acc[window] += logit, un-flipped)
@@ -1204,7 +1279,9 @@ struct Net16 {
         const DlvDeconvLayer& L = ctx->deconv[j];
         const uint4* w = reinterpret_cast<const uint4*>(wpack<P>(L));
         const bool rows = !ctx->no_zmarch;
-        if (!rows) DLV_TRY(materialise(a, din));  // the per-parity kernel has no activation on load
+        // the per-parity kernel has no activation on load; the weight-stationary kernel of the deep levels (Cin >= 128) would
+        // repeat it for every (parity, output block) it enumerates: there the (small) input is activated by one norm pass
+        if (!rows || L.cin >= 128) DLV_TRY(materialise(a, din));
         const uint4* in = a.p;
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
@@ -1235,8 +1312,14 @@ struct Net16 {
                 if (regw) hipLaunchKernelGGL((deconv2_regw_kernel<P, 4>), grid, dim3(256), 0, ctx->stream, in, w, L.bias, out, din.D, din.H, din.W, segs, ssin);
                 else DLV_DECONV(4);
                 break;
-            case 8: DLV_DECONV(8); break;
-            case 16: DLV_DECONV(16); break;
+            case 8:
+                if (rows) hipLaunchKernelGGL((deconv2_wst_kernel<P, 8>), dim3(dlv_cdiv((long long)din.D * din.H * segs, 4 * DW_IPW), 4 * (L.cout / 32), B), dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W, segs, ssin);
+                else DLV_DECONV(8);
+                break;
+            case 16:
+                if (rows) hipLaunchKernelGGL((deconv2_wst_kernel<P, 16>), dim3(dlv_cdiv((long long)din.D * din.H * segs, 4 * DW_IPW), 4 * (L.cout / 32), B), dim3(256), 0, ctx->stream, in, w, L.bias, out, L.cout, din.D, din.H, din.W, segs, ssin);
+                else DLV_DECONV(16);
+                break;
             default: return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: Cin=%d not in {32,64,128,256}", j, L.cin);
         }
 #undef DLV_DECONV
