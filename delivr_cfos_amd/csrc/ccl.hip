@@ -43,31 +43,56 @@ __device__ __forceinline__ void uf_union(u32* L, u32 a, u32 b) {
     }
 }
 
-__global__ void __launch_bounds__(256) ccl_init_kernel(u32* __restrict__ L, u64 n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) L[i] = (u32)i;
+// foreground bits of the 16 voxels [i0, i0 + 16) of the mask (bit k = voxel i0 + k); one 16-byte load when the chunk is
+// whole and the mask pointer is 16-byte aligned (i0 is a multiple of 16).  A sparse mask (cells: < 1 % foreground) is
+// scanned at 16 voxels per load, and every kernel below returns early on a chunk without foreground.
+__device__ __forceinline__ unsigned mask_bits16(const uint8_t* __restrict__ mask, u64 i0, u64 n, bool aligned) {
+    unsigned bits = 0;
+    if (aligned && i0 + 16 <= n) {
+        const uint4 u = *reinterpret_cast<const uint4*>(mask + i0);
+        if ((u.x | u.y | u.z | u.w) == 0u) return 0u;
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if ((w[q] >> (8 * b)) & 0xffu) bits |= 1u << (4 * q + b);
+    } else {
+        for (int k = 0; k < 16; ++k)
+            if (i0 + k < n && mask[i0 + k]) bits |= 1u << k;
+    }
+    return bits;
 }
 
-// one thread per 4 consecutive x voxels of a row (rows are padded virtually: x+3 may exceed X)
+// parents of the foreground voxels only (the background entries of L are never read: 17 GB of writes less on a
+// 2^32-voxel volume)
+__global__ void __launch_bounds__(256) ccl_init_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n,
+                                                       bool aligned) {
+    const u64 nch = (n + 15) / 16;
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
+        unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            L[c * 16 + k] = (u32)(c * 16 + k);
+        }
+    }
+}
+
+// one thread per 16 consecutive voxels (linear index; a chunk may straddle rows): for every foreground voxel the
+// 13 neighbours that precede it in raster order
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, int Z,
-                                                        int Y, int X) {
-    const int xq = (X + 3) / 4;
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (u64)Z * Y * xq) return;
-    const int x0 = (int)(t % xq) * 4;
-    const int y = (int)((t / xq) % Y);
-    const int z = (int)(t / ((u64)xq * Y));
-    const u64 row = ((u64)z * Y + y) * X;
-    unsigned bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (x0 + k < X && mask[row + x0 + k]) bits |= 1u << k;
-    if (!bits) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!(bits & (1u << k))) continue;
-        const int x = x0 + k;
-        const u64 i = row + x;
-        // 13 neighbours that precede voxel i in raster order
+                                                        int Y, int X, u64 n, bool aligned) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * 16 >= n) return;
+    unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const u64 i = c * 16 + k;
+        const int x = (int)(i % (u64)X);
+        const u64 r = i / (u64)X;
+        const int y = (int)(r % (u64)Y), z = (int)(r / (u64)Y);
         for (int dz = -1; dz <= 0; ++dz) {
             const int zz = z + dz;
             if (zz < 0) continue;
@@ -87,13 +112,20 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) ccl_compress_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        if (mask[i]) {
+__global__ void __launch_bounds__(256) ccl_compress_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n,
+                                                           bool aligned) {
+    const u64 nch = (n + 15) / 16;
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
+        unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const u64 i = c * 16 + k;
             u32 r = (u32)i, p;
             while ((p = L[r]) != r) r = p;
             L[i] = r;  // racing writers store the same root; readers that see an older parent still reach it
         }
+    }
 }
 
 constexpr int RPT = 16;                 // voxels per thread in the renumbering kernels
@@ -117,12 +149,14 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 }
 
 __global__ void __launch_bounds__(256) ccl_count_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
-                                                              u64 n, u32* __restrict__ counts) {
+                                                              u64 n, u32* __restrict__ counts, bool aligned) {
     const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
     int c = 0;
-    for (int k = 0; k < RPT; ++k) {
-        const u64 i = base + k;
-        if (i < n && mask[i] && L[i] == (u32)i) ++c;
+    unsigned bits = base < n ? mask_bits16(mask, base, n, aligned) : 0u;
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        if (L[base + k] == (u32)(base + k)) ++c;
     }
     int total;
     block_excl_scan(c, &total);
@@ -158,26 +192,52 @@ __global__ void __launch_bounds__(1024) ccl_scan_counts_kernel(u32* __restrict__
 
 __global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
                                                                u64 n, const u32* __restrict__ offsets,
-                                                               u32* __restrict__ labels) {
+                                                               u32* __restrict__ labels, bool aligned) {
     const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
     int c = 0;
-    for (int k = 0; k < RPT; ++k) {
-        const u64 i = base + k;
-        if (i < n && mask[i] && L[i] == (u32)i) ++c;
+    unsigned roots = 0;
+    unsigned bits = base < n ? mask_bits16(mask, base, n, aligned) : 0u;
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        if (L[base + k] == (u32)(base + k)) {
+            ++c;
+            roots |= 1u << k;
+        }
     }
     int total;
     u32 rank = offsets[blockIdx.x] + (u32)block_excl_scan(c, &total);
-    for (int k = 0; k < RPT; ++k) {
-        const u64 i = base + k;
-        if (i < n && mask[i] && L[i] == (u32)i) labels[i] = ++rank;
+    while (roots) {
+        const int k = __ffs((int)roots) - 1;
+        roots &= roots - 1;
+        labels[base + k] = ++rank;
     }
 }
 
+// every voxel of the label volume is written exactly once here (16 voxels = four 16-byte stores per thread): 0 for the
+// background, the root's label for the rest (roots already hold theirs)
 __global__ void __launch_bounds__(256) ccl_relabel_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
-                                                          u64 n, u32* __restrict__ labels) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        if (!mask[i]) labels[i] = 0;
-        else if (L[i] != (u32)i) labels[i] = labels[L[i]];
+                                                          u64 n, u32* __restrict__ labels, bool aligned) {
+    const u64 nch = (n + 15) / 16;
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
+        const u64 base = c * 16;
+        const unsigned bits = mask_bits16(mask, base, n, aligned);
+        u32 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = 0;
+            if (bits & (1u << k)) {
+                const u32 r = L[base + k];
+                v[k] = labels[r];  // r == base + k for a root: its label was assigned by ccl_assign_roots_kernel
+            }
+        }
+        if (aligned && base + 16 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(labels + base + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        } else {
+            for (int k = 0; k < 16 && base + k < n; ++k) labels[base + k] = v[k];
+        }
     }
 }
 
@@ -379,23 +439,26 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     DLV_TRY(dlv_ws_get(ctx, WS_CCL, parent_bytes + (size_t)(nb + 1) * 4 + 256, (void**)&ws));
     u32* L = (u32*)ws;
     u32* counts = (u32*)(ws + ((parent_bytes + 255) & ~(size_t)255));
-    const int gs = (int)std::min<u64>((n + 255) / 256, (u64)256 * 64);
-    DlvProf pr(ctx, "ccl26", 0.0, (double)n * (1 + 4 + 4 + 4));
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, L, n);
+    const u64 nch = (n + 15) / 16;
+    const int gs = (int)std::min<u64>((nch + 255) / 256, (u64)256 * 64);
+    // 16-byte accesses need the mask 16-byte and the labels 16-byte aligned (hipMalloc / torch allocations are)
+    const bool aligned = ((reinterpret_cast<uintptr_t>(mask_dev) | reinterpret_cast<uintptr_t>(labels_dev)) & 15) == 0;
+    // algorithmic bytes: the mask is scanned by 6 kernels (1 B each), the labels are written once (4 B)
+    DlvProf pr(ctx, "ccl26", 0.0, (double)n * (6 + 4));
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_init_kernel");
-    const u64 nt = (u64)Z * Y * ((X + 3) / 4);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, mask_dev, L, Z, Y, X);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, ctx->stream, mask_dev, L, Z, Y, X, n, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_merge_kernel");
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n);
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_compress_kernel");
-    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts);
+    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_count_roots_kernel");
     hipLaunchKernelGGL(ccl_scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, nb);
     DLV_LAUNCH_CHECK(ctx, "ccl_scan_counts_kernel");
     hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts,
-                       labels_dev);
+                       labels_dev, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_assign_roots_kernel");
-    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, labels_dev);
+    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, labels_dev, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_relabel_kernel");
     pr.end();
     u32 total = 0;
