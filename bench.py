@@ -326,7 +326,7 @@ def main():
                     k = tj["kernels"][name]
                     r["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
                     t = k["traffic_bytes"]
-                    if scaled and k.get("algorithmic_bytes"):
+                    if k.get("algorithmic_bytes"):  # the PMC run's launches held a different number of windows on average
                         t *= r["algorithmic_bytes"] / k["algorithmic_bytes"]
                     r["traffic"] = t
                     r["traffic_over_algorithmic"] = t / r["algorithmic_bytes"] if r["algorithmic_bytes"] else None
