@@ -343,6 +343,14 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             const int n_epi = erow >= 0 ? EPI_OPS : 0;
             const int n_side = n_frag + n_act + n_piece + n_epi;
             auto side = [&](int k) __attribute__((always_inline)) {
+#ifdef ZR_ABL  // timing-only ablation builds (WRONG results; `make abl`, never part of libdelivr_hip.so): bit 0 no barrier,
+               // bit 1 no epilogue (statistics, pack, store), bit 2 no global loads of the plane after next, bit 3 no fragment
+               // reads, bit 4 no LDS writes of the next plane
+                if ((ZR_ABL & 8) && k < n_frag) return;
+                if ((ZR_ABL & 2) && k >= n_frag && k < n_frag + n_epi) return;
+                if ((ZR_ABL & 16) && k >= n_frag + n_epi && k <= n_frag + n_epi + n_act) return;
+                if ((ZR_ABL & 4) && k > n_frag + n_epi + n_act) return;
+#endif
                 if (k < n_frag) {
                     load_frag(g + 1, k);
                 } else if (k < n_frag + n_epi) {
@@ -400,7 +408,16 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             }
             if (g == 0) flush_check(p - 2);  // plane p-2 is complete (its last row was emitted in this group)
         }
+#ifdef ZR_ABL
+        if (ZR_ABL & 16) {  // the loads stay alive although nothing writes them to LDS
+#pragma unroll
+            for (int q2 = 0; q2 < C::NPIECE; ++q2) asm volatile("" ::"v"(pre[q2 / C::NIT][q2 % C::NIT]));
+        }
+#endif
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes of plane p+1 have landed
+#ifdef ZR_ABL
+        if (!(ZR_ABL & 1))
+#endif
         __builtin_amdgcn_s_barrier();        // plane p+1 visible; everybody is done reading plane p
     };
 
