@@ -142,6 +142,16 @@ struct DlvProf {
 
 static inline int dlv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware tile order for kernels whose gridDim.x enumerates spatial tiles (row-major: x, then y, then z neighbours):
+// workgroups go round-robin to the 8 XCDs (each with its own L2), so with gridDim.x a multiple of 8 the XCD of a workgroup
+// is blockIdx.x % 8; every XCD gets a contiguous run of tiles instead of every 8th one, neighbouring tiles run at the same
+// time and find each other's halo lines in their L2 (z-reg conv, PMC: 1.27x / 1.47x -> 1.06x / 1.08x of the algorithmic bytes)
+#ifdef __HIPCC__
+__device__ __forceinline__ int dlv_xcd_tile(unsigned bx, unsigned gx) {
+    return (gx % 8 == 0) ? (int)((bx % 8) * (gx / 8) + bx / 8) : (int)bx;
+}
+#endif
+
 // ---- internal engine entry points (defined in the .hip files) ---------------------------------
 int dlv_unet_forward_f32(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
 int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16);

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64 * TYT / VB, MINW) conv3_zmarch_kernel(const
     // blockIdx.y = z segment + nseg * output-channel block (32 channels each; Cout = 64 layers run two blocks
     // over the same input)
     const int seg = blockIdx.y % nseg, cb = blockIdx.y / nseg;
-    const int tile = blockIdx.x;
+    const int tile = dlv_xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int y0 = ty * TYT, x0 = tx * ZM_TX;
     const int zs = seg * zseg, ze = min(zs + zseg, D);  // output planes [zs, ze)

@@ -130,7 +130,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
 
     const int n = blockIdx.z;
     const int seg = blockIdx.y % nseg, cb = blockIdx.y / nseg;       // z segment, 32-channel output block
-    const int tile = blockIdx.x;
+    const int tile = dlv_xcd_tile(blockIdx.x, gridDim.x);  // XCD-aware tile order (common.h)
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int y0 = ty * TYT, x0 = tx * 32;
     const int zs = seg * zseg, ze = min(zs + zseg, D);               // output planes [zs, ze)

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
     __shared__ unsigned tile[2][SM_NT];
     __shared__ float red[4 * 64];
     const int n = blockIdx.z;
-    const int t = blockIdx.x;
+    const int t = dlv_xcd_tile(blockIdx.x, gridDim.x);
     const int tx = t % tilesX, ty = (t / tilesX) % tilesY, tg = t / (tilesX * tilesY);
     const int zbase = tg * (SM_ZC * SM_TZ), y0 = ty * SM_TY, x0 = tx * SM_TX;
     const int nzc = min(SM_ZC, (D - zbase + SM_TZ - 1) / SM_TZ);
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
     uint4* slab = reinterpret_cast<uint4*>(smem_raw);
     uint4* wlds = slab + T::SLAB;  // WLDS: this slab's weights, [cb][tap][k-step][lane]
     const int n = blockIdx.z;
-    const int tile = blockIdx.x;
+    const int tile = dlv_xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, tz = tile / (tilesX * tilesY);
     const int z0 = tz * T::TZ, y0 = ty * T::TY, x0 = tx * TX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
