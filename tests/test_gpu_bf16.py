@@ -312,3 +312,53 @@ def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     # the default build carries no conv bias (InstanceNorm removes it), the LDS-weights builds do: the stored raw values
     # round differently
     assert (out - base).abs().max() < 2 * tol_max
+
+
+_SWITCH_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from delivr_cfos_amd.engine import HipEngine
+from delivr_cfos_amd.synth import synth_volume_np
+from delivr_cfos_amd.weights import random_state_dict
+eng = HipEngine(0)
+eng.load_state_dict({"state_dict": random_state_dict(0)})
+vol = synth_volume_np((64, 96, 128), seed=9, dense=True)
+acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+eng.sw_infer(eng.make_sw_params(vol.shape, (64, 64, 64), 0.5, None, 0, sys.argv[3]), eng.to_device(vol), acc)
+eng.sync()
+np.save(sys.argv[2], acc.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, prec):
+    """Every environment switch the product library reads selects kernels, never results: the activation fused into the
+    z-reg conv's staging (DLV_FUSE_LEVELS), edge-step code on every plane (DLV_ZREG_DBG), the LDS-weights z-march instead
+    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes.  The switches are read once
+    per process, hence one process per setting; 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env):
+        out = str(tmp_path / ("acc_" + "_".join(f"{k}{v}" for k, v in env.items()) + ".npy"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([sys.executable, "-c", _SWITCH_SNIPPET, root, out, prec], env=e, timeout=600)
+        return np.load(out)
+
+    base = run({})
+    std = float(base.std())
+    # bit-identical: same arithmetic in another order of execution / another code path of the same kernel
+    for env in ({"DLV_LANES": "1"}, {"DLV_ZREG_DBG": "1"}, {"DLV_GENERIC_NCB": "1"}):
+        np.testing.assert_array_equal(run(env), base, err_msg=str(env))
+    # same values up to the rounding of one 16-bit store (activation applied while staging: the activated tensor is never
+    # rounded through HBM differently, but the InstanceNorm partial sums are taken over other tiles) / another kernel
+    tol = 2e-3 if prec == "fp16" else 2e-2
+    for env in ({"DLV_FUSE_LEVELS": "1"}, {"DLV_FUSE_LEVELS": "3"}, {"DLV_ZREG_MASK": "0"}):
+        a = run(env)
+        rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
+        print(env, "rel rms vs default:", rel)
+        assert rel < tol, (env, rel)
