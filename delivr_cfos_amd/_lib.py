@@ -127,6 +127,7 @@ SIGNATURES = {
     "dlv_cc_stats_raw_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint64, _P, _P, _P, _P]),
     "dlv_paint_owner_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_uint64, _P]),
     "dlv_paint_apply_dev": (C.c_int, [_P, _P, _P, C.c_uint64, _P, C.c_int, _P]),
+    "dlv_edt_u16_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "dlv_heatmap_counts_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "dlv_gauss_blur_f32_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dlv_tiff_last_error": (C.c_char_p, []),

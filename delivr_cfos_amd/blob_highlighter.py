@@ -61,9 +61,14 @@ def blob_highlighter(settings, brain_item, stack_shape, engine=None):
     brain = brain_item[0]
     viz = settings["visualization"]
     if viz.get("no_atlas_depthmap"):
-        # the reference's depth_map_blobs indexes its 3-D memmap with four indices (blob_depthmap.py:139) and raises
-        # IndexError before it paints anything: there is no behaviour to mirror
-        raise NotImplementedError("no_atlas_depthmap: the reference path raises IndexError at blob_depthmap.py:139")
+        # "only map the blobs over their distance from the sample's outside" (:163-165; no atlas, hence no cell table -
+        # the reference skips loading it at :67-69).  Its depth_map_blobs cannot run (IndexError at blob_depthmap.py:139);
+        # the mirror implements what the function states after that line (blob_depthmap.py in this package)
+        from .blob_depthmap import depth_map_blobs
+
+        depth_map_blobs(settings, brain, stack_shape, engine=engine)
+        print(f"{datetime.datetime.now()} : Cleanup")
+        return
     path_binary = viz["input_prediction_location"]
     path_cell_csv = viz["input_csv_location"]
     path_out = viz["output_location"]

@@ -209,3 +209,116 @@ int dlv_gauss_blur_f32_dev(dlv_ctx* ctx, float* vol_dev, int Z, int Y, int X, co
 }
 
 }  // extern "C"
+
+// ---- exact Euclidean distance transform (depth-coded blob map, blob_depthmap.py:160-170) -----------------------
+// scipy.ndimage.distance_transform_edt(np.pad(stack, 1), sampling=(sz, sy, sx))[1:-1, 1:-1, 1:-1].astype(uint16): distance
+// of every non-zero voxel to the nearest zero voxel, the volume being surrounded by zeros.  Separable exact algorithm
+// (Felzenszwalb / Huttenlocher lower envelope of parabolas) in fp64: x by two scans, then y and z by one envelope per
+// line; the zeros of the padding are two extra parabolas of height 0 at positions -1 and n of every line.
+namespace {
+
+#pragma clang fp contract(off)
+
+// f[z][y][x] = (dx * sx)^2, dx = voxels to the nearest zero along x (the padding counts)
+__global__ void __launch_bounds__(256) edt_x_kernel(const uint16_t* __restrict__ in, double* __restrict__ f, long long rows, int X,
+                                                    double sx) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const uint16_t* a = in + r * X;
+    double* o = f + r * X;
+    int d = 0;  // distance to the zero at x = -1 is x + 1
+    for (int x = 0; x < X; ++x) {
+        d = a[x] ? d + 1 : 0;
+        o[x] = (double)d;
+    }
+    d = 0;
+    for (int x = X - 1; x >= 0; --x) {
+        d = a[x] ? d + 1 : 0;
+        const double m = fmin(o[x], (double)d) * sx;
+        o[x] = m * m;
+    }
+}
+
+// one line of n values at stride `stride`: g[p] = min_q f[q] + ((p - q) * w)^2 over q in -1 .. n with f[-1] = f[n] = 0
+__global__ void __launch_bounds__(64) edt_line_kernel(double* __restrict__ f, long long lines, long long inner, long long outer_stride,
+                                                      long long stride, int n, double w, int* __restrict__ vbuf,
+                                                      double* __restrict__ zbuf, double* __restrict__ gbuf) {
+    const long long l = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (l >= lines) return;
+    double* line = f + (l / inner) * outer_stride + (l % inner);
+    int* v = vbuf + l * (n + 2);
+    double* z = zbuf + l * (n + 3);
+    double* g = gbuf + l * (n + 2);
+    const int m = n + 2;  // extended positions 0 .. n+1 <-> voxel positions -1 .. n
+    auto fe = [&](int q) -> double { return (q == 0 || q == m - 1) ? 0.0 : line[(long long)(q - 1) * stride]; };
+    const double w2 = w * w;
+    int k = 0;
+    v[0] = 0;
+    z[0] = -INFINITY;
+    z[1] = INFINITY;
+    for (int q = 1; q < m; ++q) {
+        const double fq = fe(q) + w2 * ((double)q * (double)q);
+        double s;
+        while (true) {
+            const int vk = v[k];
+            s = (fq - (fe(vk) + w2 * ((double)vk * (double)vk))) / (2.0 * w2 * (double)(q - vk));
+            if (s <= z[k] && k > 0) --k;
+            else break;
+        }
+        ++k;
+        v[k] = q;
+        z[k] = s;
+        z[k + 1] = INFINITY;
+    }
+    k = 0;
+    for (int p = 1; p < m - 1; ++p) {
+        while (z[k + 1] < (double)p) ++k;
+        const double dd = (double)(p - v[k]) * w;
+        g[p] = dd * dd + fe(v[k]);
+    }
+    for (int p = 1; p < m - 1; ++p) line[(long long)(p - 1) * stride] = g[p];
+}
+
+__global__ void __launch_bounds__(256) edt_sqrt_u16_kernel(const double* __restrict__ f, uint16_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (uint16_t)(unsigned long long)sqrt(f[i]);  // numpy's astype(uint16): truncation, modulo 2^16
+}
+
+}  // namespace
+
+extern "C" int dlv_edt_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int Y, int X, const double* sampling_zyx,
+                               uint16_t* out_dev) {
+    if (!ctx || !in_dev || !out_dev || !sampling_zyx) return DLV_EINVAL;
+    if (Z <= 0 || Y <= 0 || X <= 0) return dlv_fail(ctx, DLV_EINVAL, "bad shape");
+    for (int k = 0; k < 3; ++k)
+        if (!(sampling_zyx[k] > 0.0) || sampling_zyx[k] > 1e9) return dlv_fail(ctx, DLV_EINVAL, "sampling must be positive");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nvox = (long long)Z * Y * X;
+    const int nmax = std::max(Y, Z);
+    const long long lmax = std::max((long long)Z * X, (long long)Y * X);  // lines along y / along z
+    // [f: nvox doubles | z: lmax*(nmax+3) doubles | g: lmax*(nmax+2) doubles | v: lmax*(nmax+2) ints]
+    const size_t off_z = (size_t)nvox * 8, off_g = off_z + (size_t)lmax * (nmax + 3) * 8, off_v = off_g + (size_t)lmax * (nmax + 2) * 8;
+    char* ws;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, off_v + (size_t)lmax * (nmax + 2) * 4, (void**)&ws));
+    double* f = (double*)ws;
+    double* zb = (double*)(ws + off_z);
+    double* gb = (double*)(ws + off_g);
+    int* vb = (int*)(ws + off_v);
+    DlvProf p(ctx, "edt_u16", 0.0, 2.0 * nvox + 6.0 * 8.0 * nvox);
+    hipLaunchKernelGGL(edt_x_kernel, dim3((unsigned)(((long long)Z * Y + 255) / 256)), dim3(256), 0, ctx->stream, in_dev, f,
+                       (long long)Z * Y, X, sampling_zyx[2]);
+    DLV_LAUNCH_CHECK(ctx, "edt_x_kernel");
+    // along y: lines (z, x): base = z * Y*X + x, stride X
+    hipLaunchKernelGGL(edt_line_kernel, dim3((unsigned)(((long long)Z * X + 63) / 64)), dim3(64), 0, ctx->stream, f, (long long)Z * X,
+                       (long long)X, (long long)Y * X, (long long)X, Y, sampling_zyx[1], vb, zb, gb);
+    DLV_LAUNCH_CHECK(ctx, "edt_line_kernel(y)");
+    // along z: lines (y, x): base = y * X + x, stride Y*X
+    hipLaunchKernelGGL(edt_line_kernel, dim3((unsigned)(((long long)Y * X + 63) / 64)), dim3(64), 0, ctx->stream, f, (long long)Y * X,
+                       (long long)Y * X, 0LL, (long long)Y * X, Z, sampling_zyx[0], vb, zb, gb);
+    DLV_LAUNCH_CHECK(ctx, "edt_line_kernel(z)");
+    hipLaunchKernelGGL(edt_sqrt_u16_kernel, dim3((unsigned)std::min<long long>((nvox + 255) / 256, 65536)), dim3(256), 0, ctx->stream,
+                       f, out_dev, nvox);
+    p.end();
+    DLV_LAUNCH_CHECK(ctx, "edt_sqrt_u16_kernel");
+    return DLV_OK;
+}

@@ -491,6 +491,19 @@ class HipEngine:
         self.sync()
 
     # ---- blob painting -----------------------------------------------------------------------------
+    def edt_u16(self, stack, sampling_zyx):
+        """blob_depthmap.py:160-170: exact Euclidean distance (units of `sampling_zyx`) of every non-zero voxel of the
+        uint16 stack to the nearest zero voxel, the stack surrounded by zeros; truncated to uint16 (dlv_edt_u16_dev)."""
+        torch = self.torch
+        Z, Y, X = (int(v) for v in stack.shape)
+        out = torch.empty((Z, Y, X), dtype=torch.uint16, device=self.device)
+        samp = (C.c_double * 3)(*[float(v) for v in sampling_zyx])
+        self._enter()
+        self._check(self.lib.dlv_edt_u16_dev(self.ctx, self._dev(stack, torch.uint16, "stack"), Z, Y, X, samp,
+                                             C.c_void_p(out.data_ptr())))
+        self._leave()
+        return out
+
     def paint_boxes(self, bin_img, boxes: np.ndarray, values):
         """blob_highlighter.py:108-125 / :150-158 on the device.  bin_img: uint8 (Z,Y,X) in HBM; boxes (n,6) int32
         half-open slices in painting order; values: list of (n,) uint8 / uint16 arrays (one image per array).

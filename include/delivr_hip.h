@@ -284,6 +284,14 @@ int dlv_paint_owner_dev(dlv_ctx* ctx, const uint8_t* bin_dev, int Z, int Y, int 
 int dlv_paint_apply_dev(dlv_ctx* ctx, const uint32_t* owner_dev, const uint8_t* bin_dev, uint64_t nvox,
                         const void* values_dev, int elem_bytes, void* out_dev);
 
+/* Depth-coded blob map (blob_depthmap.py:160-170): scipy.ndimage.distance_transform_edt(np.pad(stack, 1), sampling)
+ * [1:-1,1:-1,1:-1].astype(np.uint16) of the down-sampled masked stack - the distance (in the units of `sampling_zyx`, 3
+ * doubles on the host) of every non-zero voxel to the nearest zero voxel, the stack being surrounded by zeros; exact
+ * (separable lower-envelope algorithm in fp64), truncated to uint16 like numpy's astype.  The painting itself
+ * (blob_depthmap.py:186-198: IMG[box] = bin_img[box] * depth_of_the_cell) is dlv_paint_owner_dev + dlv_paint_apply_dev. */
+int dlv_edt_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int Y, int X, const double* sampling_zyx, uint16_t* out_dev);
+
+
 /* ---- cell-density heat map in atlas space (region assignment step) --------------- */
 /* create_heatmap (cells_to_atlas.py:174-200): heat (Z,Y,X) float32 = number of cells per atlas voxel (cells (n,3) int32
  * = x,y,z as in the reference's columns; cells outside the grid are ignored - the reference drops them before, :139-144),

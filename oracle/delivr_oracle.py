@@ -489,6 +489,33 @@ def paint_blobs(bin_img: np.ndarray, bounding_boxes: np.ndarray, cc_ids: Sequenc
     return out
 
 
+def edt_depth_u16(masked_stack: np.ndarray, sampling_zyx: Sequence[float]) -> np.ndarray:
+    """blob_depthmap.py:160-170: zero-pad, scipy's exact Euclidean distance transform with anisotropic sampling, crop,
+    astype(uint16)."""
+    from scipy.ndimage import distance_transform_edt
+
+    padded = np.pad(masked_stack, ((1, 1), (1, 1), (1, 1)))
+    dist = distance_transform_edt(padded, sampling=tuple(float(v) for v in sampling_zyx))
+    return dist[1:-1, 1:-1, 1:-1].astype(np.uint16)
+
+
+def depth_map_blobs(bin_img: np.ndarray, stats: dict, n: int, masked_stack: np.ndarray, down_um_zyx: Sequence[float],
+                    orig_um_zyx: Sequence[float]) -> np.ndarray:
+    """blob_depthmap.py:158-198 as written (the function cannot run in the reference: `bin_img[0,:,:,:]` on a 3-D memmap at
+    :139 raises IndexError; everything after it is restated literally): depth = EDT of the down-sampled masked stack at
+    the cell's centroid scaled to the down-sampled grid (astype(int)); `for cc_id in range(N)` walks the STATISTICS rows,
+    i.e. row 0 (background: the whole volume's box) first and never row N; later boxes overwrite earlier ones."""
+    distances = edt_depth_u16(masked_stack, down_um_zyx)
+    coords = np.asarray(stats["centroids"], dtype=np.float64).copy()
+    for k in range(3):
+        coords[:, k] = coords[:, k] / (float(down_um_zyx[k]) / float(orig_um_zyx[k]))
+    coords = coords.astype(int)
+    stack_shape = (1, 1) + tuple(bin_img.shape)
+    bbs = np.asarray(stats["bounding_boxes"]).copy()
+    depths = [int(distances[coords[c, 0], coords[c, 1], coords[c, 2]]) for c in range(n)]
+    return paint_blobs(bin_img, bbs, list(range(n)), np.asarray(depths, dtype=np.int64), stack_shape, np.uint16)
+
+
 def atlas_to_ccf(cells: dict, label_shape: Sequence[int]) -> dict:
     """mbrainaligner_atlas_to_ccf (cells_to_atlas.py:114-151), column by column."""
     c = {k: np.asarray(v, dtype=np.float64).copy() for k, v in cells.items()}

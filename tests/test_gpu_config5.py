@@ -131,3 +131,77 @@ def test_config5_chain_downsample_warp_inference_cells_coordinates(tmp_path):
     np.testing.assert_allclose(orc.scale_coords(cells_raw, raw.shape, ds_ref.shape), ref_ds, rtol=0, atol=1e-9)  # and back down
     if n_ref:
         assert cells_raw.shape == (n_ref, 3) and (cells_raw[:, 0] <= raw.shape[0] * 1.1).all()
+
+
+@pytest.mark.parametrize("sampling", [(25.0, 25.0, 25.0), (6.0, 2.5, 2.5), (3.0, 1.0, 1.0)])
+def test_edt_bit_exact_vs_scipy(sampling):
+    """dlv_edt_u16_dev against the oracle (scipy's distance_transform_edt of the zero-padded stack, astype(uint16)):
+    blobs of tissue with holes, a slab that touches the border, an all-foreground and an all-zero volume."""
+    from delivr_cfos_amd.engine import HipEngine
+    from oracle import delivr_oracle as orc
+
+    eng = HipEngine(0)
+    rng = np.random.default_rng(12)
+    cases = []
+    z, y, x = np.mgrid[0:37, 0:52, 0:45]
+    ell = (((z - 18) / 15.0) ** 2 + ((y - 26) / 22.0) ** 2 + ((x - 22) / 19.0) ** 2 < 1.0)
+    holes = rng.random(ell.shape) < 0.002
+    cases.append((ell & ~holes).astype(np.uint16) * 900)
+    slab = np.zeros((20, 30, 33), dtype=np.uint16)
+    slab[:, 5:, :20] = 7
+    cases.append(slab)
+    cases.append(np.full((9, 11, 13), 3, dtype=np.uint16))
+    cases.append(np.zeros((5, 6, 7), dtype=np.uint16))
+    cases.append((rng.random((24, 40, 31)) > 0.01).astype(np.uint16))
+    for vol in cases:
+        got = eng.edt_u16(eng.to_device(vol), sampling).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.edt_depth_u16(vol, sampling))
+    eng.close()
+
+
+def test_depth_map_blobs_files_vs_oracle(tmp_path):
+    """blob_depthmap.depth_map_blobs end to end (binaries.npy + down-sampled masked stack -> depthmap_####.tif planes)
+    against the oracle's literal restatement of the reference loop (statistics row 0 = background painted first)."""
+    from delivr_cfos_amd import blob_depthmap
+    from delivr_cfos_amd.downsample.downsample_and_mask import read_tiff_plane
+    from delivr_cfos_amd.engine import HipEngine
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(3)
+    shape = (24, 40, 48)
+    orig_um, down_um = (6.0, 2.0, 2.0), (12.0, 8.0, 8.0)
+    ds_shape = tuple(int(n * o / d) for n, o, d in zip(shape, orig_um, down_um))  # (12, 10, 12)
+    zz, yy, xx = np.mgrid[0:ds_shape[0], 0:ds_shape[1], 0:ds_shape[2]]
+    stack = ((((zz - 5.5) / 5.0) ** 2 + ((yy - 4.5) / 4.2) ** 2 + ((xx - 5.5) / 5.2) ** 2) < 1.0).astype(np.uint16) * 1200
+    bin_img = np.zeros(shape, dtype=np.uint8)
+    for _ in range(30):
+        c = [int(rng.integers(2, n - 3)) for n in shape]
+        bin_img[c[0]:c[0] + 2, c[1]:c[1] + 3, c[2]:c[2] + 2] = 1
+    brain = "brainA"
+    pred = tmp_path / "pred"
+    (pred / (brain + "_out") / "binary_segmentations").mkdir(parents=True)
+    with open(pred / (brain + "_out") / "binary_segmentations" / "binaries.npy", "wb") as fh:
+        fh.write(b"\x00" * 128)
+        fh.write(bin_img.tobytes())
+    (tmp_path / "mask" / brain).mkdir(parents=True)
+    np.save(tmp_path / "mask" / brain / "downsampled_masked_stack.npy", stack)
+    (tmp_path / "post").mkdir()
+    settings = {
+        "visualization": {"input_prediction_location": str(pred) + "/", "output_location": str(tmp_path / "viz"),
+                          "cache_location": str(tmp_path / "cache")},
+        "postprocessing": {"output_location": str(tmp_path / "post")},
+        "mask_detection": {"output_location": str(tmp_path / "mask"),
+                           "downsample_steps": {"original_um_x": orig_um[2], "original_um_y": orig_um[1], "original_um_z": orig_um[0],
+                                                "downsample_um_x": down_um[2], "downsample_um_y": down_um[1], "downsample_um_z": down_um[0]}},
+        "FLAGS": {"LOAD_ALL_RAM": True},
+    }
+    eng = HipEngine(0)
+    blob_depthmap.depth_map_blobs(settings, brain, (1, 1) + shape, engine=eng)
+    labels, n = orc.ccl26(bin_img)
+    stats = orc.cc_stats(labels, n)
+    want = orc.depth_map_blobs(bin_img, stats, n, stack, down_um, orig_um)
+    out_dir = tmp_path / "viz" / brain / (brain + "_depthmap_tiffs")
+    got = np.stack([read_tiff_plane(str(out_dir / ("depthmap_" + str(z).zfill(4) + ".tif"))) for z in range(shape[0])])
+    np.testing.assert_array_equal(got, want)
+    assert int((want > 0).sum()) > 0
+    eng.close()
