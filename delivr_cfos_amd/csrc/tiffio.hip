@@ -2,15 +2,19 @@
 //
 // The reference reads its raw stacks plane by plane with cv2.imread / skimage.io / tifffile
 // (downsample/downsample_and_mask.py:25-30, :36-41, :396-404) - codecs from third-party libraries, one plane at a
-// time on one core.  Once inference takes seconds, that dominates the wall clock.  Here: a classic-TIFF reader
-// (little/big endian, strips, 8/16-bit single channel, compression 1 = none and 5 = LZW with or without the
-// horizontal predictor - what light-sheet stitchers and the reference's own writers emit, blob_highlighter.py:131)
-// decodes planes on a pool of host threads straight into pinned staging buffers, from which they are copied to
-// their z offset in the device volume while the next planes are being decoded.
-// Decoder pinned by fixtures written with libtiff (tests/golden/tiff_*.tif, tests/test_host_cpu.py).
+// time on one core.  Once inference takes seconds, that dominates the wall clock.  Here: a TIFF reader (classic and
+// BigTIFF, little/big endian, strips or tiles, 8/16-bit single channel, compression 1 = none, 5 = LZW, 8 / 32946 =
+// deflate through zlib, each with or without the horizontal predictor - what light-sheet stitchers and the reference's
+// own writers emit, blob_highlighter.py:131, and what its libtiff-based readers accept) decodes planes on a pool of host
+// threads straight into pinned staging buffers, from which they are copied to their z offset in the device volume while
+// the next planes are being decoded.
+// Decoder pinned by fixtures written with libtiff or decoded by it when they were written by hand (tiles, compressed
+// BigTIFF): tests/golden/tiff_*.tif, oracle/make_goldens.py, tests/test_host_cpu.py.
 #include "common.h"
 
 #include <atomic>
+#include <zlib.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -20,10 +24,13 @@
 namespace {
 
 struct TiffInfo {
-    bool big = false;
+    bool big = false;      // big-endian ("MM")
+    bool big_tiff = false; // BigTIFF (magic 43: 8-byte offsets, 20-byte IFD entries)
+    bool tiled = false;    // TileWidth / TileLength / TileOffsets / TileByteCounts instead of strips
     uint32_t width = 0, height = 0, bits = 1, compression = 1, samples = 1, rows_per_strip = 0xffffffffu, predictor = 1,
-             photometric = 1, planar = 1, sample_format = 1;
-    std::vector<uint64_t> strip_off, strip_len;
+             photometric = 1, planar = 1, sample_format = 1, tile_w = 0, tile_h = 0;
+    std::vector<uint64_t> strip_off, strip_len;  // strips, or tiles in row-major tile order
+    std::vector<uint64_t> tile_off, tile_len;
 };
 
 struct Reader {
@@ -36,22 +43,25 @@ struct Reader {
         return big ? ((uint32_t)p[o] << 24 | (uint32_t)p[o + 1] << 16 | (uint32_t)p[o + 2] << 8 | p[o + 3])
                    : ((uint32_t)p[o] | (uint32_t)p[o + 1] << 8 | (uint32_t)p[o + 2] << 16 | (uint32_t)p[o + 3] << 24);
     }
+    uint64_t u64(size_t o) const { return big ? ((uint64_t)u32(o) << 32 | u32(o + 4)) : ((uint64_t)u32(o + 4) << 32 | u32(o)); }
 };
 
-// values of an IFD entry (types BYTE 1, SHORT 3, LONG 4) as u64
-bool entry_values(const Reader& r, size_t e, std::vector<uint64_t>& out) {
+// values of an IFD entry (types BYTE 1, SHORT 3, LONG 4, and in BigTIFF LONG8 16) as u64.  Classic entries are 12 bytes
+// (count u32, 4 bytes of value / offset), BigTIFF entries 20 bytes (count u64, 8 bytes of value / offset)
+bool entry_values(const Reader& r, size_t e, bool big_tiff, std::vector<uint64_t>& out) {
     const uint16_t type = r.u16(e + 2);
-    const uint32_t count = r.u32(e + 4);
-    const size_t sz = type == 1 ? 1 : type == 3 ? 2 : type == 4 ? 4 : 0;
+    const uint64_t count = big_tiff ? r.u64(e + 4) : r.u32(e + 4);
+    const size_t sz = type == 1 ? 1 : type == 3 ? 2 : type == 4 ? 4 : (type == 16 && big_tiff) ? 8 : 0;
     if (!sz || count > (1u << 28)) return false;
-    size_t off = e + 8;
-    if ((size_t)count * sz > 4) {
-        off = r.u32(e + 8);
+    const size_t inline_bytes = big_tiff ? 8 : 4;
+    size_t off = e + (big_tiff ? 12 : 8);
+    if ((size_t)count * sz > inline_bytes) {
+        off = big_tiff ? (size_t)r.u64(off) : r.u32(off);
         if (!r.ok(off, (size_t)count * sz)) return false;
     }
     out.resize(count);
-    for (uint32_t i = 0; i < count; ++i)
-        out[i] = sz == 1 ? r.p[off + i] : sz == 2 ? r.u16(off + 2 * i) : r.u32(off + 4 * i);
+    for (uint64_t i = 0; i < count; ++i)
+        out[i] = sz == 1 ? r.p[off + i] : sz == 2 ? r.u16(off + 2 * i) : sz == 4 ? r.u32(off + 4 * i) : r.u64(off + 8 * i);
     return true;
 }
 
@@ -61,19 +71,35 @@ const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
     else if (data[0] == 'M' && data[1] == 'M') t.big = true;
     else return "not a TIFF file";
     Reader r{data, n, t.big};
-    if (r.u16(2) != 42) return "not a classic TIFF (BigTIFF is not supported)";
-    const size_t ifd = r.u32(4);
-    if (!r.ok(ifd, 2)) return "IFD offset outside the file";
-    const uint16_t ne = r.u16(ifd);
-    if (!r.ok(ifd + 2, (size_t)ne * 12)) return "IFD truncated";
+    const uint16_t magic = r.u16(2);
+    if (magic != 42 && magic != 43) return "not a TIFF file (magic is neither 42 nor 43)";
+    t.big_tiff = magic == 43;
+    size_t ifd, ne, esz, e0;
+    if (t.big_tiff) {
+        if (n < 16 || r.u16(4) != 8 || r.u16(6) != 0) return "BigTIFF header with an offset size other than 8";
+        ifd = (size_t)r.u64(8);
+        if (!r.ok(ifd, 8)) return "IFD offset outside the file";
+        const uint64_t cnt = r.u64(ifd);
+        if (cnt > 65535) return "implausible IFD entry count";
+        ne = (size_t)cnt;
+        esz = 20;
+        e0 = ifd + 8;
+    } else {
+        ifd = r.u32(4);
+        if (!r.ok(ifd, 2)) return "IFD offset outside the file";
+        ne = r.u16(ifd);
+        esz = 12;
+        e0 = ifd + 2;
+    }
+    if (!r.ok(e0, ne * esz)) return "IFD truncated";
     std::vector<uint64_t> v;
-    for (uint16_t i = 0; i < ne; ++i) {
-        const size_t e = ifd + 2 + (size_t)i * 12;
+    for (size_t i = 0; i < ne; ++i) {
+        const size_t e = e0 + i * esz;
         const uint16_t tag = r.u16(e);
         if (tag != 256 && tag != 257 && tag != 258 && tag != 259 && tag != 262 && tag != 273 && tag != 277 && tag != 278 &&
-            tag != 279 && tag != 284 && tag != 317 && tag != 339)
+            tag != 279 && tag != 284 && tag != 317 && tag != 322 && tag != 323 && tag != 324 && tag != 325 && tag != 339)
             continue;
-        if (!entry_values(r, e, v) || v.empty()) return "unsupported IFD entry type";
+        if (!entry_values(r, e, t.big_tiff, v) || v.empty()) return "unsupported IFD entry type";
         switch (tag) {
             case 256: t.width = (uint32_t)v[0]; break;
             case 257: t.height = (uint32_t)v[0]; break;
@@ -86,6 +112,10 @@ const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
             case 279: t.strip_len = v; break;
             case 284: t.planar = (uint32_t)v[0]; break;
             case 317: t.predictor = (uint32_t)v[0]; break;
+            case 322: t.tile_w = (uint32_t)v[0]; break;
+            case 323: t.tile_h = (uint32_t)v[0]; break;
+            case 324: t.tile_off = v; break;
+            case 325: t.tile_len = v; break;
             case 339: t.sample_format = (uint32_t)v[0]; break;
         }
     }
@@ -94,12 +124,20 @@ const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
     if (t.samples != 1) return "only single-channel planes are supported";
     if (t.bits != 8 && t.bits != 16) return "only 8- and 16-bit samples are supported";
     if (t.sample_format != 1) return "only unsigned integer samples are supported";
-    if (t.compression != 1 && t.compression != 5) return "only uncompressed and LZW planes are supported";
+    if (t.compression != 1 && t.compression != 5 && t.compression != 8 && t.compression != 32946)
+        return "only uncompressed, LZW and deflate planes are supported";
     if (t.predictor != 1 && t.predictor != 2) return "unsupported predictor";
-    if (t.strip_off.empty() || t.strip_off.size() != t.strip_len.size()) return "strip tables missing (tiled TIFF is not supported)";
-    if (t.rows_per_strip == 0) return "RowsPerStrip is 0";
+    if (!t.tile_off.empty() || t.tile_w || t.tile_h) {  // tiled: the tile tables take the place of the strip tables
+        if (!t.tile_w || !t.tile_h || t.tile_w > (1u << 16) || t.tile_h > (1u << 16)) return "tile size missing or implausible";
+        if (t.tile_off.empty() || t.tile_off.size() != t.tile_len.size()) return "tile tables missing";
+        t.tiled = true;
+        t.strip_off = t.tile_off;
+        t.strip_len = t.tile_len;
+    }
+    if (t.strip_off.empty() || t.strip_off.size() != t.strip_len.size()) return "strip tables missing";
+    if (!t.tiled && t.rows_per_strip == 0) return "RowsPerStrip is 0";
     for (size_t i = 0; i < t.strip_off.size(); ++i)
-        if (!r.ok((size_t)t.strip_off[i], (size_t)t.strip_len[i])) return "strip outside the file";
+        if (!r.ok((size_t)t.strip_off[i], (size_t)t.strip_len[i])) return "strip or tile outside the file";
     return nullptr;
 }
 
@@ -167,50 +205,63 @@ size_t lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
     return op < cap ? op : cap;
 }
 
-// decodes one plane into out (row-major uint16, 8-bit samples are widened); returns nullptr or an error text
+// decodes one plane into out (row-major uint16, 8-bit samples are widened); returns nullptr or an error text.
+// Segments are strips (full image width, RowsPerStrip rows, the last one short) or tiles (TileWidth x TileLength, always
+// stored whole, row-major tile order); every segment is decompressed on its own, the horizontal predictor runs along the
+// rows of the segment, and the part of it that lies inside the image is copied out.
 const char* decode_plane(const uint8_t* data, size_t n, const TiffInfo& t, uint16_t* out, std::vector<uint8_t>& scratch) {
     const size_t bps = t.bits / 8;
-    const size_t row_bytes = (size_t)t.width * bps;
-    const uint32_t rps = t.rows_per_strip < t.height ? t.rows_per_strip : t.height;
-    const size_t nstrips = ((size_t)t.height + rps - 1) / rps;
-    if (t.strip_off.size() < nstrips) return "fewer strips than the image needs";
-    scratch.resize((size_t)rps * row_bytes);
-    for (size_t s = 0; s < nstrips; ++s) {
-        const uint32_t r0 = (uint32_t)(s * rps);
-        const uint32_t rows = r0 + rps <= t.height ? rps : t.height - r0;
-        const size_t want = (size_t)rows * row_bytes;
-        const uint8_t* src = data + t.strip_off[s];
-        const uint8_t* raw;
-        if (t.compression == 1) {
-            if (t.strip_len[s] < want) return "uncompressed strip shorter than its rows";
-            raw = src;
-        } else {
-            if (lzw_decode(src, (size_t)t.strip_len[s], scratch.data(), want) != want) return "LZW strip does not decode to its rows";
-            raw = scratch.data();
-        }
-        for (uint32_t r = 0; r < rows; ++r) {
-            const uint8_t* in = raw + (size_t)r * row_bytes;
-            uint16_t* o = out + (size_t)(r0 + r) * t.width;
-            if (bps == 1) {
-                uint8_t acc = 0;
-                for (uint32_t x = 0; x < t.width; ++x) {
-                    const uint8_t v = t.predictor == 2 ? (uint8_t)(acc + in[x]) : in[x];
-                    acc = v;
-                    o[x] = v;
-                }
-            } else if (!t.big && t.predictor == 1) {
-                memcpy(o, in, row_bytes);  // little-endian samples are already in host order
-            } else {
-                uint16_t acc = 0;
-                for (uint32_t x = 0; x < t.width; ++x) {
-                    const uint16_t w = t.big ? (uint16_t)(in[2 * x] << 8 | in[2 * x + 1]) : (uint16_t)(in[2 * x] | in[2 * x + 1] << 8);
-                    const uint16_t v = t.predictor == 2 ? (uint16_t)(acc + w) : w;
-                    acc = v;
-                    o[x] = v;
+    const uint32_t seg_w = t.tiled ? t.tile_w : t.width;
+    const uint32_t seg_h = t.tiled ? t.tile_h : (t.rows_per_strip < t.height ? t.rows_per_strip : t.height);
+    const size_t nx = ((size_t)t.width + seg_w - 1) / seg_w, ny = ((size_t)t.height + seg_h - 1) / seg_h;
+    if (t.strip_off.size() < nx * ny) return t.tiled ? "fewer tiles than the image needs" : "fewer strips than the image needs";
+    const size_t seg_row_bytes = (size_t)seg_w * bps;
+    scratch.resize((size_t)seg_h * seg_row_bytes);
+    for (size_t sy = 0; sy < ny; ++sy)
+        for (size_t sx = 0; sx < nx; ++sx) {
+            const size_t s = sy * nx + sx;
+            const uint32_t r0 = (uint32_t)(sy * seg_h), c0 = (uint32_t)(sx * seg_w);
+            const uint32_t rows_in = r0 + seg_h <= t.height ? seg_h : t.height - r0;  // rows of the segment inside the image
+            const uint32_t cols_in = c0 + seg_w <= t.width ? seg_w : t.width - c0;
+            const uint32_t rows_stored = t.tiled ? seg_h : rows_in;                    // tiles are stored whole
+            const size_t want = (size_t)rows_stored * seg_row_bytes;
+            const uint8_t* src = data + t.strip_off[s];
+            const uint8_t* raw;
+            if (t.compression == 1) {
+                if (t.strip_len[s] < want) return "uncompressed segment shorter than its rows";
+                raw = src;
+            } else if (t.compression == 5) {
+                if (lzw_decode(src, (size_t)t.strip_len[s], scratch.data(), want) != want) return "LZW segment does not decode to its rows";
+                raw = scratch.data();
+            } else {  // 8 / 32946: zlib stream
+                uLongf got = (uLongf)want;
+                if (uncompress(scratch.data(), &got, src, (uLong)t.strip_len[s]) != Z_OK || (size_t)got != want)
+                    return "deflate segment does not decode to its rows";
+                raw = scratch.data();
+            }
+            for (uint32_t r = 0; r < rows_in; ++r) {
+                const uint8_t* in = raw + (size_t)r * seg_row_bytes;
+                uint16_t* o = out + (size_t)(r0 + r) * t.width + c0;
+                if (bps == 1) {
+                    uint8_t acc = 0;
+                    for (uint32_t x = 0; x < cols_in; ++x) {
+                        const uint8_t v = t.predictor == 2 ? (uint8_t)(acc + in[x]) : in[x];
+                        acc = v;
+                        o[x] = v;
+                    }
+                } else if (!t.big && t.predictor == 1) {
+                    memcpy(o, in, (size_t)cols_in * 2);  // little-endian samples are already in host order
+                } else {
+                    uint16_t acc = 0;
+                    for (uint32_t x = 0; x < cols_in; ++x) {
+                        const uint16_t w = t.big ? (uint16_t)(in[2 * x] << 8 | in[2 * x + 1]) : (uint16_t)(in[2 * x] | in[2 * x + 1] << 8);
+                        const uint16_t v = t.predictor == 2 ? (uint16_t)(acc + w) : w;
+                        acc = v;
+                        o[x] = v;
+                    }
                 }
             }
         }
-    }
     if (t.photometric == 0) {  // WhiteIsZero
         const uint16_t top = t.bits == 8 ? 255 : 65535;
         for (size_t i = 0; i < (size_t)t.width * t.height; ++i) out[i] = (uint16_t)(top - out[i]);

@@ -14,49 +14,17 @@ from __future__ import annotations
 
 import glob
 import os
-import struct
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
 from ..hostlogic import downsample_ratios, padded_shape
 
-_TIFF_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 16: "Q"}
-
-
-def _tiff_ifd(path: str):
-    with open(path, "rb") as fh:
-        head = fh.read(8)
-        if head[:2] not in (b"II", b"MM"):
-            raise ValueError(f"{path}: not a TIFF file")
-        e = "<" if head[:2] == b"II" else ">"
-        if struct.unpack(e + "H", head[2:4])[0] != 42:
-            raise ValueError(f"{path}: BigTIFF/unknown magic is not supported")
-        off = struct.unpack(e + "I", head[4:8])[0]
-        fh.seek(off)
-        n = struct.unpack(e + "H", fh.read(2))[0]
-        tags = {}
-        for _ in range(n):
-            tag, typ, cnt, val = struct.unpack(e + "HHI4s", fh.read(12))
-            size = {1: 1, 2: 1, 3: 2, 4: 4}.get(typ)
-            if size is None:
-                continue
-            fmt = e + {1: "B", 2: "c", 3: "H", 4: "I"}[typ] * cnt
-            if size * cnt <= 4:
-                vals = struct.unpack(fmt, val[: size * cnt])
-            else:
-                pos = fh.tell()
-                fh.seek(struct.unpack(e + "I", val)[0])
-                vals = struct.unpack(fmt, fh.read(size * cnt))
-                fh.seek(pos)
-            tags[tag] = vals
-        return e, tags
-
-
 def read_tiff_plane(path: str) -> np.ndarray:
-    """One z-plane as uint16 (8-bit planes are widened): classic TIFF, strips, uncompressed or LZW (with or without the
-    horizontal predictor), decoded by the native reader in libdelivr_hip.so (csrc/tiffio.hip; host code, no GPU needed).
-    Anything else (tiles, BigTIFF, deflate/JPEG, multi-channel) raises NotImplementedError."""
+    """One z-plane as uint16 (8-bit planes are widened): classic TIFF or BigTIFF, strips or tiles, uncompressed / LZW /
+    deflate (with or without the horizontal predictor), decoded by the native reader in libdelivr_hip.so
+    (csrc/tiffio.hip; host code, no GPU needed).  Anything else (JPEG, multi-channel, float samples) raises
+    NotImplementedError."""
     import ctypes as C
 
     from .. import _lib
@@ -103,8 +71,16 @@ def get_real_size(raw_folder: str) -> Tuple[int, int, int]:
     shape) - here from the TIFF header alone, no decode.  A folder holding ``stack.npy`` is accepted too."""
     names = sorted(i for i in os.listdir(raw_folder) if ".tif" in i)
     if names:
-        _, t = _tiff_ifd(os.path.join(raw_folder, names[0]))
-        return (len(names), int(t[257][0]), int(t[256][0]))
+        import ctypes as C
+
+        from .. import _lib
+
+        lib = _lib.load()
+        h, w, bits = C.c_int(), C.c_int(), C.c_int()
+        rc = lib.dlv_tiff_plane_size(os.path.join(raw_folder, names[0]).encode(), C.byref(h), C.byref(w), C.byref(bits))
+        if rc != 0:
+            raise (FileNotFoundError if rc == -1 else NotImplementedError)(lib.dlv_tiff_last_error().decode())
+        return (len(names), h.value, w.value)
     npy = os.path.join(raw_folder, "stack.npy")
     if os.path.isfile(npy):
         return tuple(int(v) for v in np.load(npy, mmap_mode="r").shape[-3:])

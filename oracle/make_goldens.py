@@ -537,7 +537,105 @@ def golden_tiff():
         assert (np.array(im) == {"tiff_lzw8.tif": b, "tiff_be16.tif": c}.get(f, a)).all()
 
 
-if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "unet_c1":
+def golden_tiff_variants():
+    """The TIFF variants libtiff-based readers (the reference's cv2 / tifffile / skimage) accept beyond LZW strips: deflate
+    (with and without the predictor) and BigTIFF written by libtiff through Pillow; tiled planes (uncompressed, and deflate
+    with the predictor; edge tiles padded) written by hand here - Pillow cannot write tiles - and read back through libtiff
+    before they are kept."""
+    import struct
+    import zlib
+
+    from PIL import Image
+
+    rng = np.random.default_rng(14)
+    a = (np.cumsum(rng.integers(-3, 4, (70, 50)), axis=1) + 3000).clip(0, 65535).astype(np.uint16)
+    a[20:30, 10:40] = rng.integers(0, 65535, (10, 30))
+    b = rng.integers(0, 256, (45, 67)).astype(np.uint8)
+    Image.fromarray(a).save(os.path.join(GOLD, "tiff_deflate16.tif"), compression="tiff_adobe_deflate")
+    Image.fromarray(a).save(os.path.join(GOLD, "tiff_deflate16_pred.tif"), compression="tiff_adobe_deflate", tiffinfo={317: 2, 278: 16})
+    Image.fromarray(b).save(os.path.join(GOLD, "tiff_big8.tif"), big_tiff=True)  # (Pillow writes BigTIFF uncompressed only)
+
+    def write_bigtiff_deflate(path, img, rows_per_strip):
+        H, W = img.shape
+        strips = [zlib.compress(img[r:r + rows_per_strip].astype("<u2").tobytes(), 6) for r in range(0, H, rows_per_strip)]
+        off = 16
+        offs = []
+        for t in strips:
+            offs.append(off)
+            off += len(t) + (-len(t) % 8)
+        tab = off                                   # StripOffsets (LONG8), StripByteCounts (LONG8)
+        ifd = tab + 16 * len(strips)
+        tags = [(256, 4, 1, W), (257, 4, 1, H), (258, 3, 1, 16), (259, 3, 1, 8), (262, 3, 1, 1), (273, 16, len(strips), tab),
+                (277, 3, 1, 1), (278, 4, 1, rows_per_strip), (279, 16, len(strips), tab + 8 * len(strips))]
+        with open(path, "wb") as fh:
+            fh.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, ifd))
+            for t in strips:
+                fh.write(t + b"\0" * (-len(t) % 8))
+            fh.write(struct.pack("<%dQ" % len(strips), *offs))
+            fh.write(struct.pack("<%dQ" % len(strips), *[len(t) for t in strips]))
+            fh.write(struct.pack("<Q", len(tags)))
+            for tag, typ, cnt, val in tags:
+                fh.write(struct.pack("<HHQQ", tag, typ, cnt, val))
+            fh.write(struct.pack("<Q", 0))
+
+    write_bigtiff_deflate(os.path.join(GOLD, "tiff_big16_deflate.tif"), a, 24)
+
+    def write_tiled(path, img, tw, th, compression, predictor):
+        bps = img.dtype.itemsize
+        H, W = img.shape
+        nx, ny = (W + tw - 1) // tw, (H + th - 1) // th
+        tiles = []
+        for ty in range(ny):
+            for tx in range(nx):
+                t = np.zeros((th, tw), dtype=img.dtype)
+                part = img[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+                t[:part.shape[0], :part.shape[1]] = part
+                if predictor == 2:
+                    t = np.concatenate([t[:, :1], np.diff(t.astype(np.int64), axis=1).astype(img.dtype)], axis=1)
+                raw = t.astype("<u%d" % bps).tobytes()
+                tiles.append(zlib.compress(raw, 6) if compression == 8 else raw)
+        off = 8
+        offs = []
+        for t in tiles:
+            offs.append(off)
+            off += len(t) + (len(t) & 1)
+        tab_off = off                      # TileOffsets, then TileByteCounts (LONG arrays)
+        ifd = tab_off + 8 * len(tiles)
+        tags = [(256, 3, 1, W), (257, 3, 1, H), (258, 3, 1, 8 * bps), (259, 3, 1, compression), (262, 3, 1, 1), (277, 3, 1, 1),
+                (317, 3, 1, predictor), (322, 3, 1, tw), (323, 3, 1, th), (324, 4, len(tiles), tab_off),
+                (325, 4, len(tiles), tab_off + 4 * len(tiles))]
+        with open(path, "wb") as fh:
+            fh.write(b"II" + struct.pack("<HI", 42, ifd))
+            for t in tiles:
+                fh.write(t + (b"\0" if len(t) & 1 else b""))
+            fh.write(struct.pack("<%dI" % len(tiles), *offs))
+            fh.write(struct.pack("<%dI" % len(tiles), *[len(t) for t in tiles]))
+            fh.write(struct.pack("<H", len(tags)))
+            for tag, typ, cnt, val in tags:
+                if cnt == 1 and typ == 3:
+                    fh.write(struct.pack("<HHIHH", tag, typ, cnt, val, 0))
+                elif cnt == 1:
+                    fh.write(struct.pack("<HHII", tag, typ, cnt, offs[0] if tag == 324 else (len(tiles[0]) if tag == 325 else val)))
+                else:
+                    fh.write(struct.pack("<HHII", tag, typ, cnt, val))
+            fh.write(struct.pack("<I", 0))
+
+    write_tiled(os.path.join(GOLD, "tiff_tiled16.tif"), a, 32, 32, 1, 1)
+    write_tiled(os.path.join(GOLD, "tiff_tiled16_deflate_pred.tif"), a, 16, 48, 8, 2)
+    write_tiled(os.path.join(GOLD, "tiff_tiled8.tif"), b, 64, 16, 8, 1)
+    np.savez_compressed(os.path.join(GOLD, "tiff_expected_variants.npz"), a16=a, b8=b)
+    for f, want in (("tiff_deflate16.tif", a), ("tiff_deflate16_pred.tif", a), ("tiff_big16_deflate.tif", a), ("tiff_big8.tif", b),
+                    ("tiff_tiled16.tif", a), ("tiff_tiled16_deflate_pred.tif", a), ("tiff_tiled8.tif", b)):
+        im = Image.open(os.path.join(GOLD, f))
+        t = dict(im.tag_v2)
+        print(f, os.path.getsize(os.path.join(GOLD, f)), "bytes", im.size, "compression", t.get(259), "predictor", t.get(317),
+              "tile", t.get(322), t.get(323), "magic", open(os.path.join(GOLD, f), "rb").read(4))
+        assert (np.array(im) == want).all(), f   # libtiff decodes the fixture to the expected pixels
+
+
+if __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "tiff_variants":
+    golden_tiff_variants()
+elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "unet_c1":
     golden_unet_c1()
 elif __name__ == "__main__" and os.environ.get("DELIVR_GOLDEN_ONLY") == "tiff":
     golden_tiff()

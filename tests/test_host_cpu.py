@@ -465,6 +465,21 @@ def test_native_tiff_writer_roundtrip_and_libtiff_readback(tmp_path, golden_dir)
     assert os.path.getsize(big) < planes["runs8"].nbytes // 4     # it does compress
 
 
+def test_native_tiff_reader_variants_libtiff_accepts(golden_dir):
+    """Deflate (+ predictor), BigTIFF (uncompressed by libtiff, deflate with LONG8 strip tables), tiles (uncompressed,
+    deflate + predictor, 8 bit; edge tiles padded): fixtures of oracle/make_goldens.py golden_tiff_variants, each
+    decoded by libtiff to the expected pixels when it was written."""
+    from delivr_cfos_amd.downsample.downsample_and_mask import read_tiff_plane
+
+    want = np.load(os.path.join(golden_dir, "tiff_expected_variants.npz"))
+    for name, key in (("tiff_deflate16.tif", "a16"), ("tiff_deflate16_pred.tif", "a16"), ("tiff_big16_deflate.tif", "a16"),
+                      ("tiff_big8.tif", "b8"), ("tiff_tiled16.tif", "a16"), ("tiff_tiled16_deflate_pred.tif", "a16"),
+                      ("tiff_tiled8.tif", "b8")):
+        got = read_tiff_plane(os.path.join(golden_dir, name))
+        assert got.dtype == np.uint16
+        np.testing.assert_array_equal(got, want[key], err_msg=name)
+
+
 def test_native_tiff_reader_survives_corrupt_files(tmp_path, golden_dir):
     """Random byte corruption and truncation of the fixtures: the reader either decodes or refuses with an exception -
     no crash, no exception across the C ABI; a header that claims a 900000 x 900000 plane is refused."""
@@ -473,7 +488,9 @@ def test_native_tiff_reader_survives_corrupt_files(tmp_path, golden_dir):
 
     rng = np.random.default_rng(0)
     p = str(tmp_path / "f.tif")
-    for name in ("tiff_lzw16.tif", "tiff_lzw16_strips.tif", "tiff_lzw8.tif", "tiff_be16.tif", "tiff_lzw16_pred.tif"):
+    for name in ("tiff_lzw16.tif", "tiff_lzw16_strips.tif", "tiff_lzw8.tif", "tiff_be16.tif", "tiff_lzw16_pred.tif",
+                 "tiff_deflate16_pred.tif", "tiff_big16_deflate.tif", "tiff_big8.tif", "tiff_tiled16.tif",
+                 "tiff_tiled16_deflate_pred.tif"):
         data = bytearray(open(os.path.join(golden_dir, name), "rb").read())
         for it in range(60):
             d = bytearray(data)
