@@ -358,6 +358,12 @@ def test_tiff_stack_ingest_to_device(golden_dir):
         assert view.data_ptr() == padded.data_ptr()
         with pytest.raises(RuntimeError):
             load_stack_to_device(eng, planes[:2] + [os.path.join(golden_dir, "tiff_be16.tif")])   # size mismatch
+        # a stack that mixes the other encodings of one image: deflate (+ predictor), BigTIFF, tiles
+        want2 = np.load(os.path.join(golden_dir, "tiff_expected_variants.npz"))["a16"]
+        names2 = ["tiff_deflate16.tif", "tiff_deflate16_pred.tif", "tiff_big16_deflate.tif", "tiff_tiled16.tif",
+                  "tiff_tiled16_deflate_pred.tif"]
+        vol2 = load_stack_to_device(eng, [os.path.join(golden_dir, names2[(3 * i) % 5]) for i in range(11)], n_threads=3)
+        np.testing.assert_array_equal(vol2.cpu().numpy(), np.broadcast_to(want2, (11,) + want2.shape))
     finally:
         eng.close()
 
