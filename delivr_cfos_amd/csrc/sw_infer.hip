@@ -103,6 +103,51 @@ __global__ void __launch_bounds__(256) window_max_kernel(const uint16_t* __restr
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(wmax + win, (int)m);
 }
 
+// The same maxima with ONE pass over the volume (overlapping windows read every voxel up to 8 times above): the window
+// starts and ends cut every axis into cells; cell maxima first (a workgroup owns one (plane, y-cell) strip: 16-byte loads
+// along x, per-thread maxima over the strip's rows, LDS atomics per x-cell, then one global atomicMax per x-cell), then
+// every window takes the maximum over the cells it covers.  xcell[x / 8] is the x-cell of the 8-voxel chunk at x (all
+// x-boundaries are multiples of 8 on this path), zcell[z] the z-cell of plane z or -1 outside every window.
+__global__ void __launch_bounds__(256) cell_max_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp, int z_lo,
+                                                       const int* __restrict__ zcell, const int* __restrict__ ybound, int ncy,
+                                                       const int* __restrict__ xcell, int x_lo8, int x_hi8, int ncx,
+                                                       int* __restrict__ cellmax) {
+    extern __shared__ int lmax[];  // ncx
+    const int cy = blockIdx.x % ncy, z = z_lo + blockIdx.x / ncy;
+    const int cz = zcell[z];
+    if (cz < 0) return;
+    for (int i = threadIdx.x; i < ncx; i += blockDim.x) lmax[i] = 0;
+    __syncthreads();
+    const int y0 = ybound[cy], y1 = ybound[cy + 1];
+    for (int c = x_lo8 + threadIdx.x; c < x_hi8; c += blockDim.x) {
+        unsigned m = 0;
+        const uint16_t* col = vol + ((long long)z * Yp + y0) * Xp + 8 * c;
+        for (int y = y0; y < y1; ++y, col += Xp) {
+            const uint4 v = *reinterpret_cast<const uint4*>(col);
+            const unsigned a = max(max(v.x & 0xffffu, v.x >> 16), max(v.y & 0xffffu, v.y >> 16));
+            const unsigned b = max(max(v.z & 0xffffu, v.z >> 16), max(v.w & 0xffffu, v.w >> 16));
+            m = max(m, max(a, b));
+        }
+        if (m) atomicMax(&lmax[xcell[c]], (int)m);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncx; i += blockDim.x)
+        if (lmax[i]) atomicMax(&cellmax[((long long)cz * ncy + cy) * ncx + i], lmax[i]);
+}
+
+// ranges: per window 6 ints (cell ranges [lo, hi) along z, y, x)
+__global__ void __launch_bounds__(256) window_from_cells_kernel(const int* __restrict__ ranges, long long n, int ncy, int ncx,
+                                                                const int* __restrict__ cellmax, int* __restrict__ wmax) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int* r = ranges + 6 * i;
+    int m = 0;
+    for (int a = r[0]; a < r[1]; ++a)
+        for (int b = r[2]; b < r[3]; ++b)
+            for (int c = r[4]; c < r[5]; ++c) m = max(m, cellmax[((long long)a * ncy + b) * ncx + c]);
+    wmax[i] = m;
+}
+
 // (B,1,d,h,w) fp32 <- uint16 volume windows, flipped along flip_dim (2 = Z, 3 = Y, 4 = X) if >= 0
 __global__ void __launch_bounds__(256) gather_f32_kernel(const uint16_t* __restrict__ vol, int Yp, int Xp,
                                                          const int* __restrict__ starts, int d, int h, int w,
@@ -162,6 +207,85 @@ __global__ void __launch_bounds__(256) fill_add_kernel(const int* __restrict__ s
 
 }  // namespace
 
+// maxima of n windows (starts: 3 ints per window, z relative to vol_dev's first plane) into wmax_host; synchronises
+static int window_maxima(dlv_ctx* ctx, const uint16_t* vol_dev, int Yp, int Xp, const int roi[3], const std::vector<int>& starts,
+                         int64_t n, int32_t* wmax) {
+    // ---- one pass over the volume: cell maxima, then windows from cells --------------------------------------------
+    {
+        std::vector<int> bz, by, bx;  // cell boundaries: the starts and ends of the windows of this call, per axis
+        for (int64_t i = 0; i < n; ++i) {
+            bz.push_back(starts[3 * i]);     bz.push_back(starts[3 * i] + roi[0]);
+            by.push_back(starts[3 * i + 1]); by.push_back(starts[3 * i + 1] + roi[1]);
+            bx.push_back(starts[3 * i + 2]); bx.push_back(starts[3 * i + 2] + roi[2]);
+        }
+        for (auto* b : {&bz, &by, &bx}) {
+            std::sort(b->begin(), b->end());
+            b->erase(std::unique(b->begin(), b->end()), b->end());
+        }
+        bool fast = (Xp % 8 == 0) && ((reinterpret_cast<uintptr_t>(vol_dev) & 15) == 0);
+        for (int v : bx) fast = fast && (v % 8 == 0);
+        const long long ncz = (long long)bz.size() - 1, ncy = (long long)by.size() - 1, ncx = (long long)bx.size() - 1;
+        fast = fast && ncz * ncy * ncx < (1ll << 24) && ncx <= 8192;
+        if (fast) {
+            const int z_lo = bz.front(), z_hi = bz.back();
+            std::vector<int> zcell((size_t)z_hi, -1), xcell((size_t)(bx.back() / 8), 0), ranges((size_t)n * 6);
+            for (size_t c = 0; c + 1 < bz.size(); ++c)
+                for (int z = bz[c]; z < bz[c + 1]; ++z) zcell[z] = (int)c;
+            for (size_t c = 0; c + 1 < bx.size(); ++c)
+                for (int x8 = bx[c] / 8; x8 < bx[c + 1] / 8; ++x8) xcell[x8] = (int)c;
+            auto cell_of = [](const std::vector<int>& b, int v) { return (int)(std::lower_bound(b.begin(), b.end(), v) - b.begin()); };
+            for (int64_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const std::vector<int>& b = k == 0 ? bz : (k == 1 ? by : bx);
+                    ranges[6 * i + 2 * k] = cell_of(b, starts[3 * i + k]);
+                    ranges[6 * i + 2 * k + 1] = cell_of(b, starts[3 * i + k] + roi[k]);
+                }
+            // [zcell | ybound | xcell | ranges | cellmax | wmax]
+            const size_t o_y = zcell.size(), o_x = o_y + by.size(), o_r = o_x + xcell.size(), o_c = o_r + ranges.size(),
+                         o_w = o_c + (size_t)(ncz * ncy * ncx), total_ints = o_w + (size_t)n;
+            int* ws;
+            DLV_TRY(dlv_ws_get(ctx, WS_MISC, total_ints * sizeof(int), (void**)&ws));
+            std::vector<int> host(o_c);
+            std::copy(zcell.begin(), zcell.end(), host.begin());
+            std::copy(by.begin(), by.end(), host.begin() + o_y);
+            std::copy(xcell.begin(), xcell.end(), host.begin() + o_x);
+            std::copy(ranges.begin(), ranges.end(), host.begin() + o_r);
+            DLV_HIP(ctx, hipMemcpyAsync(ws, host.data(), o_c * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            DLV_HIP(ctx, hipMemsetAsync(ws + o_c, 0, (size_t)(ncz * ncy * ncx) * sizeof(int), ctx->stream));
+            {
+                DlvProf pr(ctx, "window_max_u16", 0.0, 2.0 * (double)(z_hi - z_lo) * (by.back() - by.front()) * (bx.back() - bx.front()));
+                hipLaunchKernelGGL(cell_max_kernel, dim3((unsigned)((long long)(z_hi - z_lo) * ncy)), dim3(256), (size_t)ncx * sizeof(int),
+                                   ctx->stream, vol_dev, Yp, Xp, z_lo, ws, ws + o_y, (int)ncy, ws + o_x, bx.front() / 8,
+                                   bx.back() / 8, (int)ncx, ws + o_c);
+                hipLaunchKernelGGL(window_from_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ws + o_r,
+                                   (long long)n, (int)ncy, (int)ncx, ws + o_c, ws + o_w);
+                pr.end();
+            }
+            DLV_LAUNCH_CHECK(ctx, "cell_max_kernel / window_from_cells_kernel");
+            DLV_HIP(ctx, hipMemcpyAsync(wmax, ws + o_w, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also: the host tables above are consumed)
+            return DLV_OK;
+        }
+    }
+    // general case (x boundaries off the 8-voxel grid, unaligned volume): every window reads its own voxels
+    int* meta;
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, (size_t)n * 4 * sizeof(int), (void**)&meta));
+    DLV_HIP(ctx, hipMemcpyAsync(meta, starts.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    DLV_HIP(ctx, hipMemsetAsync(meta + n * 3, 0, (size_t)n * sizeof(int), ctx->stream));
+    const long long tile_vox = (long long)roi[0] * roi[1] * roi[2];
+    const int chunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 8 * 4), 1), 64);
+    {
+        DlvProf pr(ctx, "window_max_u16", 0.0, 2.0 * tile_vox * n);
+        hipLaunchKernelGGL(window_max_kernel, dim3(chunks, (unsigned)n), dim3(256), 0, ctx->stream, vol_dev, Yp, Xp, meta,
+                           roi[0], roi[1], roi[2], meta + n * 3);
+        pr.end();
+    }
+    DLV_LAUNCH_CHECK(ctx, "window_max_kernel");
+    DLV_HIP(ctx, hipMemcpyAsync(wmax, meta + n * 3, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+
 extern "C" {
 
 int dlv_sw_num_windows(const dlv_sw_params* p, int64_t* n_windows) {
@@ -215,18 +339,7 @@ int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* 
         starts[3 * i + 1] = t.st[1][iy];
         starts[3 * i + 2] = t.st[2][ix];
     }
-    int* meta;
-    DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, (size_t)n * 4 * sizeof(int), (void**)&meta));
-    DLV_HIP(ctx, hipMemcpyAsync(meta, starts.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    DLV_HIP(ctx, hipMemsetAsync(meta + n * 3, 0, (size_t)n * sizeof(int), ctx->stream));
-    const long long tile_vox = (long long)t.roi[0] * t.roi[1] * t.roi[2];
-    const int chunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 8 * 4), 1), 64);
-    hipLaunchKernelGGL(window_max_kernel, dim3(chunks, (unsigned)n), dim3(256), 0, ctx->stream, vol_dev, p->Yp, p->Xp, meta,
-                       t.roi[0], t.roi[1], t.roi[2], meta + n * 3);
-    DLV_LAUNCH_CHECK(ctx, "window_max_kernel");
-    DLV_HIP(ctx, hipMemcpyAsync(wmax, meta + n * 3, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return DLV_OK;
+    return window_maxima(ctx, vol_dev, p->Yp, p->Xp, t.roi, starts, n, wmax);
 }
 
 int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev, uint8_t* cnt_dev,
@@ -340,28 +453,13 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
         by_color[c].push_back(i);
     }
 
-    // device metadata: [starts of all windows | window maxima | per-launch start lists]
+    // device metadata: the per-launch start lists (the window maxima use their own scratch: window_maxima)
     int* meta;
-    const size_t meta_ints = (size_t)nwin * 3 + (size_t)nwin + (size_t)nwin * 3;
-    DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, meta_ints * sizeof(int), (void**)&meta));
-    int* starts_dev = meta;
-    int* wmax_dev = meta + nwin * 3;
-    int* list_dev = wmax_dev + nwin;
-    DLV_HIP(ctx, hipMemcpyAsync(starts_dev, starts.data(), (size_t)nwin * 3 * sizeof(int), hipMemcpyHostToDevice,
-                                ctx->stream));
-    DLV_HIP(ctx, hipMemsetAsync(wmax_dev, 0, (size_t)nwin * sizeof(int), ctx->stream));
+    DLV_TRY(dlv_ws_get(ctx, WS_TILE_META, (size_t)nwin * 3 * sizeof(int), (void**)&meta));
+    int* list_dev = meta;
     const long long tile_vox = (long long)d * h * w;
-    {
-        const int chunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 8 * 4), 1), 64);
-        DlvProf pr(ctx, "window_max_u16", 0.0, 2.0 * tile_vox * nwin);
-        hipLaunchKernelGGL(window_max_kernel, dim3(chunks, (unsigned)nwin), dim3(256), 0, ctx->stream, vol_dev, Yp, Xp,
-                           starts_dev, d, h, w, wmax_dev);
-        pr.end();
-        DLV_LAUNCH_CHECK(ctx, "window_max_kernel");
-    }
     std::vector<int> wmax((size_t)nwin);
-    DLV_HIP(ctx, hipMemcpyAsync(wmax.data(), wmax_dev, (size_t)nwin * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DLV_TRY(window_maxima(ctx, vol_dev, Yp, Xp, t.roi, starts, nwin, wmax.data()));
 
     // ordered launch lists: per colour [active..., skipped...]
     std::vector<int> list;

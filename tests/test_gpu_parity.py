@@ -363,3 +363,31 @@ def test_sw_pass_gaussian_blend_vs_oracle(eng_w, net, golden_dir, precision, fli
     # ... and the uint8 count map cannot hold fractional weights
     with pytest.raises(RuntimeError):
         eng_w.sw_infer(p, v, acc, cnt_c)
+
+
+def test_window_maxima_one_pass_and_general_path_vs_numpy(eng):
+    """dlv_sw_window_max_dev against numpy maxima of the reference's window list: cell-maxima path (window starts and
+    ends on the 8-voxel grid along x), general path (interval 18: x boundaries off that grid), a clamped last window,
+    a shard of the window list on a Z-slab."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(21)
+    for shape, roi, ov in (((96, 80, 128), (32, 32, 64), 0.5), ((70, 72, 108), (36, 36, 36), 0.5), ((64, 64, 72), (32, 32, 32), 0.25),
+                           ((40, 48, 64), (40, 48, 64), 0.5)):
+        vol = np.zeros(shape, dtype=np.uint16)
+        idx = tuple(rng.integers(0, n, 40) for n in shape)
+        vol[idx] = rng.integers(1, 65535, 40)
+        vol[: shape[0] // 3] = 0  # some windows stay empty
+        v = eng.to_device(vol)
+        p = eng.make_sw_params(shape, roi, ov, None, 0, "fp16")
+        wins = orc.window_list(shape, roi, ov)
+        d, h, w = (min(r, n) for r, n in zip(roi, shape))
+        want = np.array([vol[z:z + d, y:y + h, x:x + w].max() for z, y, x in wins], dtype=np.int32)
+        np.testing.assert_array_equal(eng.window_max(p, v), want)
+        if len(wins) >= 8:  # a shard: windows [3, n-2) on the planes they touch
+            lo, hi = 3, len(wins) - 2
+            z0 = int(wins[lo:hi, 0].min())
+            z1 = int(wins[lo:hi, 0].max()) + d
+            q = eng.make_sw_params(shape, roi, ov, None, 0, "fp16", win_range=(lo, hi), slab=(z0, z1 - z0))
+            np.testing.assert_array_equal(eng.window_max(q, v[z0:z1].contiguous()), want[lo:hi])
