@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_PATCH_VOXEL = 285104.0
 
 
-def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, crop_edge, precision):
+def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, crop_edge, precision, weights_name):
     """BASELINE.md section 3's CPU legs on the host cores of this box, with the oracle (the CPU port of the reference's
     algorithm; tests and this leg are its only callers):
       (i)  one 64^3 patch forward, fp32 (BASELINE config 1): 1 warm-up, median of 3;
@@ -87,31 +87,42 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
     crop = crop_dev.cpu().numpy()
     if crop.dtype != np.uint16:
         crop = crop.view(np.uint16)
+    from oracle.parity import LogitCache, flip_report, match_cells, reference_arithmetic
+
+    cache = LogitCache(lambda x: orc.unet_forward(net, x))
     acc = np.zeros(crop.shape, dtype=np.float32)
     t0 = time.perf_counter()
-    info = orc.sliding_window_pass(crop, roi, lambda x: orc.unet_forward(net, x), acc, None, 0.5, None, 1, fp16=False)
+    info = orc.sliding_window_pass(crop, roi, cache.predictor(None), acc, None, 0.5, None, 1, fp16=False)
     t1 = time.perf_counter()
     mask = orc.finalize(acc, None, crop, crop.shape, 0.5, 30)
     t2 = time.perf_counter()
-    _, ncomp = orc.ccl26(mask)
+    lab_cpu, ncomp = orc.ccl26(mask)
     t3 = time.perf_counter()
     n_done = info["n_windows"] - info["n_skipped"]
     per_window = (t1 - t0) / max(n_done, 1)
     fin_per_voxel = (t2 - t1) / crop.size
     projected = per_window * n_active_full + fin_per_voxel * vox_full  # the timed region of `value`: volume -> eroded mask
+    # the same windows in the REFERENCE's arithmetic (fp16 logits summed in fp16, uint8 count, fp16 divide): replayed from
+    # the cached logits, untimed
+    ref = reference_arithmetic(orc, crop, roi, cache, tta=False)
+    lab_ref, ncomp_ref = orc.ccl26(ref["mask"])
     # the HIP path on the same crop
     g_acc = torch.zeros(crop.shape, dtype=torch.float32, device=eng.device)
-    eng.sw_infer(eng.make_sw_params(crop.shape, roi, 0.5, None, 0, precision), crop_dev, g_acc)
-    g_mask = eng.finalize(g_acc, None, crop_dev, crop.shape, 0.5, 30, 0)
-    _, g_ncomp = eng.ccl26(g_mask.contiguous())
+    g_cnt = torch.zeros(crop.shape, dtype=torch.uint8, device=eng.device)
+    eng.sw_infer(eng.make_sw_params(crop.shape, roi, 0.5, None, 0, precision), crop_dev, g_acc, g_cnt)
+    g_mask = eng.finalize(g_acc, g_cnt, crop_dev, crop.shape, 0.5, 30, 0)
+    g_lab, g_ncomp = eng.ccl26(g_mask.contiguous())
+    g_stats = eng.cc_stats(g_lab, g_ncomp)
     ga, gm = g_acc.cpu().numpy(), g_mask.cpu().numpy()
     rel = float(np.linalg.norm(ga - acc) / max(np.linalg.norm(acc), 1e-30))
     inter, union = int(np.logical_and(gm, mask).sum()), int(np.logical_or(gm, mask).sum())
     iou = inter / union if union else 1.0
     sign = float(((ga > 0) == (acc > 0)).mean())
-    # tolerances of tests/test_gpu_production_shapes.py for the format measured
-    tol_rel, tol_iou = {"fp32": (1e-3, 0.9999), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.995)}[precision]
-    ok = bool(rel <= tol_rel and iou >= tol_iou)
+    vs_ref = flip_report(gm, ref["mask"], ref["mean"])
+    cells = match_cells(g_lab.cpu().numpy().view(np.uint32), g_ncomp, g_stats, lab_ref, ncomp_ref, orc.cc_stats(lab_ref, ncomp_ref))
+    # tolerances of tests/test_gpu_production_shapes.py / tests/test_gpu_trained_like.py for the format measured
+    tol_rel, tol_iou = {"fp32": (1e-3, 0.9995), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.99)}[precision]
+    ok = bool(rel <= tol_rel and iou >= tol_iou and vs_ref["iou"] >= tol_iou)
     return {
         "value": vox_full / projected if projected > 0 else None,
         "unit": "voxels/s",
@@ -126,8 +137,13 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
         "forward_64cube_voxels_per_s": 64.0**3 / fwd64,
         "crop": {"shape": list(crop.shape), "windows": info["n_windows"], "pass_s": t1 - t0, "finalize_erosion_s": t2 - t1,
                  "labels_s": t3 - t2, "voxels_per_s_end_to_end": crop.size / (t3 - t0), "components": int(ncomp)},
-        "agreement": {"ok": ok, "precision": precision, "logit_sum_rel_l2": rel, "sign_agreement": sign, "mask_iou": iou,
-                      "components_hip": int(g_ncomp), "components_cpu": int(ncomp), "tol_rel_l2": tol_rel, "tol_iou": tol_iou},
+        "agreement": {"ok": ok, "precision": precision, "weights": weights_name, "logit_sum_rel_l2": rel, "sign_agreement": sign,
+                      "mask_iou": iou, "components_hip": int(g_ncomp), "components_cpu": int(ncomp),
+                      # against the oracle run in the reference's own arithmetic (fp16 accumulate, uint8 count, fp16 divide)
+                      "mask_iou_vs_reference_arithmetic": vs_ref["iou"], "flipped_vs_reference_arithmetic": vs_ref["flipped"],
+                      "flip_margin_hist": {"edges": vs_ref["hist_edges"], "counts": vs_ref["hist"]},
+                      "components_reference_arithmetic": int(ncomp_ref), "cells": cells,
+                      "tol_rel_l2": tol_rel, "tol_iou": tol_iou},
     }
 
 
@@ -141,11 +157,16 @@ def main():
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="fp16 (default): IEEE-half MFMA operands, mask IoU 0.9997 vs the fp32 path; bf16: 2.7 %% faster, IoU 0.998")
     ap.add_argument("--sw-batch", type=int, default=0)
+    ap.add_argument("--weights", default="trained", choices=["trained", "random"],
+                    help="trained (default): the trained-like checkpoint (tests/golden/trained_like_weights.npz: top levels trained on the "
+                         "reference's patches + synth volumes, deep levels seeded random; bimodal logits, a mask of small blobs); "
+                         "random: seeded random weights (margin-free logits, one giant component)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=256, help="edge of the centre crop the CPU baseline runs (256: 27 windows of 128^3)")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra pass with the background skip disabled (`value_dense`)")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time CCL-26 + statistics and the resamplers on this volume (configs 4/5)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stages either side of the pass (finalize, CCL-26 + statistics, "
+                    "resamplers, one Gaussian-blend pass: BASELINE configs 4/5), which run by default at N=1")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
     args = ap.parse_args()
 
@@ -175,14 +196,15 @@ def main():
 
     from delivr_cfos_amd.engine import HipEngine
     from delivr_cfos_amd.hostlogic import arrayterator_zblock
-    from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, gather_slabs, plan_from_params
+    from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, plan_from_params
     from delivr_cfos_amd.synth import synth_planes_torch, synth_volume_torch
-    from delivr_cfos_amd.weights import random_state_dict
+    from delivr_cfos_amd.weights import TRAINED_LIKE_FIXTURE, random_state_dict, trained_like_state_dict
 
     shape, roi, seed = WORKLOADS[args.workload]
     Z, Y, X = shape
     eng = HipEngine(local_rank)
-    sd = random_state_dict(seed=0)
+    weights_name = "trained-like" if (args.weights == "trained" and os.path.isfile(TRAINED_LIKE_FIXTURE)) else "seeded random"
+    sd = trained_like_state_dict() if weights_name == "trained-like" else random_state_dict(seed=0)
     if rank == 0:
         eng.load_state_dict({"state_dict": sd})
     if world > 1:
@@ -207,7 +229,6 @@ def main():
     if we <= wb:  # a rank without windows still takes part in the exchange
         params = None
     acc = torch.zeros((shi - slo, Y, X), dtype=torch.float32, device=eng.device)
-    mask_full = torch.empty(shape, dtype=torch.uint8, device=eng.device) if (world > 1 and rank == 0) else None
 
     stats_last = {}
     cur = {"params": params}
@@ -222,9 +243,8 @@ def main():
         slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30, z0=slo)
         if slab is None:
             slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
-        if world > 1:
-            eng.sync()
-            gather_slabs(slab, plan, rank, dist, out=mask_full)
+        # N > 1: the mask stays on the ranks as Z-slabs (the planes each rank owns) - what the sharded count_blobs /
+        # parallel.ccl_sharded consume; nothing is gathered to rank 0
         return slab
 
     def fence():
@@ -241,7 +261,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if same_device else eng.device)  # (gloo reduces host tensors)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -272,13 +292,29 @@ def main():
         fence()
     stats_last.clear()
     stats_last.update(stats_timed)
+    # the mask of the benchmark's own pass: foreground voxels and a position-weighted checksum (identical for every N up to
+    # the voxels whose mean logit is within fp32 rounding of 0: the seam sums associate differently), summed over the ranks
+    own_lo = plan.z_owned[rank][0] if world > 1 else 0
+    CK_MOD = (1 << 55) - 55  # per-rank residues of up to 16 ranks add up without leaving int64
+    n_fg, ck = 0, 0
+    for zc in range(0, int(slab.shape[0]), 32):  # plane blocks: torch's arange / int64 temporaries stay small
+        m64 = slab[zc:zc + 32].reshape(-1).to(torch.int64)
+        idx = torch.arange(m64.numel(), dtype=torch.int64, device=eng.device) + (int(own_lo) + zc) * Y * X
+        n_fg += int(m64.sum())
+        ck = (ck + int((m64 * (((idx % 2147483629) * 48271) % 2147483629)).sum())) % CK_MOD
+        del m64, idx
+    mask_sig = torch.tensor([n_fg, ck], dtype=torch.int64, device=eng.device)
     if world > 1:
         st = torch.tensor([stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)], dtype=torch.int64,
                           device=eng.device)
+        if dist.get_backend() == "gloo":
+            st, mask_sig = st.cpu(), mask_sig.cpu()
         dist.all_reduce(st)
+        dist.all_reduce(mask_sig)
         n_windows, n_skipped = int(st[0]), int(st[1])
     else:
         n_windows, n_skipped = stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)
+    mask_voxels, mask_checksum = int(mask_sig[0]), int(mask_sig[1]) % CK_MOD
 
     if rank != 0:
         if world > 1:
@@ -356,9 +392,11 @@ def main():
         eng.set_lanes(lanes_used)
         roofline_isolated, _ = roofline_of(prof1, 1, 1)
 
-    # ---- optional: the stages either side of the pass (BASELINE configs 4 and 5), timed separately ----------
+    # ---- the stages either side of the pass (BASELINE configs 4 and 5), timed separately, N=1 ----------------------
+    # every entry: ms per call on this volume, the ALGORITHMIC HBM bytes of the stage (inputs read once + outputs written
+    # once, stated per voxel), and hbm_frac = bytes / time / 8 TB/s
     extras = None
-    if args.extras and world == 1:
+    if not args.no_extras and world == 1:
         def timed(fn, reps=2):
             fn()
             eng.sync()
@@ -372,39 +410,53 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t0) / reps, out
 
-        extras = {}
-        mask = slab.contiguous()
+        def entry(ms, nbytes, what):
+            return {"ms": ms, "algorithmic_bytes": nbytes, "bytes_per_voxel": what, "GBps": nbytes / (ms * 1e6),
+                    "hbm_frac": nbytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9)}
+
+        extras = {"voxels": vox}
+        zb = arrayterator_zblock(shape)
+        ms, mask = timed(lambda: eng.finalize(acc, None, vol, shape, 0.5, 30, zb), reps=2)
+        extras["finalize"] = entry(ms, vox * 7, "4 (fp32 sums) + 2 (uint16 raw) read, 1 (mask) written")
+        mask = mask.contiguous()
         ms, (labels, ncomp) = timed(lambda: eng.ccl26(mask))
-        extras["ccl26_ms"] = ms
-        extras["components"] = ncomp
+        extras["ccl26"] = entry(ms, vox * 5, "1 (mask) read, 4 (uint32 labels) written")
+        extras["ccl26"]["components"] = ncomp
+        extras["ccl26"]["mask"] = f"the pass's own mask ({weights_name} weights)"
         ms, _ = timed(lambda: eng.cc_stats(labels, ncomp), reps=1)
-        extras["cc_stats_ms"] = ms
+        extras["cc_stats"] = entry(ms, vox * 4, "4 (labels) read")
         del labels
-        # the mask a trained network would give: the synthetic cells only (blobs of 10-40 voxels, ~4e-4 per tissue
-        # voxel); the random-weight mask above is one giant component, the adversarial case for the statistics
+        # the synthetic cells themselves (blobs of 10-40 voxels, ~4e-4 per tissue voxel): a second, denser cell mask
         cells = (vol.view(torch.int16) > 6500).to(torch.uint8) if vol.dtype == torch.uint16 else (vol > 6500).to(torch.uint8)
         ms, (labels, ncells) = timed(lambda: eng.ccl26(cells))
-        extras["ccl26_cells_ms"] = ms
-        extras["components_cells"] = ncells
+        extras["ccl26_cells"] = entry(ms, vox * 5, "1 (mask) read, 4 (uint32 labels) written")
+        extras["ccl26_cells"]["components"] = ncells
         ms, _ = timed(lambda: eng.cc_stats(labels, ncells), reps=1)
-        extras["cc_stats_cells_ms"] = ms
-        extras["ccl26_cells_GBps"] = vox * 13 / (extras["ccl26_cells_ms"] * 1e6)      # algorithmic ~13 B/voxel
-        extras["cc_stats_cells_GBps"] = vox * 4 / (extras["cc_stats_cells_ms"] * 1e6)  # one read of the labels
+        extras["cc_stats_cells"] = entry(ms, vox * 4, "4 (labels) read")
         del labels, cells
         ms, ds = timed(lambda: eng.block_mean_u16(vol, (4, 15, 15)))
-        extras["block_mean_4x15x15_ms"] = ms
+        extras["block_mean_4x15x15"] = entry(ms, vox * 2 + ds.numel() * 2, "2 (uint16) read, 2/900 written")
         small = (ds.to(torch.int32) > 0).to(torch.uint8)
         ms, _ = timed(lambda: eng.zoom_spline2_u8(small, shape), reps=1)
-        extras["zoom_spline2_to_full_ms"] = ms
-        ms, _ = timed(lambda: eng.finalize(acc, None, vol, shape, 0.5, 30, arrayterator_zblock(shape)), reps=2)
-        extras["finalize_ms"] = ms
-        extras["voxels"] = vox
+        extras["zoom_spline2_to_full"] = entry(ms, vox * 1 + small.numel(), "1 (uint8 mask) written, 1/900 read")
+        del small, ds
+        # one pass with MONAI's Gaussian importance map instead of constant weights (option)
+        if params is not None:
+            wsum = torch.zeros_like(acc)
+            gp = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, blend="gaussian", wsum=wsum)
+            acc_g = torch.zeros_like(acc)
+            fence()
+            t0 = time.perf_counter()
+            eng.sw_infer(gp, vol, acc_g)
+            fence()
+            extras["gaussian_blend_pass_ms"] = 1e3 * (time.perf_counter() - t0)
+            del wsum, acc_g
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only (bench contract)
         try:
             threads = os.cpu_count() or 1
-            cpu = cpu_baseline(eng, sd, vol, shape, roi, n_active, vox, threads, args.cpu_crop, args.precision)
+            cpu = cpu_baseline(eng, sd, vol, shape, roi, n_active, vox, threads, args.cpu_crop, args.precision, weights_name)
         except Exception as exc:  # the baseline is reported, never fatal
             cpu = {"value": None, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc}"}
 
@@ -429,13 +481,15 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain, windows {roi[0]}^3, overlap 0.5, "
-                        f"1 pass (no TTA), seeded random BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
+                        f"1 pass (no TTA), {weights_name} BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
                         + (", dense (no background)" if args.dense else ", ellipsoid brain (background skipped)"),
             "volume_zyx": [Z, Y, X], "roi": list(roi), "overlap": 0.5,
             "windows": n_windows, "windows_skipped": n_skipped,
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
             "patch_voxels_per_s": tile_vox * n_active / (elapsed / args.steps),
-            "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" on rank 0" if world > 1 else ""),
+            "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),
+            "lanes": int(os.environ.get("DLV_LANES", "3")), "cu_split_mem_cus_per_xcd": int(os.environ.get("DLV_CU_SPLIT", "0")),
+            "mask_voxels": mask_voxels, "mask_checksum": mask_checksum,
             "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
         },
         # `roofline` describes the dominant kernel itself: measured with HIP events in one extra step on a single lane

@@ -10,9 +10,18 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdelivr_hip.so")
-# development: A/B of two builds of the library on one device (profiles/): DLV_LIB names the file under lib/
+# development: A/B of two builds of the library on one device (profiles/): DLV_LIB names a file under lib/ - a bare file
+# name of the form libdelivr_hip*.so only (no directories), and never one of the timing-only ablation builds
+# (libdelivr_hip_abl*.so compute WRONG results by construction) unless DLV_ALLOW_WRONG_RESULTS=1 says the caller knows
+# (profiles/tools/zreg_abl.sh)
 if os.environ.get("DLV_LIB"):
-    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), os.environ["DLV_LIB"])
+    _name = os.environ["DLV_LIB"]
+    if os.path.basename(_name) != _name or not (_name.startswith("libdelivr_hip") and _name.endswith(".so")):
+        raise ImportError(f"DLV_LIB={_name!r}: expected the bare name of a libdelivr_hip*.so under {os.path.dirname(LIB_PATH)}")
+    if "_abl" in _name and os.environ.get("DLV_ALLOW_WRONG_RESULTS") != "1":
+        raise ImportError(f"DLV_LIB={_name!r} is a timing-only ablation build (wrong results); set DLV_ALLOW_WRONG_RESULTS=1 "
+                          "to time it (profiles/tools/zreg_abl.sh does)")
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), _name)
 
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
@@ -142,6 +151,7 @@ SIGNATURES = {
     "dlv_debug_layer_bf16": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
+    "dlv_set_cu_split": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
     "dlv_prof_reset": (C.c_int, [_P]),
     "dlv_prof_report": (C.c_int, [_P, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),

@@ -46,11 +46,12 @@ def _even_slabs(Z: int, world: int):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def _count_blobs_sharded(eng, bin_img, dist):
-    """One process per GPU: every rank labels a Z-slab of the mask, seams are merged (parallel.ccl_sharded); rank 0
-    receives the label slabs and the merged statistics.  Returns (labels ndarray | None, N, stats | None)."""
-    import torch
-    from .parallel import ShardPlan, ccl_sharded, gather_slabs
+def _count_blobs_sharded(eng, bin_img, dist, path_out, brain):
+    """One process per GPU: every rank labels a Z-slab of the mask, seams are merged (parallel.ccl_sharded) and every
+    rank writes ITS label slab straight into the output .npy (rank 0 creates the file once N - and with it the label
+    dtype - is known); only the merged statistics travel to rank 0.  No rank ever holds the whole label volume (17 GB for
+    1024x2048x2048).  Returns (N, stats | None)."""
+    from .parallel import ccl_sharded
 
     rank, world = dist.get_rank(), dist.get_world_size()
     Z, Y, X = bin_img.shape
@@ -58,19 +59,32 @@ def _count_blobs_sharded(eng, bin_img, dist):
     lo, hi = slabs[rank]
     slab = eng.to_device(np.ascontiguousarray(bin_img[lo:hi])) if hi > lo else None
     labels, N, stats = ccl_sharded(eng, slab, slabs, rank, dist, (Z, Y, X))
-    plan = ShardPlan(world, 0, [(0, 0)] * world, slabs, slabs)
-    # label slabs travel HBM -> HBM (RCCL p2p over xGMI; 17 GB of labels for a 1024x2048x2048 volume fit rank 0's HBM)
-    full = torch.empty((Z, Y, X), dtype=torch.int32, device=eng.device) if rank == 0 else None
-    gather_slabs(labels, plan, rank, dist, out=full)
-    if rank != 0:
-        return None, N, None
-    return full.cpu().numpy().view(np.uint32), N, stats
+    out_path = os.path.join(path_out, f"{brain}-{N}-cc3d.npy")
+    err = [None]
+    if rank == 0:
+        try:
+            np.lib.format.open_memmap(out_path, mode="w+", dtype=_label_dtype(N), shape=(Z, Y, X)).flush()
+        except Exception as exc:  # every rank must learn about it: they all wait in the broadcast below
+            err[0] = repr(exc)
+    dist.broadcast_object_list(err, src=0)
+    if err[0] is not None:
+        raise RuntimeError(f"count_blobs: rank 0 could not create {out_path}: {err[0]}")
+    if hi > lo:
+        mm = np.load(out_path, mmap_mode="r+")
+        mm[lo:hi] = labels.cpu().numpy().view(np.uint32).astype(_label_dtype(N), copy=False)
+        mm.flush()
+        del mm
+    dist.barrier()
+    return N, stats
 
 
 def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max_size=-1, engine=None):
     """Same positional parameters as the reference.  ``engine``: a HipEngine to reuse (one is
     created on device 0 otherwise).  Under torch.distributed (one process per GPU) the labelling is sharded over the
-    ranks along z; rank 0 writes the files, every rank returns N."""
+    ranks along z; rank 0 writes the statistics and the CSV, every rank writes its slab of the labels and returns N.
+    Rank 0 alone looks for a cached labelling and tells the others which branch to take, so the ranks cannot disagree
+    about the collectives that follow (different cache views on a shared file system); a failure on rank 0 reaches the
+    other ranks as an error instead of a hang."""
     from .engine import HipEngine
 
     try:
@@ -90,30 +104,63 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
     bin_img = np.memmap(brain_path, dtype=np.uint8, mode="r", shape=shape, offset=128)
     own = engine is None
     eng = engine or HipEngine(int(os.environ.get("LOCAL_RANK", 0)) if sharded else 0)
-    labels_dev = None
-    if sharded and not load_cached_brain(settings, brain):
-        try:
-            labels, N, stats = _count_blobs_sharded(eng, bin_img, dist)
-        finally:
+    if sharded:
+        branch = [None]
+        if rank == 0:
+            try:
+                branch[0] = ("cached", bool(load_cached_brain(settings, brain)))
+            except Exception as exc:
+                branch[0] = ("error", repr(exc))
+        dist.broadcast_object_list(branch, src=0)
+        if branch[0][0] == "error":
             if own:
                 eng.close()
-        if rank == 0:
-            np.save(os.path.join(path_out, f"{brain}-{N}-cc3d.npy"), labels.astype(_label_dtype(N), copy=False))
-            with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
-                pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
-            with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
-                fh.write(cells_csv_text(stats, N))
-            end = datetime.datetime.now()
-            print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
-        dist.barrier()
-        return N
-    if sharded and rank != 0:
-        # a cached labelling exists: rank 0 alone re-uses it (and writes the statistics / CSV), the others wait for N
-        if own:
-            eng.close()
-        box = [None]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
+            raise RuntimeError(f"count_blobs: rank 0 failed while looking for a cached labelling: {branch[0][1]}")
+        if not branch[0][1]:
+            try:
+                N, stats = _count_blobs_sharded(eng, bin_img, dist, path_out, brain)
+            finally:
+                if own:
+                    eng.close()
+            if rank == 0:
+                with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
+                    pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
+                with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
+                    fh.write(cells_csv_text(stats, N))
+                end = datetime.datetime.now()
+                print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
+            dist.barrier()
+            return N
+        if rank != 0:
+            # a cached labelling exists: rank 0 alone re-uses it (and writes the statistics / CSV), the others wait for
+            # N - or for the error rank 0 ran into
+            if own:
+                eng.close()
+            box = [None]
+            dist.broadcast_object_list(box, src=0)
+            if isinstance(box[0], tuple):
+                raise RuntimeError(f"count_blobs: rank 0 failed on the cached labelling: {box[0][1]}")
+            return box[0]
+    result = [("error", "rank 0 did not finish")]
+    try:
+        N, stats = _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start)
+        with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
+            fh.write(cells_csv_text(stats, N))
+        result = [N]
+    except Exception as exc:
+        result = [("error", repr(exc))]
+        raise
+    finally:
+        if sharded:  # always: N, or the error the waiting ranks re-raise
+            dist.broadcast_object_list(result, src=0)
+    end = datetime.datetime.now()
+    print(f"{end} {brain} {brain_i} / {len_b} Done; Took {end - start}")
+    return N
+
+
+def _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start):
+    """The one-device path (also rank 0 of a sharded run that found a cached labelling): returns (N, stats)."""
+    labels_dev = None
     try:
         cached = load_cached_brain(settings, brain)
         if not cached:
@@ -145,10 +192,4 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
         if own:
             eng.close()
     # note: size filtering happens later in the reference too (count_blobs.py:105)
-    with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
-        fh.write(cells_csv_text(stats, N))
-    end = datetime.datetime.now()
-    print(f"{end} {brain} {brain_i} / {len_b} Done; Took {end - start}")
-    if sharded:
-        dist.broadcast_object_list([N], src=0)
-    return N
+    return N, stats

@@ -19,9 +19,7 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
     if (slot < 0 || slot >= WS_N_SLOTS) return dlv_fail(ctx, DLV_EINVAL, "bad scratch slot %d", slot);
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
-            DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
-            for (int k = 0; k < 3; ++k)
-                if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
+            DLV_TRY(dlv_sync_all(ctx));
             DLV_HIP(ctx, hipFree(ctx->ws[slot]));
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
@@ -38,6 +36,87 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
         ctx->ws_bytes[slot] = want;
     }
     *out = ctx->ws[slot];
+    return DLV_OK;
+}
+
+int dlv_sync_all(dlv_ctx* ctx) {
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    for (int k = 0; k < DLV_MAX_LANES - 1; ++k)
+        if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
+    for (int k = 0; k < DLV_MAX_LANES; ++k) {
+        if (ctx->split_mfma[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->split_mfma[k]));
+        if (ctx->split_mem[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->split_mem[k]));
+    }
+    return DLV_OK;
+}
+
+// ---- CU split ------------------------------------------------------------------------------------
+// hipExtStreamCreateWithCUMask: mask bit b stands for CU b / 8 of XCD b % 8 on this part (checked with
+// profiles/microbench/cu_partition.hip), so "CUs [lo, hi) of every XCD" are the bits 8*lo .. 8*hi-1: both partitions
+// keep all eight XCDs (L2s, fabric links) and differ only in how many CUs of each they may occupy.
+static void split_destroy(dlv_ctx* ctx) {
+    for (int l = 0; l < DLV_MAX_LANES; ++l) {
+        for (hipStream_t* s : {&ctx->split_mfma[l], &ctx->split_mem[l]})
+            if (*s) {
+                (void)hipStreamSynchronize(*s);
+                (void)hipStreamDestroy(*s);
+                *s = nullptr;
+            }
+        for (auto& e : ctx->split_ev[l])
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+    }
+    ctx->split_built = 0;
+}
+
+int dlv_split_prepare(dlv_ctx* ctx, int nlanes) {
+    const int m = ctx->split_mem_cus;
+    if (m == 0) return DLV_OK;
+    if (m >= 32) return dlv_fail(ctx, DLV_EINVAL, "CU split: %d of 32 CUs per XCD for the memory partition", m);
+    if (ctx->split_built != m) split_destroy(ctx);
+    if (m < 0) {
+        // priority mode (no CU masks): the convs of every lane on a high-priority stream, the HBM-class kernels on a
+        // low-priority one - a conv that is ready is dispatched before a pending memory-class workgroup, which then fills
+        // what the conv leaves free (a conv wave owns 440 of a SIMD's 512 registers: one 64-register wave fits beside it)
+        int lo = 0, hi = 0;
+        DLV_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest priority (numerically lower)
+        for (int l = 0; l < nlanes && l < DLV_MAX_LANES; ++l) {
+            if (!ctx->split_mfma[l]) DLV_HIP(ctx, hipStreamCreateWithPriority(&ctx->split_mfma[l], hipStreamNonBlocking, hi));
+            if (!ctx->split_mem[l]) DLV_HIP(ctx, hipStreamCreateWithPriority(&ctx->split_mem[l], hipStreamNonBlocking, lo));
+            for (auto& e : ctx->split_ev[l])
+                if (!e) DLV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        ctx->split_built = m;
+        return DLV_OK;
+    }
+    auto masked = [&](int cu_lo, int cu_hi, hipStream_t* out) -> int {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 8 * cu_lo; b < 8 * cu_hi; ++b) mask[b / 32] |= 1u << (b % 32);
+        DLV_HIP(ctx, hipExtStreamCreateWithCUMask(out, 8, mask));
+        return DLV_OK;
+    };
+    for (int l = 0; l < nlanes && l < DLV_MAX_LANES; ++l) {
+        if (!ctx->split_mfma[l]) DLV_TRY(masked(0, 32 - m, &ctx->split_mfma[l]));
+        if (!ctx->split_mem[l]) DLV_TRY(masked(32 - m, 32, &ctx->split_mem[l]));
+        for (auto& e : ctx->split_ev[l])
+            if (!e) DLV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    ctx->split_built = m;
+    return DLV_OK;
+}
+
+int dlv_use_class(dlv_ctx* ctx, int cls) {
+    if (!ctx->split_active) return DLV_OK;
+    const int l = ctx->lane;
+    hipStream_t want = cls == DLV_K_MEM ? ctx->split_mem[l] : ctx->split_mfma[l];
+    if (want == ctx->stream) return DLV_OK;
+    hipEvent_t e = ctx->split_ev[l][ctx->split_ev_next[l]];
+    ctx->split_ev_next[l] = (ctx->split_ev_next[l] + 1) % 16;
+    DLV_HIP(ctx, hipEventRecord(e, ctx->stream));
+    DLV_HIP(ctx, hipStreamWaitEvent(want, e, 0));
+    ctx->stream = want;
     return DLV_OK;
 }
 
@@ -92,9 +171,7 @@ void DlvProf::end() {
 
 static int prof_drain(dlv_ctx* ctx) {
     if (ctx->prof_pending.empty()) return DLV_OK;
-    DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
-    for (int k = 0; k < 3; ++k)
-        if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
+    DLV_TRY(dlv_sync_all(ctx));
     for (auto& p : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -250,10 +327,10 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     if (hipMalloc(&ctx->zero_page, 256) == hipSuccess) (void)hipMemset(ctx->zero_page, 0, 256);
     if (!getenv("DLV_ONE_LANE")) {
         bool ok = true;
-        for (int k = 0; k < 3 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < DLV_MAX_LANES && ok; ++k) ok = hipEventCreateWithFlags(&ctx->ev_lane[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < DLV_MAX_LANES - 1 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < DLV_MAX_LANES + 1 && ok; ++k) ok = hipEventCreateWithFlags(&ctx->ev_lane[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < DLV_MAX_LANES - 1; ++k)
                 if (ctx->aux[k]) {
                     (void)hipStreamDestroy(ctx->aux[k]);
                     ctx->aux[k] = nullptr;
@@ -262,6 +339,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         ctx->aux_stream = ctx->aux[0];
     }
     if (const char* e = getenv("DLV_LANES")) ctx->lanes_wanted = std::max(1, std::min(DLV_MAX_LANES, atoi(e)));
+    if (const char* e = getenv("DLV_CU_SPLIT")) ctx->split_mem_cus = std::max(-1, std::min(31, atoi(e)));
     *out = ctx;
     return DLV_OK;
 }
@@ -269,7 +347,8 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
 int dlv_ctx_destroy(dlv_ctx* ctx) {
     if (!ctx) return DLV_EINVAL;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->main_stream);
+    (void)dlv_sync_all(ctx);
+    split_destroy(ctx);
     for (auto& p : ctx->prof_pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -279,12 +358,12 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->blob) (void)hipFree(ctx->blob);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < DLV_MAX_LANES - 1; ++k)
         if (ctx->aux[k]) {
             (void)hipStreamSynchronize(ctx->aux[k]);
             (void)hipStreamDestroy(ctx->aux[k]);
         }
-    for (int k = 0; k < DLV_MAX_LANES; ++k)
+    for (int k = 0; k < DLV_MAX_LANES + 1; ++k)
         if (ctx->ev_lane[k]) (void)hipEventDestroy(ctx->ev_lane[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->main_stream);
     delete ctx;
@@ -427,6 +506,12 @@ int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
 int dlv_set_lanes(dlv_ctx* ctx, int lanes) {
     if (!ctx || lanes < 1 || lanes > DLV_MAX_LANES) return DLV_EINVAL;
     ctx->lanes_wanted = lanes;
+    return DLV_OK;
+}
+
+int dlv_set_cu_split(dlv_ctx* ctx, int mem_cus_per_xcd) {
+    if (!ctx || mem_cus_per_xcd < -1 || mem_cus_per_xcd > 31) return DLV_EINVAL;
+    ctx->split_mem_cus = mem_cus_per_xcd;
     return DLV_OK;
 }
 

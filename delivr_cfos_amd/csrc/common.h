@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -13,7 +14,7 @@
 #include "../../include/delivr_hip.h"
 
 #define DLV_WAVE 64
-#define DLV_MAX_LANES 4
+#define DLV_MAX_LANES 6
 
 struct DlvProfSlot {
     char name[48];
@@ -57,25 +58,35 @@ enum DlvWsSlot {
     WS_CCL,           // CCL scratch
     WS_MISC,
     WS_LANE_ACT0,     // extra pipeline lanes (aux streams): activations, then stats, DLV_MAX_LANES-1 each
-    WS_LANE_ACT1,
-    WS_LANE_ACT2,
-    WS_LANE_STATS0,
-    WS_LANE_STATS1,
-    WS_LANE_STATS2,
-    WS_N_SLOTS
+    WS_LANE_STATS0 = WS_LANE_ACT0 + DLV_MAX_LANES - 1,
+    WS_N_SLOTS = WS_LANE_STATS0 + DLV_MAX_LANES - 1
 };
+
+// Which part of the chip a kernel of the forward belongs on when the CU split is on (dlv_set_cu_split): the 3x3x3 convs
+// (MFMA-bound, one wave per SIMD, the whole register file) on the large partition, the HBM-class kernels that carry the
+// Mish (stem, InstanceNorm+Mish(+pool) passes, transposed convs, final conv + blend) on the small one.
+enum DlvKernelClass { DLV_K_MFMA = 0, DLV_K_MEM = 1 };
 
 struct dlv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream the NEXT launch goes to (main or aux lane)
     hipStream_t main_stream = nullptr;  // the ctx stream proper
     hipStream_t aux_stream = nullptr;   // lane 1 (kept as a named alias of aux[0])
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // extra lanes: batches rotate over the lanes so that the
+    hipStream_t aux[DLV_MAX_LANES - 1] = {nullptr};  // extra lanes: batches rotate over the lanes so that the
                                         // HBM-bound kernels of one batch overlap the MFMA kernels of another
-    hipEvent_t ev_lane[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_lane[DLV_MAX_LANES + 1] = {nullptr};  // one per lane + one for the main stream (split mode)
     int lane = 0;
+    // CU split (spatial partition of the chip, dlv_set_cu_split / DLV_CU_SPLIT): per lane one stream whose CU mask holds
+    // the first 32 - split_mem_cus CUs of every XCD (convs) and one with the remaining split_mem_cus (HBM-class kernels);
+    // a forward hops between its lane's two streams with an event per hop (dlv_use_class)
+    int split_mem_cus = 0;     // wanted: 0 = off
+    int split_built = 0;       // the value the masked streams were created for
+    bool split_active = false; // set by dlv_sw_infer_dev for the duration of a pass
+    hipStream_t split_mfma[DLV_MAX_LANES] = {nullptr};
+    hipStream_t split_mem[DLV_MAX_LANES] = {nullptr};
+    hipEvent_t split_ev[DLV_MAX_LANES][16] = {{nullptr}};
+    int split_ev_next[DLV_MAX_LANES] = {0};
     int lanes_wanted = 3;  // C3: 1 lane 6.86 s, 2: 6.58, 3: 6.56, 4: 6.63 per pass (profiles/lanes_sweep.sh, r02)
-    hipEvent_t ev_main = nullptr, ev_aux = nullptr;  // lane joins
     bool own_stream = false;
     std::string err;
     // weights
@@ -131,6 +142,13 @@ int dlv_fail(dlv_ctx* ctx, int code, const char* fmt, ...);
 
 // grow-only scratch slot
 int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out);
+// waits for every stream the context launches on (main, lanes, CU-split streams)
+int dlv_sync_all(dlv_ctx* ctx);
+// CU split: creates the masked streams of `nlanes` lanes for ctx->split_mem_cus (no-op when they exist)
+int dlv_split_prepare(dlv_ctx* ctx, int nlanes);
+// CU split: the next launch of the forward running on lane ctx->lane is of class `cls` (DlvKernelClass); when that means
+// another stream, the new stream waits for everything the lane queued so far.  No-op unless ctx->split_active.
+int dlv_use_class(dlv_ctx* ctx, int cls);
 
 // kernel timer: DlvProf p(ctx, "name", flops, bytes); <launch>; p.end();
 struct DlvProf {
@@ -141,6 +159,13 @@ struct DlvProf {
 };
 
 static inline int dlv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// "this kernel's dynamic-LDS attribute is set on this device": one bit per device in a function-local static.  The ranks of
+// dlv_sw_infer_sharded are host threads that go through the same launchers, so the bits are atomic (a lost race only
+// repeats hipFuncSetAttribute, which is idempotent).
+typedef std::atomic<unsigned long long> dlv_attr_bits;
+static inline bool dlv_attr_is_set(const dlv_attr_bits& bits, int device) { return (bits.load(std::memory_order_acquire) >> (device & 63)) & 1ull; }
+static inline void dlv_attr_mark(dlv_attr_bits& bits, int device) { bits.fetch_or(1ull << (device & 63), std::memory_order_release); }
 
 // XCD-aware tile order for kernels whose gridDim.x enumerates spatial tiles (row-major: x, then y, then z neighbours):
 // workgroups go round-robin to the 8 XCDs (each with its own L2), so with gridDim.x a multiple of 8 the XCD of a workgroup

@@ -930,11 +930,11 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
     // kernel variants (DLV_ZM_VARIANT selects one for A/B timing): VB rows per wave, TYT tile rows -> TYT/VB waves
 #define DLV_ZM_LAUNCH_P(P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_)                                                                                  \
     do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit per device */                                                               \
-        if (!((attr_set >> (ctx->device & 63)) & 1ull)) {                                                                                                 \
+        static dlv_attr_bits attr_set{0}; /* bit per device */                                                               \
+        if (!dlv_attr_is_set(attr_set, ctx->device)) {                                                                                                 \
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch_kernel<P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>,                         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZmCfg<CIN_, TYT_>::LDS_BYTES));  \
-            attr_set |= 1ull << (ctx->device & 63);                                                                                             \
+            dlv_attr_mark(attr_set, ctx->device);                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_zmarch_kernel<P_, CIN_, VB_, MINW_, TYT_, PIN_, DIST_, ABL_, STAG_>), grid, dim3(64 * TYT_ / VB_), (ZmCfg<CIN_, TYT_>::LDS_BYTES),       \
                            ctx->stream, (const uint4*)in1, c1 / 8, (const uint4*)in2, c2 / 8, (const uint4*)wpk, bias,   \
@@ -942,11 +942,11 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
     } while (0)
 #define DLV_ZM2_LAUNCH(P_, NSRC_, ABL_, DMA_, PIPE_)                                                                              \
     do {                                                                                                                 \
-        static unsigned long long attr_set2 = 0; /* bit per device */                                                              \
-        if (!((attr_set2 >> (ctx->device & 63)) & 1ull)) {                                                                                                \
+        static dlv_attr_bits attr_set2{0}; /* bit per device */                                                              \
+        if (!dlv_attr_is_set(attr_set2, ctx->device)) {                                                                                                \
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch2_kernel<P_, NSRC_, ABL_, DMA_, PIPE_>,                \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Zm2Cfg<NSRC_>::LDS_BYTES)); \
-            attr_set2 |= 1ull << (ctx->device & 63);                                                                                            \
+            dlv_attr_mark(attr_set2, ctx->device);                                                                                            \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_zmarch2_kernel<P_, NSRC_, ABL_, DMA_, PIPE_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES,  \
                            ctx->stream, (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, bias, (uint4*)out,      \
@@ -957,11 +957,11 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
         ((cin == 32 && c1 == 32) || (cin == 64 && c1 == 32 && c2 == 32))) {
 #define DLV_ZM4_LAUNCH(P_, NSRC_, ST_, ABL_)                                                                                       \
     do {                                                                                                                 \
-        static unsigned long long attr_set4 = 0; /* bit per device */                                                              \
-        if (!((attr_set4 >> (ctx->device & 63)) & 1ull)) {                                                                                                \
+        static dlv_attr_bits attr_set4{0}; /* bit per device */                                                              \
+        if (!dlv_attr_is_set(attr_set4, ctx->device)) {                                                                                                \
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zmarch4_kernel<P_, NSRC_, ST_, ABL_>,                               \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Zm2Cfg<NSRC_>::LDS_BYTES)); \
-            attr_set4 |= 1ull << (ctx->device & 63);                                                                                            \
+            dlv_attr_mark(attr_set4, ctx->device);                                                                                            \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_zmarch4_kernel<P_, NSRC_, ST_, ABL_>), grid, dim3(512), Zm2Cfg<NSRC_>::LDS_BYTES, ctx->stream,    \
                            (const uint4*)in1, (const uint4*)in2, (const uint4*)wpk, (uint4*)out, partials, D, H, W,      \

@@ -482,11 +482,11 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
 // host side of one instantiation: LDS attribute + launch
 template <class P, int CIN, int TYT, bool ACT>
 int zr_launch(dlv_ctx* ctx, const ZrArgs& a) {
-    static unsigned long long attr_set = 0;  // bit per device
-    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
+    static dlv_attr_bits attr_set{0};  // bit per device
+    if (!dlv_attr_is_set(attr_set, ctx->device)) {
         DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_zreg_kernel<P, CIN, TYT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)ZrCfg<CIN, TYT>::LDS_BYTES));
-        attr_set |= 1ull << (ctx->device & 63);
+        dlv_attr_mark(attr_set, ctx->device);
     }
     hipLaunchKernelGGL((conv3_zreg_kernel<P, CIN, TYT, ACT>), dim3(a.gx, a.gy, a.gz), dim3(256), (ZrCfg<CIN, TYT>::LDS_BYTES), ctx->stream,
                        (const uint4*)a.in1, a.c1_8, (const float2*)a.ss1, (const uint4*)a.in2, a.c2_8, (const float2*)a.ss2,

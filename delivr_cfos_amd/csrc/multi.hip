@@ -11,13 +11,19 @@
 // (tests on a one-GPU box) exchange with hipMemcpyAsync instead.  No all-reduce exists on this path: xGMI is
 // point-to-point, every seam crosses exactly one link.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
+#include <new>
 #include <thread>
 
 #include "common.h"
+
+// The few RCCL declarations this file needs (librccl.so is loaded with dlopen at run time, so the build does not depend on
+// the RCCL development headers); values as in rccl/rccl.h of ROCm 7.x = NCCL's public ABI.
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclFloat32 = 7 } ncclDataType_t;
 
 struct dlv_comm {
     int n = 0;
@@ -89,10 +95,19 @@ int stage_get(dlv_comm* c, int r, size_t bytes, void** out) {
 
 }  // namespace
 
+// no C++ exception crosses the C ABI (std::bad_alloc from the vectors, std::system_error from std::thread)
+#define DLV_ABI_GUARD_BEGIN try {
+#define DLV_ABI_GUARD_END(c)                                                                 \
+    }                                                                                        \
+    catch (const std::bad_alloc&) { return comm_fail((c), DLV_ENOMEM, "out of host memory"); } \
+    catch (const std::exception& e) { return comm_fail((c), DLV_EHIP, "host exception: %s", e.what()); } \
+    catch (...) { return comm_fail((c), DLV_EHIP, "unknown host exception"); }
+
 extern "C" {
 
 int dlv_shard_plan_make(const dlv_sw_params* p, int world, const float* weights, dlv_shard_plan* out) {
     if (!p || !out || world < 1 || world > DLV_MAX_RANKS) return DLV_EINVAL;
+    DLV_ABI_GUARD_BEGIN
     int64_t n = 0;
     int rc = dlv_sw_num_windows(p, &n);
     if (rc != DLV_OK) return rc;
@@ -172,6 +187,7 @@ int dlv_shard_plan_make(const dlv_sw_params* p, int world, const float* weights,
         lo = hi;
     }
     return DLV_OK;
+    DLV_ABI_GUARD_END(nullptr)
 }
 
 int dlv_shard_slab(const dlv_shard_plan* plan, int rank, int Z, int erode_iters, int zblock, int* z0, int* nz) {
@@ -201,6 +217,7 @@ int dlv_comm_init_all(int n, const int* devs, dlv_comm** out) {
     *out = nullptr;
     dlv_comm* c = new (std::nothrow) dlv_comm();
     if (!c) return DLV_ENOMEM;
+    try {
     c->n = n;
     c->devs.assign(devs, devs + n);
     c->ctx.assign(n, nullptr);
@@ -245,13 +262,17 @@ int dlv_comm_init_all(int n, const int* devs, dlv_comm** out) {
             return DLV_EHIP;
         }
     }
+    } catch (...) {
+        dlv_comm_destroy(c);
+        return DLV_ENOMEM;
+    }
     *out = c;
     return DLV_OK;
 }
 
 int dlv_comm_destroy(dlv_comm* c) {
     if (!c) return DLV_EINVAL;
-    for (int r = 0; r < c->n; ++r) {
+    for (int r = 0; r < (int)c->stage.size(); ++r) {
         if (c->stage[r]) {
             (void)hipSetDevice(c->devs[r]);
             (void)hipFree(c->stage[r]);
@@ -272,6 +293,7 @@ const char* dlv_comm_last_error(dlv_comm* c) { return c ? c->err.c_str() : "null
 
 int dlv_bcast_weights(dlv_comm* c, int root) {
     if (!c || root < 0 || root >= c->n) return DLV_EINVAL;
+    DLV_ABI_GUARD_BEGIN
     dlv_ctx* src = c->ctx[root];
     if (!src->weights_loaded || !src->blob) return comm_fail(c, DLV_ESTATE, "dlv_bcast_weights: rank %d has no weights (dlv_unet_load first)", root);
     for (int r = 0; r < c->n; ++r) {
@@ -284,11 +306,16 @@ int dlv_bcast_weights(dlv_comm* c, int root) {
     DLV_CHIP(c, hipStreamSynchronize(src->main_stream));
     if (!c->comm.empty()) {
         DLV_NCCL(c, c->GroupStart());
-        for (int r = 0; r < c->n; ++r) {
-            DLV_CHIP(c, hipSetDevice(c->devs[r]));
-            DLV_NCCL(c, c->Broadcast(src->blob, c->ctx[r]->blob, src->blob_bytes, ncclUint8, root, c->comm[r], c->ctx[r]->main_stream));
-        }
-        DLV_NCCL(c, c->GroupEnd());
+        const int rc = [&]() -> int {  // an error inside the group must not leave it open
+            for (int r = 0; r < c->n; ++r) {
+                DLV_CHIP(c, hipSetDevice(c->devs[r]));
+                DLV_NCCL(c, c->Broadcast(src->blob, c->ctx[r]->blob, src->blob_bytes, ncclUint8, root, c->comm[r], c->ctx[r]->main_stream));
+            }
+            return DLV_OK;
+        }();
+        const ncclResult_t ge = c->GroupEnd();
+        if (rc != DLV_OK) return rc;
+        DLV_NCCL(c, ge);
     } else {
         for (int r = 0; r < c->n; ++r)
             if (r != root) {
@@ -301,12 +328,14 @@ int dlv_bcast_weights(dlv_comm* c, int root) {
         DLV_CHIP(c, hipStreamSynchronize(c->ctx[r]->main_stream));
     }
     return DLV_OK;
+    DLV_ABI_GUARD_END(c)
 }
 
 int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_plan* plan, const int* slab_z0, const int* slab_nz,
                          const uint16_t* const* vol_slab_dev, float* const* acc_slab_dev, uint8_t* const* cnt_slab_dev,
                          dlv_sw_stats* stats) {
     if (!c || !p || !plan || !slab_z0 || !slab_nz || !vol_slab_dev || !acc_slab_dev) return DLV_EINVAL;
+    DLV_ABI_GUARD_BEGIN
     if (plan->world != c->n) return comm_fail(c, DLV_EINVAL, "plan for %d ranks, communicator has %d", plan->world, c->n);
     const int n = c->n;
     const size_t plane = (size_t)p->Yp * p->Xp;
@@ -322,6 +351,14 @@ int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_pl
     std::vector<int> rcs(n, DLV_OK);
     {
         std::vector<std::thread> pool;
+        pool.reserve(n);
+        struct Joiner {  // a failed thread start (std::system_error) must not destroy joinable threads: std::terminate
+            std::vector<std::thread>& p;
+            ~Joiner() {
+                for (auto& t : p)
+                    if (t.joinable()) t.join();
+            }
+        } joiner{pool};
         for (int r = 0; r < n; ++r)
             pool.emplace_back([&, r]() {
                 if (stats) memset(&stats[r], 0, sizeof(dlv_sw_stats));
@@ -334,7 +371,6 @@ int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_pl
                 rcs[r] = dlv_sw_infer_dev(c->ctx[r], &q, vol_slab_dev[r], acc_slab_dev[r], cnt_slab_dev ? cnt_slab_dev[r] : nullptr,
                                           stats ? &stats[r] : nullptr);
             });
-        for (auto& t : pool) t.join();
     }
     for (int r = 0; r < n; ++r)
         if (rcs[r] != DLV_OK) return comm_fail(c, rcs[r], "rank %d: %s", r, dlv_last_error(c->ctx[r]));
@@ -364,6 +400,7 @@ int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_pl
     }
     const bool rccl = !c->comm.empty();
     if (rccl) DLV_NCCL(c, c->GroupStart());
+    const int xrc = [&]() -> int {  // an error inside the group must not leave it open
     for (const Seam& s : seams) {
         const size_t nvox = (size_t)(s.hi - s.lo) * plane;
         const float* sa = acc_slab_dev[s.src] + (size_t)(s.lo - slab_z0[s.src]) * plane;
@@ -383,7 +420,15 @@ int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_pl
             if (sc) DLV_CHIP(c, hipMemcpyAsync(dc, sc, nvox, hipMemcpyDeviceToDevice, c->ctx[s.dst]->main_stream));
         }
     }
-    if (rccl) DLV_NCCL(c, c->GroupEnd());
+    return DLV_OK;
+    }();
+    if (rccl) {
+        const ncclResult_t ge = c->GroupEnd();
+        if (xrc != DLV_OK) return xrc;
+        DLV_NCCL(c, ge);
+    } else if (xrc != DLV_OK) {
+        return xrc;
+    }
     for (const Seam& s : seams) {  // owner adds, in increasing source-rank order per destination (the list is sorted so)
         const size_t nvox = (size_t)(s.hi - s.lo) * plane;
         DLV_CHIP(c, hipSetDevice(c->devs[s.dst]));
@@ -401,6 +446,7 @@ int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_pl
         DLV_CHIP(c, hipStreamSynchronize(c->ctx[r]->main_stream));
     }
     return DLV_OK;
+    DLV_ABI_GUARD_END(c)
 }
 
 }  // extern "C"

@@ -246,37 +246,40 @@ __global__ void __launch_bounds__(64) edt_line_kernel(double* __restrict__ f, lo
     const long long l = (long long)blockIdx.x * 64 + threadIdx.x;
     if (l >= lines) return;
     double* line = f + (l / inner) * outer_stride + (l % inner);
-    int* v = vbuf + l * (n + 2);
-    double* z = zbuf + l * (n + 3);
-    double* g = gbuf + l * (n + 2);
+    // envelope scratch interleaved by line (element i of line l at i * lines + l): the 64 lanes of a wave walk their lines in
+    // step, so every access of the wave is one contiguous run
+    auto V = [&](int i) -> int& { return vbuf[(long long)i * lines + l]; };
+    auto Zb = [&](int i) -> double& { return zbuf[(long long)i * lines + l]; };
+    auto G = [&](int i) -> double& { return gbuf[(long long)i * lines + l]; };
     const int m = n + 2;  // extended positions 0 .. n+1 <-> voxel positions -1 .. n
     auto fe = [&](int q) -> double { return (q == 0 || q == m - 1) ? 0.0 : line[(long long)(q - 1) * stride]; };
     const double w2 = w * w;
     int k = 0;
-    v[0] = 0;
-    z[0] = -INFINITY;
-    z[1] = INFINITY;
+    V(0) = 0;
+    Zb(0) = -INFINITY;
+    Zb(1) = INFINITY;
     for (int q = 1; q < m; ++q) {
         const double fq = fe(q) + w2 * ((double)q * (double)q);
         double s;
         while (true) {
-            const int vk = v[k];
+            const int vk = V(k);
             s = (fq - (fe(vk) + w2 * ((double)vk * (double)vk))) / (2.0 * w2 * (double)(q - vk));
-            if (s <= z[k] && k > 0) --k;
+            if (s <= Zb(k) && k > 0) --k;
             else break;
         }
         ++k;
-        v[k] = q;
-        z[k] = s;
-        z[k + 1] = INFINITY;
+        V(k) = q;
+        Zb(k) = s;
+        Zb(k + 1) = INFINITY;
     }
     k = 0;
     for (int p = 1; p < m - 1; ++p) {
-        while (z[k + 1] < (double)p) ++k;
-        const double dd = (double)(p - v[k]) * w;
-        g[p] = dd * dd + fe(v[k]);
+        while (Zb(k + 1) < (double)p) ++k;
+        const int vk = V(k);
+        const double dd = (double)(p - vk) * w;
+        G(p) = dd * dd + fe(vk);
     }
-    for (int p = 1; p < m - 1; ++p) line[(long long)(p - 1) * stride] = g[p];
+    for (int p = 1; p < m - 1; ++p) line[(long long)(p - 1) * stride] = G(p);
 }
 
 __global__ void __launch_bounds__(256) edt_sqrt_u16_kernel(const double* __restrict__ f, uint16_t* __restrict__ out, long long n) {
@@ -294,12 +297,13 @@ extern "C" int dlv_edt_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int 
         if (!(sampling_zyx[k] > 0.0) || sampling_zyx[k] > 1e9) return dlv_fail(ctx, DLV_EINVAL, "sampling must be positive");
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     const long long nvox = (long long)Z * Y * X;
-    const int nmax = std::max(Y, Z);
-    const long long lmax = std::max((long long)Z * X, (long long)Y * X);  // lines along y / along z
-    // [f: nvox doubles | z: lmax*(nmax+3) doubles | g: lmax*(nmax+2) doubles | v: lmax*(nmax+2) ints]
-    const size_t off_z = (size_t)nvox * 8, off_g = off_z + (size_t)lmax * (nmax + 3) * 8, off_v = off_g + (size_t)lmax * (nmax + 2) * 8;
+    // envelope scratch of one pass: lines * (n + 3) elements - Z*X lines of Y along y, Y*X lines of Z along z: ~nvox either
+    // way (not max(lines) * max(n), which asks for max(Y,Z)/min(Y,Z) times too much on an anisotropic stack)
+    const size_t elems = (size_t)std::max((long long)Z * X * (Y + 3), (long long)Y * X * (Z + 3));
+    // [f: nvox doubles | z: elems doubles | g: elems doubles | v: elems ints]
+    const size_t off_z = (size_t)nvox * 8, off_g = off_z + elems * 8, off_v = off_g + elems * 8;
     char* ws;
-    DLV_TRY(dlv_ws_get(ctx, WS_MISC, off_v + (size_t)lmax * (nmax + 2) * 4, (void**)&ws));
+    DLV_TRY(dlv_ws_get(ctx, WS_MISC, off_v + elems * 4, (void**)&ws));
     double* f = (double*)ws;
     double* zb = (double*)(ws + off_z);
     double* gb = (double*)(ws + off_g);

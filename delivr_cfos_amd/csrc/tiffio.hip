@@ -546,6 +546,18 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
         std::atomic<int> next{0};
         std::vector<std::string> errs(n_threads);
         std::vector<std::thread> pool;
+        pool.reserve(n_threads);
+        struct Joiner {  // a failed thread start (std::system_error) must find no joinable thread in the dying vector
+            std::vector<std::thread>& p;
+            std::atomic<bool>& stop;
+            ~Joiner() {
+                for (auto& th : p)
+                    if (th.joinable()) {
+                        stop = true;
+                        th.join();
+                    }
+            }
+        } joiner{pool, failed};
         for (int t = 0; t < std::min(n_threads, cn); ++t)
             pool.emplace_back([&, t]() {
                 try {  // an exception escaping a thread function would call std::terminate

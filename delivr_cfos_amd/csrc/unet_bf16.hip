@@ -1128,6 +1128,13 @@ struct Net16 {
 
     int grid1d(long long n) const { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
 
+    // CU split (dlv_set_cu_split): the next launch works on a tensor of `d` voxels per window and is of class `cls`.  Only
+    // the large levels hop to the memory partition; the kernels of the deep levels are small and stay with the convs.
+    int use(int cls, Dims d) {
+        if (!ctx->split_active) return DLV_OK;
+        return dlv_use_class(ctx, d.vox() * B >= (1ll << 22) ? cls : DLV_K_MFMA);
+    }
+
     // does the register-resident-weights conv run this layer (and with which inputs may it apply the activation itself)?
     bool zreg_runs(int li, int c1, int c2, Dims d) const {
         const DlvConvLayer& L = ctx->conv[li];
@@ -1171,6 +1178,7 @@ struct Net16 {
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
         if (a2) DLV_TRY(materialise(*a2, d));
         if (!fuses_first_input(li, c1, c2, d)) DLV_TRY(materialise(a1, d));
+        DLV_TRY(use(DLV_K_MFMA, d));
         const uint4* in1 = a1.p;
         const uint4* in2 = a2 ? a2->p : nullptr;
         if (zreg_runs(li, c1, c2, d)) {
@@ -1223,11 +1231,11 @@ struct Net16 {
         DlvProf pr(ctx, name, flops, bytes);
 #define DLV_CONV_LAUNCH(NCB_, TX_, WLDS_)                                                                                \
     do {                                                                                                                 \
-        static unsigned long long attr_done = 0; /* bit per device */                                                              \
-        if (!((attr_done >> (ctx->device & 63)) & 1ull)) {                                                                                                \
+        static dlv_attr_bits attr_done{0}; /* bit per device */                                                              \
+        if (!dlv_attr_is_set(attr_done, ctx->device)) {                                                                                                \
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)conv3_mfma_kernel<P, NCB_, TX_, WLDS_>,                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_done |= 1ull << (ctx->device & 63);                                                                                            \
+            dlv_attr_mark(attr_done, ctx->device);                                                                                            \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_mfma_kernel<P, NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
                            c2 / 8, reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, out, partials, L.cout, d.D, d.H,    \
@@ -1259,6 +1267,7 @@ struct Net16 {
     // InstanceNorm apply + Mish (+ MaxPool into `pooled`); writeback = false (pool only): x stays raw for consumers that
     // activate while loading
     int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
+        DLV_TRY(use(DLV_K_MEM, d));
         const long long work = pooled ? d.vox() / 8 : d.vox();
         dim3 grid(std::max(1, std::min(grid1d(work), 2048)), C / 8, B);
         DlvProf pr(ctx, pooled ? (writeback ? (P::IS_F16 ? "norm_mish_pool_f16" : "norm_mish_pool_bf16") : (P::IS_F16 ? "pool_act_f16" : "pool_act_bf16"))
@@ -1282,6 +1291,7 @@ struct Net16 {
         // the per-parity kernel has no activation on load; the weight-stationary kernel of the deep levels (Cin >= 128) would
         // repeat it for every (parity, output block) it enumerates: there the (small) input is activated by one norm pass
         if (!rows || L.cin >= 128) DLV_TRY(materialise(a, din));
+        DLV_TRY(use(DLV_K_MEM, Dims{2 * din.D, 2 * din.H, 2 * din.W}));
         const uint4* in = a.p;
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
@@ -1367,6 +1377,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         bool two_pass_stem = false;
         if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
         const DlvConvLayer& L = ctx->conv[0];
+        DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, (vol && !ctx->no_zmarch) ? "stem_mfma_u16" : "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
         if (vol && !ctx->no_zmarch) {
             const int tY = dlv_cdiv(h, SM_TY), tX = dlv_cdiv(w, SM_TX), tZ = dlv_cdiv(d, SM_TZ * SM_ZC);
@@ -1439,6 +1450,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     }
     {
         dim3 grid(std::min(net.grid1d(dm[0].vox()), 2048), B);
+        DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
         if (acc)

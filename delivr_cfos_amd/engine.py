@@ -625,6 +625,10 @@ class HipEngine:
     def set_lanes(self, lanes: int):
         self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))
 
+    def set_cu_split(self, mem_cus_per_xcd: int):
+        """0 = off; m = the HBM-class kernels of the 16-bit forward run on m CUs of every XCD, the convs on the other 32 - m."""
+        self._check(self.lib.dlv_set_cu_split(self.ctx, int(mem_cus_per_xcd)))
+
     def prof_enable(self, on: bool = True):
         self._check(self.lib.dlv_prof_enable(self.ctx, 1 if on else 0))
 

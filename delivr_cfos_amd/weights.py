@@ -7,7 +7,8 @@ gamma ~ 1 + 0.25 N(0,1), beta ~ 0.2 N(0,1) so that every parameter path is exerc
 """
 from __future__ import annotations
 
-from typing import Dict, Sequence
+import os
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 
@@ -50,4 +51,28 @@ def random_state_dict(seed: int = 0, features: Sequence[int] = FEATURES, module_
     b = 1.0 / np.sqrt(f[5])
     put("final_conv.weight", rng.uniform(-b, b, size=(1, f[5], 1, 1, 1)))
     put("final_conv.bias", rng.uniform(-b, b, size=(1,)))
+    return sd
+
+
+TRAINED_LIKE_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                    "trained_like_weights.npz")
+
+
+def trained_like_state_dict(fixture: Optional[str] = None, module_prefix: bool = True) -> Dict[str, "object"]:
+    """``random_state_dict(seed=0)`` with the tensors of the trained-like fixture put in place: the two top levels of the
+    network trained for a few hundred steps on the reference's training patches and on synth volumes
+    (oracle/train_weights.py made the file; it holds fp16 values), the deep levels seeded random.  The logits of this
+    network are bimodal and its mask is thousands of small blobs - the stand-in for the reference's absent checkpoint
+    (models/inference_weights.tar, inference/inference.py:199-200) wherever agreement of masks and cell tables is measured."""
+    import torch
+
+    sd = random_state_dict(seed=0, module_prefix=module_prefix)
+    z = np.load(fixture or TRAINED_LIKE_FIXTURE)
+    pre = "module." if module_prefix else ""
+    for k in z.files:
+        if k.startswith("w:"):
+            name = pre + k[2:]
+            if name not in sd or tuple(sd[name].shape) != tuple(z[k].shape):
+                raise KeyError(f"trained-like fixture: unexpected tensor {k[2:]} {z[k].shape}")
+            sd[name] = torch.from_numpy(z[k].astype(np.float32))
     return sd

@@ -252,8 +252,9 @@ int dlv_cc_stats_raw_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y,
 
 /* ---- TIFF z-plane ingest -------------------------------------------------------- */
 /* Replaces the per-plane cv2.imread / skimage.io / tifffile reads of the raw stack
- * (downsample/downsample_and_mask.py:25-30, :36-41, :396-404).  Classic TIFF, II/MM, strips, 8/16-bit unsigned single
- * channel, compression 1 (none) or 5 (LZW, predictor 1 or 2); anything else is refused with DLV_EUNSUP.
+ * (downsample/downsample_and_mask.py:25-30, :36-41, :396-404).  Classic TIFF and BigTIFF, II/MM, strips or tiles, 8/16-bit
+ * unsigned single channel, compression 1 (none), 5 (LZW) or 8 / 32946 (deflate), predictor 1 or 2; anything else (JPEG,
+ * float or multi-sample planes, ...) is refused with DLV_EUNSUP.
  *  dlv_tiff_plane_size / dlv_tiff_read_plane_u16: host-only (no context, no GPU): header fields / one decoded plane
  *    (8-bit samples widened) into a caller-owned (height,width) uint16 host array; dlv_tiff_last_error() holds the
  *    message of the calling thread's last failure.
@@ -337,9 +338,16 @@ typedef struct dlv_prof_entry {
     double flops;        /* algorithmic FLOPs summed over those launches */
     double bytes;        /* algorithmic HBM bytes summed over those launches */
 } dlv_prof_entry;
-/* 1 = run batches back to back on the ctx stream; 2 .. 4 (default 3) = rotate consecutive batches over that many HIP
+/* 1 = run batches back to back on the ctx stream; 2 .. 6 (default 3) = rotate consecutive batches over that many HIP
  * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
 int dlv_set_lanes(dlv_ctx* ctx, int lanes);
+/* CU split: spatial partition of the chip for dlv_sw_infer_dev's 16-bit path.  mem_cus_per_xcd = 0 (off): every kernel may
+ * use all 256 CUs.  1..31: the 3x3x3 convs of a forward run on the first 32 - m CUs of every XCD, its HBM-class kernels
+ * (stem, InstanceNorm+Mish passes, transposed convs, final conv + blend) on the remaining m, on CU-masked streams
+ * (hipExtStreamCreateWithCUMask) - the two kinds of work of neighbouring batches then run side by side instead of
+ * competing for the same SIMDs; lanes (dlv_set_lanes) = batches in flight, 1..6.  -1: no CU masks, but the two kinds of
+ * kernels on a high- and a low-priority stream per lane.  Results are identical to the unsplit pass in every mode.  The DLV_CU_SPLIT environment variable sets the value a new context starts with.  No reference counterpart. */
+int dlv_set_cu_split(dlv_ctx* ctx, int mem_cus_per_xcd);
 int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
@@ -349,10 +357,12 @@ int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_
  * that tests/ can compare each kernel with the oracle in isolation.  kind 0: conv block `index`
  * (1..17: Conv3d k3 + InstanceNorm + Mish) on the channel concatenation [in1 (c1), in2 (c2, may be
  * 0)] -> out (B,Cout,D,H,W); kind 1: ConvTranspose3d `index` (0..3) -> out (B,Cout,2D,2H,2W). */
-/* selects a build variant of the z-marching 3x3x3 conv (same as the DLV_ZM_VARIANT environment variable read at
- * dlv_ctx_create): 0 default; 3/4/6 tile, stagger and streaming-store variants; 20/24 double-buffered half-planes with
- * register / LDS-DMA staging; 40 software-pipelined step; 11-13, 30, 41-45 timing-only or stamped diagnostic builds
- * (profiles/README.md).  No reference counterpart. */
+/* Diagnostic library only (libdelivr_hip_diag.so, `make diag`): selects an A/B, stamped or timing-only build of the
+ * LDS-weights z-marching conv (3/4/6 tile, stagger and streaming-store variants; 20/24 double-buffered half-planes; 40
+ * software-pipelined step; 11-13, 30, 41-45 timing-only or stamped builds, profiles/README.md).  The PRODUCT library holds
+ * none of them: it accepts 0 / 50 (default: register-resident-weights conv) and 51 (the LDS-weights kernel for every
+ * z-march layer, an A/B that gives the same results), refuses every other value with DLV_EUNSUP and ignores the
+ * DLV_ZM_VARIANT environment variable.  No reference counterpart. */
 int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant);
 /* diagnostic: buffer (caller-owned, HBM, >= tiles*8*(D+4)*64 bytes, zeroed) that the stamped build of the z-march
  * conv (DLV_ZM_VARIANT=30) fills with s_memtime stamps of window 0; NULL switches it off.  No reference counterpart. */

@@ -1,15 +1,27 @@
-"""Scan the ISA of a kernel (gpurun_out/tmp/k.s, written by regions.sh) for VALU writes of a register that one of the next
-three instructions reads as an operand of an asm v_mfma WITHOUT an s_nop in between: the asm MFMAs of conv_zreg.hip are
-invisible to hipcc's hazard recognizer.  Prints every finding with the line number; exit code 1 if an unpadded one exists."""
+"""VALU-write -> asm-MFMA-read hazard scan of the register-resident-weights conv (conv_zreg_kernel.h).
+
+The MFMAs of that kernel are inline asm with AGPR operands, invisible to hipcc's hazard recogniser: a VALU write of a
+register that one of the next instructions reads as an MFMA operand needs wait states (s_nop) the compiler will not
+insert.  `scan(lines)` walks an ISA listing (hipcc -save-temps .s text, or `llvm-objdump -d` output) and returns every
+VALU write that an MFMA within the next three instructions reads with fewer than 2 wait states in between.
+
+    python profiles/tools/hazard_scan.py [file.s]        # exit code 1 if an unpadded pair exists
+    python profiles/tools/hazard_scan.py --lib [libdelivr_hip.so]   # every conv3_zreg_kernel in the built library
+
+`library_report(path)` (used by tests/test_isa_gate_cpu.py) extracts the gfx950 code objects from the shared library's
+.hip_fatbin section, disassembles the z-reg kernels and returns, per kernel, the hazard count, the MFMA count and the
+resource usage from the code-object metadata (VGPRs, AGPRs, scratch, SGPR spills).
+"""
+import os
 import re
+import subprocess
 import sys
+import tempfile
 
-path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tmp/k.s"
-raw = open(path).read().split("\n")
-lines = [(i + 1, l.strip()) for i, l in enumerate(raw) if l.strip() and not l.strip().startswith((";", "."))]
+LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def regs(tok):
+def _regs(tok):
     out = set()
     for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]", tok):
         out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
@@ -18,29 +30,120 @@ def regs(tok):
     return out
 
 
-bad = 0
-for idx, (ln, t) in enumerate(lines):
-    if not t.startswith("v_mfma"):
-        continue
-    args = t.split(None, 1)[1].split(",")
-    reads = set()
-    for x in args[1:]:
-        reads |= regs(x)
-    states = 0
-    for back in range(1, 4):
-        if idx - back < 0:
-            break
-        pl, pt = lines[idx - back]
-        op = pt.split(None, 1)[0]
-        if op == "s_nop":
-            states += int(pt.split()[1]) + 1
+def scan(raw_lines):
+    """-> (findings, n_mfma): findings = [(line_no_of_write, write_text, line_no_of_mfma, mfma_text, wait_states)]"""
+    lines = []
+    for i, l in enumerate(raw_lines):
+        t = l.split("//")[0].strip()  # llvm-objdump appends '// address: encoding'
+        if t and not t.startswith((";", ".")) and not t.endswith(":"):
+            lines.append((i + 1, t))
+    findings, n_mfma = [], 0
+    for idx, (ln, t) in enumerate(lines):
+        if not t.startswith("v_mfma"):
             continue
-        if op.startswith("v_") and not op.startswith("v_mfma") and len(pt.split(None, 1)) > 1:
-            w = regs(pt.split(None, 1)[1].split(",")[0])
-            if w & reads and states < 2:
-                bad += 1
-                if bad <= 20:
-                    print(f"line {pl}: {pt}   ->   line {ln}: {t}   (wait states between: {states})")
-        states += 1
-print("unpadded VALU-write -> MFMA-read pairs:", bad)
-sys.exit(1 if bad else 0)
+        n_mfma += 1
+        args = t.split(None, 1)[1].split(",")
+        reads = set()
+        for x in args[1:]:
+            reads |= _regs(x)
+        states = 0
+        for back in range(1, 4):
+            if idx - back < 0:
+                break
+            pl, pt = lines[idx - back]
+            op = pt.split(None, 1)[0]
+            if op == "s_nop":
+                states += int(pt.split()[1]) + 1
+                continue
+            if op.startswith("v_") and not op.startswith("v_mfma") and len(pt.split(None, 1)) > 1:
+                w = _regs(pt.split(None, 1)[1].split(",")[0])
+                if w & reads and states < 2:
+                    findings.append((pl, pt, ln, t, states))
+            states += 1
+    return findings, n_mfma
+
+
+def code_objects(lib_path, workdir):
+    """gfx950 code objects inside the library's .hip_fatbin (one clang offload bundle per translation unit) -> file paths"""
+    data = open(lib_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], 0
+    while True:
+        pos = data.find(magic, pos)
+        if pos < 0:
+            break
+        n = int.from_bytes(data[pos + 24:pos + 32], "little")
+        p = pos + 32
+        for _ in range(n):
+            off = int.from_bytes(data[p:p + 8], "little")
+            size = int.from_bytes(data[p + 8:p + 16], "little")
+            tl = int.from_bytes(data[p + 16:p + 24], "little")
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size > 0:
+                f = os.path.join(workdir, f"co_{len(out)}.elf")
+                open(f, "wb").write(data[pos + off:pos + off + size])
+                out.append(f)
+        pos += len(magic)
+    return out
+
+
+def _kernel_metadata(elf):
+    """amdhsa.kernels entries of a code object: {symbol: {vgpr_count, agpr_count, private_segment_fixed_size, sgpr_spill_count, ...}}"""
+    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", elf], capture_output=True, text=True).stdout
+    meta, cur = {}, None
+    for line in txt.split("\n"):
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip().strip("'")
+        if k == "agpr_count":  # first key of a kernel entry (the keys of an entry are sorted)
+            cur = {"agpr_count": int(v)}
+        elif cur is not None and k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count",
+                                       "group_segment_fixed_size"):
+            cur[k] = int(v)
+        elif cur is not None and k == "symbol":
+            meta[v[:-3] if v.endswith(".kd") else v] = cur  # (vgpr_count follows: same dict)
+    return meta
+
+
+def library_report(lib_path, name_filter="conv3_zreg_kernel"):
+    rep = {}
+    with tempfile.TemporaryDirectory() as wd:
+        for elf in code_objects(lib_path, wd):
+            syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "--wide", elf], capture_output=True, text=True).stdout
+            names = [l.split()[-1] for l in syms.split("\n") if name_filter in l and " FUNC " in l]
+            if not names:
+                continue
+            meta = _kernel_metadata(elf)
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf], capture_output=True, text=True).stdout
+            # split the listing per function symbol
+            cur, body = None, {}
+            for line in dis.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    cur = m.group(1)
+                    body[cur] = []
+                elif cur is not None:
+                    body[cur].append(line)
+            for nm in names:
+                findings, n_mfma = scan(body.get(nm, []))
+                rep[nm] = {"hazards": len(findings), "first": findings[:3], "mfma": n_mfma, **meta.get(nm, {})}
+    return rep
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--lib":
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "delivr_cfos_amd", "lib", "libdelivr_hip.so")
+        bad = 0
+        for k, v in sorted(library_report(lib).items()):
+            print(k, {x: y for x, y in v.items() if x != "first"})
+            bad += v["hazards"]
+        sys.exit(1 if bad else 0)
+    path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tmp/k.s"
+    found, n = scan(open(path).read().split("\n"))
+    for pl, pt, ln, t, states in found[:20]:
+        print(f"line {pl}: {pt}   ->   line {ln}: {t}   (wait states between: {states})")
+    print("MFMAs:", n, " unpadded VALU-write -> MFMA-read pairs:", len(found))
+    sys.exit(1 if found else 0)

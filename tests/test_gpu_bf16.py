@@ -266,7 +266,28 @@ def test_sw_pass_fp16_matches_fp32_engine(eng, golden_dir):
 # ---------------------------------------------------------------------------------------------------
 # opt-in builds of the z-march conv (dlv_debug_set_zm_variant): same torch reference, same tolerance
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [6, 11, 20, 24, 40, 50, 51])
+def _diag_lib():
+    import os
+
+    return "diag" in os.environ.get("DLV_LIB", "")
+
+
+def test_product_library_refuses_the_diagnostic_zmarch_builds(eng):
+    """ONE test for all of them: the experimental / stamped / timing-only builds (6, 11, 20, 24, 40, ...) live in
+    libdelivr_hip_diag.so only; the product library refuses to select them (and ignores DLV_ZM_VARIANT), so no setting can
+    reach a wrong-result kernel."""
+    from delivr_cfos_amd._lib import DelivrHipError
+
+    if _diag_lib():
+        pytest.skip("diagnostic library loaded")
+    for variant in (3, 4, 6, 11, 12, 13, 20, 24, 30, 40, 41, 45):
+        with pytest.raises(DelivrHipError):
+            eng.set_zm_variant(variant)
+    eng.set_zm_variant(0)
+
+
+# the variants a run can execute: 50 / 51 in the product library, the A/B builds too with DLV_LIB=libdelivr_hip_diag.so
+@pytest.mark.parametrize("variant", [50, 51] + ([6, 11, 20, 24, 40] if _diag_lib() else []))
 @pytest.mark.parametrize("li,c1,c2,prec", [(1, 32, 0, "fp16"), (16, 32, 32, "fp16"), (1, 32, 0, "bf16"), (16, 32, 32, "bf16")])
 def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     """Register-resident-weights conv (50 = the default) and the LDS-resident-weights kernel (51) in the product library;
@@ -287,16 +308,6 @@ def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     with torch.no_grad():
         raw = F.conv3d(xin, rnd(blk.conv.weight), blk.conv.bias, padding=1)
         ref = F.mish(F.instance_norm(raw, weight=blk.adn.N.weight, bias=blk.adn.N.bias, eps=1e-5))
-    import os
-    from delivr_cfos_amd._lib import DelivrHipError
-
-    if variant not in (50, 51) and "diag" not in os.environ.get("DLV_LIB", ""):
-        # the experimental / stamped / timing-only builds live in libdelivr_hip_diag.so only: the product library refuses
-        # them (and ignores DLV_ZM_VARIANT), so no environment variable can select a wrong-result kernel
-        with pytest.raises(DelivrHipError):
-            eng.set_zm_variant(variant)
-        eng.set_zm_variant(0)
-        return
     if variant == 11:
         return  # timing-only build (no epilogue): wrong results by construction, diagnostic library only
     try:

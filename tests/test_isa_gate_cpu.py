@@ -1,0 +1,51 @@
+"""ISA gate of the hot kernel (CPU, runs on the built library): the MFMAs of conv_zreg_kernel.h are inline asm with AGPR
+operands, which hipcc's hazard recogniser does not see - a compiler change could put a VALU write of an MFMA operand right in
+front of the MFMA that reads it.  profiles/tools/hazard_scan.py disassembles every conv3_zreg_kernel instantiation of
+libdelivr_hip.so and this test fails loudly on any unpadded VALU-write -> MFMA-read pair, on scratch use, on a register
+budget that no longer fits one wave per SIMD, or on an unexpected accumulator-register count."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "delivr_cfos_amd", "lib", "libdelivr_hip.so")
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(ROOT, "profiles", "tools", "hazard_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_scanner_finds_a_planted_hazard():
+    hs = _tool()
+    clean = ["v_mov_b32 v5, v1", "s_nop 1", "v_mfma_f32_16x16x32_f16 a[0:3], a[10:13], v[4:7], a[0:3]"]
+    planted = ["v_mov_b32 v5, v1", "v_mfma_f32_16x16x32_f16 a[0:3], a[10:13], v[4:7], a[0:3]"]
+    far = ["v_mov_b32 v5, v1", "v_add_u32 v9, v9, v9", "v_add_u32 v8, v8, v8", "v_mfma_f32_16x16x32_f16 a[0:3], a[10:13], v[4:7], a[0:3]"]
+    assert hs.scan(clean) == ([], 1)
+    found, n = hs.scan(planted)
+    assert n == 1 and len(found) == 1 and found[0][4] == 0
+    assert hs.scan(far)[0] == []
+
+
+# (Cin, tile rows, activate-on-load) -> AGPRs that hold the weight fragments + what the schedule pins
+EXPECTED_MFMA = {("Li32E", "Li16E"): 2592, ("Li32E", "Li8E"): 1296, ("Li64E", "Li8E"): 2592}
+
+
+def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd():
+    hs = _tool()
+    rep = hs.library_report(LIB)
+    assert len(rep) == 10, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0; Cin 64: t8 a0/a1)
+    for name, r in rep.items():
+        assert r["hazards"] == 0, (name, r["first"])
+        assert r.get("private_segment_fixed_size", 0) == 0, (name, "scratch")
+        assert r.get("vgpr_spill_count", 0) == 0, name
+        # unified register file: 512 per lane and SIMD; the metadata's vgpr_count is the unified total (arch VGPRs rounded up
+        # to the AGPR base + AGPRs): one wave per SIMD must fit
+        v, a = r["vgpr_count"], r["agpr_count"]
+        assert a < v <= 512, (name, v, a)
+        # the weight fragments live in AGPRs: 27 taps x Cin/32 fragments x 4 registers, + the pinned accumulators
+        cin = 64 if "Li64E" in name else 32
+        assert a >= 27 * (cin // 32) * 4, (name, a)
+        key = [k for k in EXPECTED_MFMA if k[0] in name and k[1] in name]
+        assert key and r["mfma"] == EXPECTED_MFMA[key[0]], (name, r["mfma"])
