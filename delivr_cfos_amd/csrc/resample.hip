@@ -8,6 +8,8 @@
 //   mask + pad   : img *= mask_us[i]; masked_nii[0,0,i,:Y,:X] = img  (downsample_and_mask.py:396-417)
 //   trilinear    : north-star extension (no reference counterpart)
 // All HBM-bound: one coalesced pass over z-major slabs, X contiguous.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,6 +37,52 @@ __global__ void __launch_bounds__(256) block_mean_u16_kernel(const uint16_t* __r
             }
         }
         out[i] = (uint16_t)(s / div);
+    }
+}
+
+// The same sums with coalesced reads: one workgroup per (output z, output y) strip walks the fz x fy input rows of its
+// blocks; a thread owns 8 consecutive columns (one 16-byte load per row), the 8 column sums go to LDS and one thread per
+// output voxel adds its fx columns.  x is processed in chunks whose width is a multiple of 8 and of fx, so that a chunk
+// starts on a 16-byte boundary and on a block boundary.  Requires X % 8 == 0 and fz * fy <= 65536 (uint32 column sums);
+// the kernel above serves every other shape.
+template <int CH>  // chunk capacity in columns (multiple of 8), 8 columns per thread
+__global__ void __launch_bounds__(CH / 8) block_mean_strip_kernel(const uint16_t* __restrict__ in, int Z, int Y, int X, int fz, int fy,
+                                                                int fx, uint16_t* __restrict__ out, int oy, int ox, int chunk_w) {
+    __shared__ unsigned col[CH];
+    const int z = blockIdx.y, y = blockIdx.x;
+    const unsigned long long div = (unsigned long long)fz * fy * fx;
+    const int nb = chunk_w / fx;  // output voxels per chunk
+    for (int c0 = 0; c0 < X; c0 += chunk_w) {
+        const int xc = c0 + (int)threadIdx.x * 8;
+        unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((int)threadIdx.x * 8 < chunk_w && xc < X) {
+            for (int a = 0; a < fz; ++a) {
+                const int zz = z * fz + a;
+                if (zz >= Z) break;
+                for (int b = 0; b < fy; ++b) {
+                    const int yy = y * fy + b;
+                    if (yy >= Y) break;
+                    const uint4 v = *reinterpret_cast<const uint4*>(in + ((long long)zz * Y + yy) * X + xc);
+                    acc[0] += v.x & 0xffffu; acc[1] += v.x >> 16;
+                    acc[2] += v.y & 0xffffu; acc[3] += v.y >> 16;
+                    acc[4] += v.z & 0xffffu; acc[5] += v.z >> 16;
+                    acc[6] += v.w & 0xffffu; acc[7] += v.w >> 16;
+                }
+            }
+        }
+        __syncthreads();  // the previous chunk's sums have been read
+        if ((int)threadIdx.x * 8 < chunk_w) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) col[threadIdx.x * 8 + k] = acc[k];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+            const int xo = c0 / fx + j;
+            if (xo >= ox) break;
+            unsigned long long t = 0;
+            for (int c = 0; c < fx; ++c) t += col[j * fx + c];  // columns beyond X hold 0 (the reference zero-pads)
+            out[((long long)z * oy + y) * ox + xo] = (uint16_t)(t / div);
+        }
     }
 }
 
@@ -73,6 +121,19 @@ __device__ __forceinline__ Taps spline2_taps(int i, int n_in, int n_out) {
     return t;
 }
 
+// the centre index alone (same arithmetic as spline2_taps; `scale` = (n_in-1)/(n_out-1) computed once by the caller - the
+// fp64 division is the most expensive operation of the whole kernel)
+__device__ __forceinline__ int spline2_centre(int i, double scale) {
+    return (int)floor(__dadd_rn(__dmul_rn((double)i, scale), 0.5));
+}
+// whole-sample mirror of a tap index in [-1, n_in] (the centre lies in [0, n_in-1]): equal to spline2_taps' modulo form
+__device__ __forceinline__ int mirror1(int k, int n_in) {
+    if (n_in == 1) return 0;
+    if (k < 0) k = -k;
+    if (k >= n_in) k = 2 * (n_in - 1) - k;
+    return k;
+}
+
 __global__ void __launch_bounds__(256) zoom_spline2_u8_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
                                                               uint8_t* __restrict__ out, int oz, int oy, int ox) {
     const long long n = (long long)oz * oy * ox;
@@ -95,6 +156,83 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_kernel(const uint8_t* __r
         double r = t > 0.0 ? __dadd_rn(t, 0.5) : 0.0;
         r = r > 255.0 ? 255.0 : r;
         out[i] = (uint8_t)r;
+    }
+}
+
+// The same values, 16 consecutive x outputs per thread.  Up-sampling a small mask by (4,15,15) makes almost every output
+// voxel look at 27 equal inputs: if every input the run's taps touch holds one value c, each of its outputs is
+// (uint8)(c * S + 0.5) with S = sum of the 27 weight products = 1 +- 1e-14 (the weights of an axis add up to 1 up to two
+// roundings), which is c for every uint8 c - no fp64 arithmetic needed and the result is the one the full evaluation
+// gives (tests: bit-exact vs scipy on masks with edges, and this kernel against the one above on random data).  Runs
+// whose taps see different values take the full evaluation.  One 16-byte store per run when the row layout allows it.
+__global__ void __launch_bounds__(256) zoom_spline2_u8_run16_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
+                                                                    uint8_t* __restrict__ out, int oz, int oy, int ox) {
+    const int runs = (ox + 15) / 16;
+    const long long n = (long long)oz * oy * runs;
+    const bool aligned = (ox % 16 == 0) && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i % runs), y = (int)((i / runs) % oy), z = (int)(i / ((long long)runs * oy));
+        const int x0 = r * 16, nx = min(16, ox - x0);
+        const Taps tz = spline2_taps(z, iz, oz), ty = spline2_taps(y, iy, oy);
+        // input columns the run touches
+        int kmin = ix, kmax = -1;
+        const double scale_x = ox > 1 ? (double)(ix - 1) / (double)(ox - 1) : 0.0;
+        for (int j = 0; j < nx; ++j) {
+            const int ci = spline2_centre(x0 + j, scale_x);
+#pragma unroll
+            for (int t = -1; t <= 1; ++t) {
+                const int k = mirror1(ci + t, ix);
+                kmin = min(kmin, k);
+                kmax = max(kmax, k);
+            }
+        }
+        bool uniform = kmax - kmin < 8;
+        unsigned cval = 0;
+        if (uniform) {
+            cval = in[((long long)tz.k[0] * iy + ty.k[0]) * ix + kmin];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const uint8_t* row = in + ((long long)tz.k[a] * iy + ty.k[b]) * ix;
+                    for (int k = kmin; k <= kmax; ++k) uniform = uniform && (row[k] == cval);
+                }
+        }
+        unsigned char v[16];
+        if (uniform) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (unsigned char)cval;
+        } else {
+            for (int j = 0; j < nx; ++j) {
+                const Taps tx = spline2_taps(x0 + j, ix, ox);
+                double t = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const uint8_t* row = in + ((long long)tz.k[a] * iy + ty.k[b]) * ix;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const double val = (double)row[tx.k[c]];
+                            t = __dadd_rn(t, __dmul_rn(__dmul_rn(__dmul_rn(val, tz.w[a]), ty.w[b]), tx.w[c]));
+                        }
+                    }
+                double rr = t > 0.0 ? __dadd_rn(t, 0.5) : 0.0;
+                rr = rr > 255.0 ? 255.0 : rr;
+                v[j] = (unsigned char)rr;
+            }
+        }
+        uint8_t* dst = out + ((long long)z * oy + y) * ox + x0;
+        if (aligned) {
+            uint4 u;
+            u.x = v[0] | (v[1] << 8) | (v[2] << 16) | ((unsigned)v[3] << 24);
+            u.y = v[4] | (v[5] << 8) | (v[6] << 16) | ((unsigned)v[7] << 24);
+            u.z = v[8] | (v[9] << 8) | (v[10] << 16) | ((unsigned)v[11] << 24);
+            u.w = v[12] | (v[13] << 8) | (v[14] << 16) | ((unsigned)v[15] << 24);
+            *reinterpret_cast<uint4*>(dst) = u;
+        } else {
+            for (int j = 0; j < nx; ++j) dst[j] = v[j];
+        }
     }
 }
 
@@ -192,8 +330,20 @@ int dlv_block_mean_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int Y, i
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     const int oz = (Z + fz - 1) / fz, oy = (Y + fy - 1) / fy, ox = (X + fx - 1) / fx;
     DlvProf p(ctx, "block_mean_u16", 0.0, 2.0 * Z * Y * X + 2.0 * oz * oy * ox);
-    hipLaunchKernelGGL(block_mean_u16_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev, Z,
-                       Y, X, fz, fy, fx, out_dev, oz, oy, ox);
+    // coalesced strip kernel where the layout allows it (16-byte loads need X % 8 == 0 and an aligned base; uint32 column
+    // sums need fz * fy <= 65536; a chunk of <= 2048 columns must hold whole blocks of fx columns on 8-column boundaries)
+    long long l = fx;
+    while (l % 8) l += fx;  // lcm(fx, 8)
+    const bool strip = X % 8 == 0 && (reinterpret_cast<unsigned long long>(in_dev) & 15ull) == 0 && (long long)fz * fy <= 65536 &&
+                       l <= 2048 && oz <= 65535 && !getenv("DLV_RESAMPLE_SIMPLE");
+    if (strip) {
+        const int chunk_w = (int)((2048 / l) * l);
+        hipLaunchKernelGGL((block_mean_strip_kernel<2048>), dim3(oy, oz), dim3(256), 0, ctx->stream, in_dev, Z, Y, X, fz, fy, fx,
+                           out_dev, oy, ox, chunk_w);
+    } else {
+        hipLaunchKernelGGL(block_mean_u16_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev, Z,
+                           Y, X, fz, fy, fx, out_dev, oz, oy, ox);
+    }
     p.end();
     DLV_LAUNCH_CHECK(ctx, "block_mean_u16_kernel");
     return DLV_OK;
@@ -205,8 +355,12 @@ int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy,
     if (iz <= 0 || iy <= 0 || ix <= 0 || oz <= 0 || oy <= 0 || ox <= 0) return dlv_fail(ctx, DLV_EINVAL, "bad shape");
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     DlvProf p(ctx, "zoom_spline2_u8", 0.0, 1.0 * oz * oy * ox + 1.0 * iz * iy * ix);
-    hipLaunchKernelGGL(zoom_spline2_u8_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev,
-                       iz, iy, ix, out_dev, oz, oy, ox);
+    if (getenv("DLV_RESAMPLE_SIMPLE"))  // the one-voxel-per-thread kernel (A/B and cross-check in tests)
+        hipLaunchKernelGGL(zoom_spline2_u8_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev,
+                           iz, iy, ix, out_dev, oz, oy, ox);
+    else
+        hipLaunchKernelGGL(zoom_spline2_u8_run16_kernel, dim3(grid_for((long long)oz * oy * ((ox + 15) / 16))), dim3(256), 0,
+                           ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox);
     p.end();
     DLV_LAUNCH_CHECK(ctx, "zoom_spline2_u8_kernel");
     return DLV_OK;

@@ -197,6 +197,42 @@ def test_resamplers_vs_goldens(eng, golden_dir):
     np.testing.assert_array_equal(z.cpu().numpy(), g["zoom_out"])  # bit-exact incl. ties
 
 
+@pytest.mark.parametrize("shape,factors", [((10, 47, 256), (4, 15, 15)), ((9, 31, 4104), (4, 15, 15)), ((7, 20, 64), (2, 3, 8)),
+                                           ((5, 9, 72), (1, 1, 9)), ((6, 33, 250), (4, 15, 15))])
+def test_block_mean_strip_kernel_vs_oracle(eng, shape, factors):
+    """The coalesced strip kernel (X % 8 == 0: 16-byte loads, LDS column sums; several x chunks for X > 2040) and the
+    one-voxel-per-thread kernel behind it (X % 8 != 0) against the oracle's integer restatement of
+    downscale_local_mean(...).astype(uint16) (downsample/downsample_and_mask.py:44), ragged block ends included."""
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.integers(0, 65536, size=shape).astype(np.uint16)
+    vol[:, :, : shape[2] // 5] = 65535  # full-scale blocks: the uint32 column sums must hold fz*fy rows of them
+    out = eng.block_mean_u16(eng.to_device(vol), factors).cpu().numpy()
+    np.testing.assert_array_equal(out, orc.block_mean_u16(vol, factors))
+
+
+@pytest.mark.parametrize("in_shape,out_shape", [((12, 20, 24), (48, 300, 352)), ((12, 20, 24), (45, 290, 355)), ((30, 40, 50), (13, 17, 21)),
+                                                ((6, 9, 11), (24, 135, 176))])
+def test_zoom_run_kernel_bit_exact_vs_scipy(eng, in_shape, out_shape):
+    """The 16-outputs-per-thread zoom with the uniform-neighbourhood shortcut against scipy itself
+    (scipy.ndimage.zoom(..., output=uint8, order=2, prefilter=False), downsample/downsample_and_mask.py:299): a blobby
+    mask with constant regions of several values (0, 1, 3, 200, 255 - the shortcut returns the region's value) and noisy
+    edges (full evaluation incl. 1/2 ties), rows that are / are not a multiple of 16 long, and a down-sampling zoom."""
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(in_shape[0] * 100 + out_shape[2])
+    m = np.zeros(in_shape, dtype=np.uint8)
+    m[in_shape[0] // 4:, in_shape[1] // 3:, in_shape[2] // 3:] = 1
+    m[: in_shape[0] // 3, : in_shape[1] // 2, : in_shape[2] // 4] = 255
+    m[in_shape[0] // 2:, : in_shape[1] // 4, in_shape[2] // 2:] = 200
+    m[:2, -3:, -4:] = 3
+    noise = rng.random(in_shape) < 0.03
+    m[noise] = rng.integers(0, 256, size=int(noise.sum())).astype(np.uint8)
+    out = eng.zoom_spline2_u8(eng.to_device(m), out_shape).cpu().numpy()
+    np.testing.assert_array_equal(out, orc.zoom_spline2_u8(m, out_shape))
+
+
 def test_mask_pad_writer(eng):
     rng = np.random.default_rng(2)
     raw = rng.integers(0, 65535, size=(5, 7, 9)).astype(np.uint16)
