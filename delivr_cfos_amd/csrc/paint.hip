@@ -8,6 +8,11 @@
 // Integer only; identical to the sequential loop for any box list (tests/test_gpu_parity.py, tests/golden/ref_paint.npz).
 #include "common.h"
 
+// scipy-exact fp64 arithmetic below (Gaussian filter, distance transform): no a*b+c may become an fma - HIP contracts by
+// default and the __d*_rn "intrinsics" are plain operators in its headers
+#pragma clang fp contract(off)
+
+
 namespace {
 
 typedef unsigned int u32;

@@ -12,6 +12,11 @@
 
 #include "common.h"
 
+// Every resampler below is bit-exact against numpy / scipy arithmetic: no a*b+c may become an fma (HIP's default for device
+// code is -ffp-contract=fast, and __dmul_rn / __dadd_rn are plain operators in HIP's headers, so they do not prevent it:
+// the spline-2 zoom differed from scipy at exact 1/2 ties - e.g. a zoom factor of 3.75 - until this pragma covered it).
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ void __launch_bounds__(256) block_mean_u16_kernel(const uint16_t* __restrict__ in, int Z, int Y, int X, int fz,
@@ -91,9 +96,10 @@ struct Taps {
     double w[3];
 };
 
-__device__ __forceinline__ Taps spline2_taps(int i, int n_in, int n_out) {
+// `scale` = (n_in - 1) / (n_out - 1) in fp64, computed ONCE ON THE HOST and passed in: the quotient decides which side of an
+// exact 1/2 tie an output lands on, so it has to be the IEEE quotient numpy computes
+__device__ __forceinline__ Taps spline2_taps(int i, int n_in, double scale) {
     Taps t;
-    const double scale = n_out > 1 ? (double)(n_in - 1) / (double)(n_out - 1) : 0.0;
     const double x = __dmul_rn((double)i, scale);
     const double c = floor(__dadd_rn(x, 0.5));
     const double d = __dsub_rn(x, c);
@@ -134,12 +140,16 @@ __device__ __forceinline__ int mirror1(int k, int n_in) {
     return k;
 }
 
+struct ZoomScales {
+    double z, y, x;
+};
+
 __global__ void __launch_bounds__(256) zoom_spline2_u8_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
-                                                              uint8_t* __restrict__ out, int oz, int oy, int ox) {
+                                                              uint8_t* __restrict__ out, int oz, int oy, int ox, ZoomScales sc) {
     const long long n = (long long)oz * oy * ox;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % ox), y = (int)((i / ox) % oy), z = (int)(i / ((long long)ox * oy));
-        const Taps tz = spline2_taps(z, iz, oz), ty = spline2_taps(y, iy, oy), tx = spline2_taps(x, ix, ox);
+        const Taps tz = spline2_taps(z, iz, sc.z), ty = spline2_taps(y, iy, sc.y), tx = spline2_taps(x, ix, sc.x);
         double t = 0.0;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -166,45 +176,80 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_kernel(const uint8_t* __r
 // gives (tests: bit-exact vs scipy on masks with edges, and this kernel against the one above on random data).  Runs
 // whose taps see different values take the full evaluation.  One 16-byte store per run when the row layout allows it.
 __global__ void __launch_bounds__(256) zoom_spline2_u8_run16_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
-                                                                    uint8_t* __restrict__ out, int oz, int oy, int ox) {
+                                                                    uint8_t* __restrict__ out, int oz, int oy, int ox, ZoomScales sc) {
     const int runs = (ox + 15) / 16;
     const long long n = (long long)oz * oy * runs;
     const bool aligned = (ox % 16 == 0) && ((reinterpret_cast<unsigned long long>(out) & 15ull) == 0);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(i % runs), y = (int)((i / runs) % oy), z = (int)(i / ((long long)runs * oy));
-        const int x0 = r * 16, nx = min(16, ox - x0);
-        const Taps tz = spline2_taps(z, iz, oz), ty = spline2_taps(y, iy, oy);
-        // input columns the run touches
-        int kmin = ix, kmax = -1;
-        const double scale_x = ox > 1 ? (double)(ix - 1) / (double)(ox - 1) : 0.0;
-        for (int j = 0; j < nx; ++j) {
-            const int ci = spline2_centre(x0 + j, scale_x);
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count: the lanes of a wave classify one run each, then share the runs that need the full evaluation
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long rounds = (n + stride - 1) / stride;
+    for (long long rd = 0; rd < rounds; ++rd) {
+        const long long i = first + rd * stride;
+        const bool active = i < n;
+        int z = 0, y = 0, x0 = 0, nx = 0;
+        bool uniform = false;
+        if (active) {
+            const int r = (int)(i % runs);
+            y = (int)((i / runs) % oy);
+            z = (int)(i / ((long long)runs * oy));
+            x0 = r * 16;
+            nx = min(16, ox - x0);
+            // input rows / columns the run touches (indices only: no weights yet)
+            int kz[3], ky[3];
+            const int cz = spline2_centre(z, sc.z), cy = spline2_centre(y, sc.y);
 #pragma unroll
-            for (int t = -1; t <= 1; ++t) {
-                const int k = mirror1(ci + t, ix);
-                kmin = min(kmin, k);
-                kmax = max(kmax, k);
+            for (int t = 0; t < 3; ++t) {
+                kz[t] = mirror1(cz + t - 1, iz);
+                ky[t] = mirror1(cy + t - 1, iy);
+            }
+            int kmin = ix, kmax = -1;
+            for (int j = 0; j < nx; ++j) {
+                const int ci = spline2_centre(x0 + j, sc.x);
+#pragma unroll
+                for (int t = -1; t <= 1; ++t) {
+                    const int k = mirror1(ci + t, ix);
+                    kmin = min(kmin, k);
+                    kmax = max(kmax, k);
+                }
+            }
+            uniform = kmax - kmin < 8;
+            if (uniform) {
+                const unsigned cval = in[((long long)kz[0] * iy + ky[0]) * ix + kmin];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const uint8_t* row = in + ((long long)kz[a] * iy + ky[b]) * ix;
+                        for (int k = kmin; k <= kmax; ++k) uniform = uniform && (row[k] == cval);
+                    }
+                if (uniform) {
+                    uint8_t* dst = out + ((long long)z * oy + y) * ox + x0;
+                    if (aligned) {
+                        const unsigned w = cval * 0x01010101u;
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(w, w, w, w);
+                    } else {
+                        for (int j = 0; j < nx; ++j) dst[j] = (uint8_t)cval;
+                    }
+                }
             }
         }
-        bool uniform = kmax - kmin < 8;
-        unsigned cval = 0;
-        if (uniform) {
-            cval = in[((long long)tz.k[0] * iy + ty.k[0]) * ix + kmin];
+        // the other runs (mask edges): four at a time, one output voxel per lane
+        unsigned long long todo = __ballot(active && !uniform);
+        while (todo) {
+            int srcs[4];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const uint8_t* row = in + ((long long)tz.k[a] * iy + ty.k[b]) * ix;
-                    for (int k = kmin; k <= kmax; ++k) uniform = uniform && (row[k] == cval);
-                }
-        }
-        unsigned char v[16];
-        if (uniform) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = (unsigned char)cval;
-        } else {
-            for (int j = 0; j < nx; ++j) {
-                const Taps tx = spline2_taps(x0 + j, ix, ox);
+            for (int q = 0; q < 4; ++q) {
+                srcs[q] = todo ? __ffsll((long long)todo) - 1 : -1;
+                if (todo) todo &= todo - 1;
+            }
+            const int slot = lane >> 4, j = lane & 15;
+            const int src = slot == 0 ? srcs[0] : (slot == 1 ? srcs[1] : (slot == 2 ? srcs[2] : srcs[3]));
+            const int sl = src < 0 ? 0 : src;
+            const int rz = __shfl(z, sl, 64), ry = __shfl(y, sl, 64), rx0 = __shfl(x0, sl, 64), rnx = __shfl(nx, sl, 64);
+            if (src >= 0 && j < rnx) {
+                const Taps tz = spline2_taps(rz, iz, sc.z), ty = spline2_taps(ry, iy, sc.y), tx = spline2_taps(rx0 + j, ix, sc.x);
                 double t = 0.0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
@@ -214,24 +259,13 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_run16_kernel(const uint8_
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const double val = (double)row[tx.k[c]];
-                            t = __dadd_rn(t, __dmul_rn(__dmul_rn(__dmul_rn(val, tz.w[a]), ty.w[b]), tx.w[c]));
+                            t = t + ((val * tz.w[a]) * ty.w[b]) * tx.w[c];
                         }
                     }
-                double rr = t > 0.0 ? __dadd_rn(t, 0.5) : 0.0;
+                double rr = t > 0.0 ? t + 0.5 : 0.0;  // scipy CASE_INTERP_OUT_UINT
                 rr = rr > 255.0 ? 255.0 : rr;
-                v[j] = (unsigned char)rr;
+                out[((long long)rz * oy + ry) * ox + rx0 + j] = (uint8_t)rr;
             }
-        }
-        uint8_t* dst = out + ((long long)z * oy + y) * ox + x0;
-        if (aligned) {
-            uint4 u;
-            u.x = v[0] | (v[1] << 8) | (v[2] << 16) | ((unsigned)v[3] << 24);
-            u.y = v[4] | (v[5] << 8) | (v[6] << 16) | ((unsigned)v[7] << 24);
-            u.z = v[8] | (v[9] << 8) | (v[10] << 16) | ((unsigned)v[11] << 24);
-            u.w = v[12] | (v[13] << 8) | (v[14] << 16) | ((unsigned)v[15] << 24);
-            *reinterpret_cast<uint4*>(dst) = u;
-        } else {
-            for (int j = 0; j < nx; ++j) dst[j] = v[j];
         }
     }
 }
@@ -355,12 +389,16 @@ int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy,
     if (iz <= 0 || iy <= 0 || ix <= 0 || oz <= 0 || oy <= 0 || ox <= 0) return dlv_fail(ctx, DLV_EINVAL, "bad shape");
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     DlvProf p(ctx, "zoom_spline2_u8", 0.0, 1.0 * oz * oy * ox + 1.0 * iz * iy * ix);
+    ZoomScales sc;
+    sc.z = oz > 1 ? (double)(iz - 1) / (double)(oz - 1) : 0.0;
+    sc.y = oy > 1 ? (double)(iy - 1) / (double)(oy - 1) : 0.0;
+    sc.x = ox > 1 ? (double)(ix - 1) / (double)(ox - 1) : 0.0;
     if (getenv("DLV_RESAMPLE_SIMPLE"))  // the one-voxel-per-thread kernel (A/B and cross-check in tests)
         hipLaunchKernelGGL(zoom_spline2_u8_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev,
-                           iz, iy, ix, out_dev, oz, oy, ox);
+                           iz, iy, ix, out_dev, oz, oy, ox, sc);
     else
         hipLaunchKernelGGL(zoom_spline2_u8_run16_kernel, dim3(grid_for((long long)oz * oy * ((ox + 15) / 16))), dim3(256), 0,
-                           ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox);
+                           ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox, sc);
     p.end();
     DLV_LAUNCH_CHECK(ctx, "zoom_spline2_u8_kernel");
     return DLV_OK;
