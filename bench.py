@@ -351,10 +351,10 @@ def main():
         # guide prescribes).  The passes ran the 512^3 workload (25k launches of C3 under PMC exceed the time limit): same
         # kernels, same batch of 16 windows per launch; a launch of another batch is scaled by algorithmic bytes.
         try:
-            tfile = os.path.join(ROOT, "profiles", f"traffic_r02_{args.workload}.json")
+            tfile = os.path.join(ROOT, "profiles", f"traffic_r03_{args.workload}.json")
             scaled = False
             if not os.path.isfile(tfile):
-                tfile = os.path.join(ROOT, "profiles", "traffic_r02_c2.json")
+                tfile = os.path.join(ROOT, "profiles", "traffic_r03_c2.json")
                 scaled = True
             if os.path.isfile(tfile) and args.sw_batch == 0:
                 tj = json.load(open(tfile))

@@ -68,7 +68,7 @@ def load(sub, counter):
 
 ft, fc, fa, fu = load("fetch", "FETCH_SIZE")
 wt, wc, _, wu = load("write", "WRITE_SIZE")
-out = {"workload": wl, "precision": precision, "build": "r02",
+out = {"workload": wl, "precision": precision, "build": os.environ.get("DLV_BUILD_TAG", "r03"),
        "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged over the launches of one label; "
                "algorithmic_bytes = the figure the library's DlvProf bracket declares for that launch (DESIGN.md)",
        "unmatched_launches": fu + wu, "kernels": {}}
