@@ -24,7 +24,7 @@ root, wl, precision = sys.argv[1], sys.argv[2], sys.argv[3]
 FAMILY = [("conv3_zreg_", ["conv3_zreg_kernel"]), ("conv3_zmarch_", ["conv3_zmarch_kernel"]), ("conv3_mfma_", ["conv3_mfma_kernel"]),
           ("norm_mish_", ["norm_mish_kernel"]), ("pool_act_", ["norm_mish_kernel"]), ("deconv2_mfma_", ["deconv2_rows_kernel|deconv2_regw_kernel|deconv2_wst_kernel"]),
           ("stem_mfma_", ["stem_mfma_kernel", "stem_mfma_kernel"]), ("final_conv_", ["final_conv_kernel"]), ("erode_x_", ["erode_x_kernel|erode_x_bits_kernel"]),
-          ("erode_y_", ["erode_y_kernel"]), ("erode_z_", ["erode_z_final_kernel"]), ("window_max_", ["window_max_kernel"]),
+          ("erode_y_", ["erode_y_kernel"]), ("erode_z_", ["erode_z_final_kernel"]), ("window_max_", ["cell_max_kernel|window_max_kernel"]),
           ("skip_fill_", ["fill_add_kernel"])]
 
 
