@@ -288,6 +288,16 @@ def main():
         elapsed_dense, _ = timed_steps(1)
         stats_dense = dict(stats_last)
         cur["params"] = params
+    # the other 16-bit format, one pass (BASELINE's configs name bf16; fp16 is the default for its closer masks)
+    elapsed_alt, alt_prec = None, {"fp16": "bf16", "bf16": "fp16"}.get(args.precision)
+    if alt_prec and not args.no_dense and not args.dense:
+        if params is not None:
+            cur["params"] = eng.make_sw_params(shape, roi, 0.5, None, 0, alt_prec, sw_batch=args.sw_batch, win_range=(wb, we),
+                                               slab=(slo, shi - slo))
+        step()  # warm-up of the other format's kernels
+        elapsed_alt, _ = timed_steps(1)
+        cur["params"] = params
+    if not args.no_dense and not args.dense:
         slab = step()  # leave acc / slab holding the benchmark's own pass (the extras and the CPU leg read them)
         fence()
     stats_last.clear()
@@ -472,6 +482,9 @@ def main():
         "value_dense": (vox / elapsed_dense) if elapsed_dense else None,
         "windows_run_dense": (stats_dense.get("n_windows", 0) - stats_dense.get("n_skipped", 0)) if (elapsed_dense and world == 1) else None,
         "ms_per_step_dense": 1e3 * elapsed_dense if elapsed_dense else None,
+        # one pass in the other 16-bit format (same volume, same skip list)
+        "other_format": {"dtype": {"bf16": "bf16", "fp16": "f16"}[alt_prec], "ms_per_step": 1e3 * elapsed_alt,
+                         "value": vox / elapsed_alt} if elapsed_alt else None,
         # the same `steps` passes with every launch bracketed by HIP events (what `kernels` / `roofline_timed_region` saw)
         "ms_per_step_profiled": 1e3 * elapsed_prof / args.steps if elapsed_prof else None,
         "higher_is_better": True,
