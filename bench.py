@@ -123,6 +123,21 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
     # tolerances of tests/test_gpu_production_shapes.py / tests/test_gpu_trained_like.py for the format measured
     tol_rel, tol_iou = {"fp32": (1e-3, 0.9995), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.99)}[precision]
     ok = bool(rel <= tol_rel and iou >= tol_iou and vs_ref["iou"] >= tol_iou)
+    # the other 16-bit format on the same crop (reported, not part of `ok`)
+    other = None
+    alt = {"fp16": "bf16", "bf16": "fp16"}.get(precision)
+    if alt:
+        a_acc = torch.zeros(crop.shape, dtype=torch.float32, device=eng.device)
+        a_cnt = torch.zeros(crop.shape, dtype=torch.uint8, device=eng.device)
+        eng.sw_infer(eng.make_sw_params(crop.shape, roi, 0.5, None, 0, alt), crop_dev, a_acc, a_cnt)
+        a_mask = eng.finalize(a_acc, a_cnt, crop_dev, crop.shape, 0.5, 30, 0)
+        a_lab, a_n = eng.ccl26(a_mask.contiguous())
+        a_rep = flip_report(a_mask.cpu().numpy(), ref["mask"], ref["mean"])
+        a_cells = match_cells(a_lab.cpu().numpy().view(np.uint32), a_n, eng.cc_stats(a_lab, a_n), lab_ref, ncomp_ref,
+                              orc.cc_stats(lab_ref, ncomp_ref))
+        other = {"precision": alt, "mask_iou_vs_reference_arithmetic": a_rep["iou"], "flipped_vs_reference_arithmetic": a_rep["flipped"],
+                 "components_hip": int(a_n), "cells": a_cells}
+        del a_acc, a_cnt, a_mask, a_lab
     return {
         "value": vox_full / projected if projected > 0 else None,
         "unit": "voxels/s",
@@ -142,7 +157,7 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
                       # against the oracle run in the reference's own arithmetic (fp16 accumulate, uint8 count, fp16 divide)
                       "mask_iou_vs_reference_arithmetic": vs_ref["iou"], "flipped_vs_reference_arithmetic": vs_ref["flipped"],
                       "flip_margin_hist": {"edges": vs_ref["hist_edges"], "counts": vs_ref["hist"]},
-                      "components_reference_arithmetic": int(ncomp_ref), "cells": cells,
+                      "components_reference_arithmetic": int(ncomp_ref), "cells": cells, "other_format": other,
                       "tol_rel_l2": tol_rel, "tol_iou": tol_iou},
     }
 
