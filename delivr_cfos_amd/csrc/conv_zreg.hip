@@ -56,7 +56,7 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: needs Cout %% 32 == 0, W >= 32 and inputs of 32, 32+32 or 64 channels");
     if (ss2 != nullptr || (ss1 != nullptr && c1 != 32))
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: only a 32-channel first input can be activated while staging");
-    if ((long long)D * H * W >= (1ll << 27)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets");
+    if ((long long)D * H * W >= (1ll << 26)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets (buffer resources of 2 x 16 B x voxels)");
     const int ncb = cout / 32;
     const bool act = ss1 != nullptr || ss2 != nullptr;
     // tile height: 16 rows (Cin = 32 only) for windows large enough that 16 of them fill the chip with z-columns of at

@@ -155,12 +155,17 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     }
 
     // ---- staging map: wave w stages chunks w, w+4 of the halo plane; constant along z -------------------------------
-    unsigned goff[C::NIT];  // byte offset of this lane's element within a chunk plane (0 for out-of-window lanes)
+    // Zero padding of the halo: without activation on load (the default instantiations) the plane is fetched with BUFFER
+    // loads whose resource covers exactly one chunk plane - a lane outside the window carries an offset beyond it and the
+    // hardware returns zeros, so the staged piece goes to LDS as it is (no per-dword select in front of every ds_write).
+    // With activation on load the zeros must be those of the ACTIVATED tensor: global loads + a select after the Mish.
+    constexpr bool BUF = !ACT;
+    unsigned goff[C::NIT];  // byte offset of this lane's element within a chunk plane (out-of-window lanes: 0 / out of range)
     unsigned valid = 0;
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
         const int e = it * 64 + lane;
-        goff[it] = 0;
+        goff[it] = BUF ? 0xfffffff0u : 0u;
         if (e < C::PL) {
             const int xh = e % ZR_HX, yh = e / ZR_HX;
             const int gy = y0 + yh - 1, gx = x0 + xh - 1;
@@ -196,9 +201,15 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     u32x4 pre[C::SPW][C::NIT];
     const long long plane_b = (long long)plane * 16;
     auto load_piece = [&](int p, int s, int it) __attribute__((always_inline)) {
-        unsigned o = goff[it];
-        asm volatile("" : "+v"(o));  // keeps the zero-extension next to the load: SGPR base + 32-bit VGPR offset form
-        pre[s][it] = *reinterpret_cast<const u32x4*>(src[s] + (long long)p * plane_b + o);
+        if constexpr (BUF) {  // (the lane offset goes into the instruction as it is: no address arithmetic in the VALU)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src[s] + (long long)p * plane_b), 0,
+                                                                                (int)plane_b, 0x00020000);
+            pre[s][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[it], 0, 0);
+        } else {
+            unsigned o = goff[it];
+            asm volatile("" : "+v"(o));  // keeps the zero-extension next to the load: SGPR base + 32-bit VGPR offset form
+            pre[s][it] = *reinterpret_cast<const u32x4*>(src[s] + (long long)p * plane_b + o);
+        }
     };
     const unsigned wbase = (unsigned)(wave * C::CS + lane);  // + buf*BUF + 4*s*CS + it*64
     // one staged piece: 64 consecutive elements of one chunk plane: [norm + Mish] -> zero padding -> LDS
@@ -208,9 +219,13 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
         const float b = zr_mish(fmaf(P::hi(u), sc[s][2 * k2 + 1], sh[s][2 * k2 + 1]));
         pre[s][it][k2] = P::pack2(a, b);
     };
-    auto store_piece = [&](int buf, int s, int it, bool plane_ok) __attribute__((always_inline)) {
+    auto store_piece = [&](auto INT_, int buf, int s, int it, bool plane_ok) __attribute__((always_inline)) {
         u32x4 v = pre[s][it];
-        if (!(((valid >> it) & 1u) && plane_ok)) v = u32x4{0u, 0u, 0u, 0u};  // zero padding of the ACTIVATED tensor
+        if constexpr (BUF) {  // out-of-window lanes already hold zeros; only a plane that does not exist needs the mask
+            if (!decltype(INT_)::value && !plane_ok) v = u32x4{0u, 0u, 0u, 0u};
+        } else if (!(((valid >> it) & 1u) && plane_ok)) {
+            v = u32x4{0u, 0u, 0u, 0u};  // zero padding of the ACTIVATED tensor
+        }
         if (it * 64 + 63 < C::CS || it * 64 + lane < C::CS) lds[wbase + buf * C::BUF + 4 * s * C::CS + it * 64] = v;
     };
 
@@ -234,6 +249,10 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     // (wave-uniform base pointer + 32-bit lane offset; (q >> 1) * vox * 16 < 2^31 is guaranteed by the launcher)
     char* const obase = reinterpret_cast<char*>(out + ((long long)n * cout8 + cb * 4 + half * 2) * vox);
     const unsigned ooff = ((unsigned)(q >> 1) * (unsigned)vox + (unsigned)((y0 + rg * RW) * W + x0 + l16)) * 16u + (unsigned)(q & 1) * 8u;
+    // interior steps store through a buffer resource over this wave's two output chunks: lane offset (per column block) in a
+    // VGPR that never changes, (plane, row) offset in an SGPR - no per-store address arithmetic in the VALU
+    const unsigned ooff_b[2] = {ooff, ooff + 256u};
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)(2u * (unsigned)vox * 16u), 0x00020000);
     const bool xok[2] = {x0 + l16 < W, x0 + 16 + l16 < W};
     const unsigned toff = (unsigned)(threadIdx.x * 8u + (blockIdx.x & 31u) * 2048u);  // masked-out stores land here (64 KB)
 
@@ -268,6 +287,9 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     // epilogue micro-ops of (row r, block b) of output plane oz, accumulator set `set`: k = 0..3 sums, 4..7 sums of
     // squares, 8 pack + store.  INT: no guards.  Otherwise (steps near the segment ends, partial tiles) the same code with
     // data masks instead of branches: masked-out values add 0 to the statistics and are stored to a trash line.
+    // a finished AGPR accumulator is read into VGPRs ONCE (k == 0) and the nine micro-ops of its epilogue use that copy: left to
+    // the compiler every use (sum, sum of squares, pack) re-reads the AGPRs - 96 v_accvgpr_read per step instead of 32
+    f32x4 epi_v[2] = {fzero, fzero};
     auto epi_op = [&](auto INT_, int set, int r, int b, int k, int oz) __attribute__((always_inline)) {
         constexpr bool INT = decltype(INT_)::value;
         const int oy = y0 + rg * RW + r;
@@ -277,10 +299,15 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             // Pin the first read of the finished accumulator HERE: left alone, the optimiser hoists the element extracts
             // up to the asm MFMA that produced the value - i.e. in front of the wait states an MFMA result needs before
             // anything but another MFMA may read it (asm MFMAs are invisible to the hazard recognizer).
-            if (r < RA) asm volatile("" : "+a"(acca[set][r < RA ? r : 0][b]));
-            else asm volatile("" : "+v"(accv[set][r >= RA ? r - RA : 0][b]));
+            if (r < RA) {
+                asm volatile("" : "+a"(acca[set][r < RA ? r : 0][b]));
+                epi_v[b] = acca[set][r < RA ? r : 0][b];
+                asm volatile("" : "+v"(epi_v[b]));
+            } else {
+                asm volatile("" : "+v"(accv[set][r >= RA ? r - RA : 0][b]));
+            }
         }
-        const f32x4 v = r < RA ? acca[set][r < RA ? r : 0][b] : accv[set][r >= RA ? r - RA : 0][b];
+        const f32x4 v = r < RA ? epi_v[b] : accv[set][r >= RA ? r - RA : 0][b];
         if (k < 4) {
             // pinned (volatile asm keeps its place between the MFMAs; plain C++ adds are re-associated and sunk to the
             // end of the step by the optimiser, where nothing overlaps them)
@@ -294,9 +321,8 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             u.x = P::pack2(v[0], v[1]);
             u.y = P::pack2(v[2], v[3]);
             if constexpr (INT) {
-                unsigned o = ooff + (unsigned)b * 256u;
-                asm volatile("" : "+v"(o));
-                *reinterpret_cast<uint2*>(obase + ((long long)oz * plane + (long long)r * W) * 16 + o) = u;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{u.x, u.y}, ors, (int)ooff_b[b], (int)((unsigned)(oz * plane + r * W) * 16u), 0);
             } else {  // per-lane address: the real voxel or this lane's slot of the trash line
                 char* const real = obase + ((long long)oz * plane + (long long)r * W) * 16 + ooff + (unsigned)b * 256u;
                 *reinterpret_cast<uint2*>(ok ? real : trash + toff) = u;
@@ -360,7 +386,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
                 } else if (k < n_frag + n_epi + n_act) {
                     if (ps == 0) act_elem(ps, pit, k - n_frag - n_epi);  // (ACT instantiation: in1 is always raw)
                 } else if (k == n_frag + n_epi + n_act) {
-                    store_piece(wb, ps, pit, wr_ok);
+                    store_piece(INT_, wb, ps, pit, wr_ok);
                 } else {
                     load_piece(pld, ps, pit);
                 }
@@ -434,7 +460,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) act_elem(s, it, k2);
             }
-            store_piece(p0 & 1, s, it, p0 >= 0);
+            store_piece(std::false_type{}, p0 & 1, s, it, p0 >= 0);
         }
 #pragma unroll
         for (int q2 = 0; q2 < C::NPIECE; ++q2) load_piece(min(zs, D - 1), q2 / C::NIT, q2 % C::NIT);
