@@ -840,11 +840,13 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
                                                            const float* __restrict__ bias, uint4* __restrict__ out, int D,
                                                            int H, int W, int segs, const float2* __restrict__ ss) {
     const int n = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform by construction: lets z / y /
+                                                                                 // the row offsets live in SGPRs)
     const int h = lane >> 5, col = lane & 31;
     const long long vox = (long long)D * H * W;
-    const long long nitems = (long long)D * H * segs;
-    const long long item0 = ((long long)blockIdx.x * 4 + wave) * DC_IPW;
+    const unsigned nitems = (unsigned)D * (unsigned)H * (unsigned)segs;  // row segments of one window: 32-bit index math
+    const unsigned item0 = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * (unsigned)DC_IPW;
     if (item0 >= nitems) return;
     const bool odd = col & 1;
     uint4 w0[4][KP], w1[4][KP];
@@ -855,9 +857,9 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
             w0[ab][kp] = wpk[((long long)(ab * 2 + 0) * KP + kp) * 64 + lane];
             w1[ab][kp] = wpk[((long long)(ab * 2 + 1) * KP + kp) * 64 + lane];
         }
-    float bs[16];
+    f32x16 bsv;  // the bias is the C operand of each parity's first MFMA (no 16 moves per parity to seed an accumulator)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bs[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int r = 0; r < 16; ++r) bsv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
     float sc[KP][8], sh[KP][8];
     if (ss) {
 #pragma unroll
@@ -872,12 +874,17 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int OH = 2 * H, OW = 2 * W;
     const long long ovox = vox * 8;
+    // output through a buffer resource over this sample's four chunks (4 * ovox * 16 B < 2^32: the launcher checks): the
+    // chunk part of an address is an SGPR offset, the voxel part a 32-bit lane offset; lanes beyond the row end carry an
+    // out-of-range offset and the hardware drops their store
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out + (long long)n * 4 * ovox, 0, (int)(unsigned)(4 * ovox * 16), 0x00020000);
+    const unsigned chunk_b = (unsigned)ovox * 16u;
     const uint4* inb = in + ((long long)n * (2 * KP) + h) * vox;
-    auto fetch = [&](long long item, uint4 (&u)[KP]) __attribute__((always_inline)) {
-        const int sg = (int)(item % segs);
-        const long long zy = item / segs;  // z * H + y
+    auto fetch = [&](unsigned item, uint4 (&u)[KP]) __attribute__((always_inline)) {
+        const int sg = (int)(item % (unsigned)segs);
+        const unsigned zy = item / (unsigned)segs;  // z * H + y
         const int xi = sg * 16 + (col >> 1);
-        const long long vin = zy * W + (xi < W ? xi : 0);
+        const long long vin = (long long)zy * W + (xi < W ? xi : 0);
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) u[kp] = inb[(long long)(2 * kp) * vox + vin];
     };
@@ -885,10 +892,10 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
     fetch(item0, cur);
 #pragma unroll 1
     for (int it = 0; it < DC_IPW; ++it) {
-        const long long item = item0 + it;
+        const unsigned item = item0 + (unsigned)it;
         if (item >= nitems) break;
         if (item + 1 < nitems && it + 1 < DC_IPW) fetch(item + 1, nxt);
-        const int sg = (int)(item % segs), y = (int)((item / segs) % H), z = (int)(item / ((long long)segs * H));
+        const int sg = (int)(item % (unsigned)segs), y = (int)((item / (unsigned)segs) % (unsigned)H), z = (int)(item / ((unsigned)segs * (unsigned)H));
         const bool ok = sg * 16 + (col >> 1) < W;
         uint4 b0[KP], b1[KP];
 #pragma unroll
@@ -898,15 +905,15 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
             b0[kp] = AS_FRAG((ok && !odd) ? u : zero4);
             b1[kp] = AS_FRAG((ok && odd) ? u : zero4);
         }
-        const int ox = 2 * sg * 16 + col;
+        const unsigned ox = (unsigned)(2 * sg * 16 + col);
+        const unsigned lane_b = ok ? (ox + (unsigned)h * (unsigned)ovox) * 16u : 0xfffffff0u;  // chunk gp + h: h in the lane part
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {
-            const long long o = ((long long)(2 * z + (ab >> 1)) * OH + (2 * y + (ab & 1))) * OW + ox;
-            f32x16 acc;
+            const unsigned row_b = (unsigned)(((2 * z + (ab >> 1)) * OH + (2 * y + (ab & 1))) * OW) * 16u;  // wave-uniform
+            f32x16 acc = P::mfma(AS_FRAG(w0[ab][0]), b0[0], bsv, 0, 0, 0);
+            acc = P::mfma(AS_FRAG(w1[ab][0]), b1[0], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bs[r];
-#pragma unroll
-            for (int kp = 0; kp < KP; ++kp) {
+            for (int kp = 1; kp < KP; ++kp) {
                 acc = P::mfma(AS_FRAG(w0[ab][kp]), b0[kp], acc, 0, 0, 0);
                 acc = P::mfma(AS_FRAG(w1[ab][kp]), b1[kp], acc, 0, 0, 0);
             }
@@ -921,7 +928,9 @@ __global__ void __launch_bounds__(256) deconv2_regw_kernel(const uint4* __restri
                 // lanes 0-31 end up with all 8 channels of chunk gp, lanes 32-63 with chunk gp+1
                 const auto sx = __builtin_amdgcn_permlane32_swap(px[gp], px[gp + 1], false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(py[gp], py[gp + 1], false, false);
-                if (ok) out[((long long)n * 4 + gp + h) * ovox + o] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4v{sx[0], sy[0], sx[1], sy[1]}, ors, (int)lane_b,
+                                                       (int)(row_b + (unsigned)gp * chunk_b), 0);
             }
         }
 #pragma unroll
@@ -1298,7 +1307,8 @@ struct Net16 {
         dim3 grid(rows ? dlv_cdiv((long long)din.D * din.H * segs, 4) : dlv_cdiv(din.vox(), 128), B);
         // register-resident weights + segment pipeline where the weights fit (Cout = 32, Cin <= 64) and a window has enough
         // row segments (a property of the window shape, not of the batch)
-        const bool regw = rows && L.cout == 32 && L.cin <= 64 && (long long)din.D * din.H * segs >= 4 * DC_IPW * 64;
+        const bool regw = rows && L.cout == 32 && L.cin <= 64 && (long long)din.D * din.H * segs >= 4 * DC_IPW * 64 &&
+                          din.vox() * 8 * 4 * 16 < (1ll << 32);  // (its stores address one sample's output with 32-bit offsets)
         if (regw) grid.x = dlv_cdiv((long long)din.D * din.H * segs, 4 * DC_IPW);
         char dname[48];
         snprintf(dname, sizeof(dname), "deconv2_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
