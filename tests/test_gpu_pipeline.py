@@ -50,7 +50,7 @@ def test_cli_steps_2_and_3(tmp_path, precision, tta):
     crop = (32, 32, 32)
     # not a multiple of the window -> padding matters; the 13-pass cases run a smaller stack (27 windows instead of 75: the
     # oracle replays 13 passes of them in numpy)
-    vol = synth_volume_np((40, 70, 66) if not tta else (40, 50, 44), seed=21, dense=True)
+    vol = synth_volume_np((40, 70, 66) if not tta else (40, 50, 60), seed=21, dense=True)
     vol[:, :, :8] = 0
     root = str(tmp_path)
     raw_dir = os.path.join(root, "raw", brain)
