@@ -201,7 +201,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # DLV_BENCH_FORCE_DIST=1 (with `torch.distributed.run --nproc-per-node 1`): take the N > 1 code path - nccl (= RCCL)
+    # process group, weight broadcast, balanced plan with its all_gather_object, p2p self-test, all_reduce, barrier - at world
+    # size 1, so that every RCCL call of the multi-GPU path has run once on a one-GPU box (tests/test_gpu_rccl.py)
+    dist_mode = world > 1 or os.environ.get("DLV_BENCH_FORCE_DIST") == "1"
+    if dist_mode:
         import torch.distributed as dist
 
         if same_device:
@@ -211,7 +215,7 @@ def main():
 
     from delivr_cfos_amd.engine import HipEngine
     from delivr_cfos_amd.hostlogic import arrayterator_zblock
-    from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, plan_from_params
+    from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, p2p_selftest, plan_from_params
     from delivr_cfos_amd.synth import synth_planes_torch, synth_volume_torch
     from delivr_cfos_amd.weights import TRAINED_LIKE_FIXTURE, random_state_dict, trained_like_state_dict
 
@@ -222,12 +226,15 @@ def main():
     sd = trained_like_state_dict() if weights_name == "trained-like" else random_state_dict(seed=0)
     if rank == 0:
         eng.load_state_dict({"state_dict": sd})
-    if world > 1:
+    if dist_mode:
         broadcast_weights(eng, dist, rank)
+        # one ring exchange of a seam-sized buffer through batch_isend_irecv, compared byte for byte: a broken p2p transport
+        # fails HERE with a clear message, not as a wrong mask after the pass
+        p2p_selftest(dist, eng.device, rank, world, 64 << 20)
 
     params_all = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch)
     nb = arrayterator_zblock((Z, Y, X))
-    if world == 1:
+    if not dist_mode:
         vol = synth_volume_torch(shape, seed, eng.device, dense=args.dense)
         torch.cuda.synchronize()
         plan = plan_from_params(params_all, 1, None)
@@ -252,7 +259,7 @@ def main():
         acc.zero_()
         if cur["params"] is not None:
             stats_last.update(eng.sw_infer(cur["params"], vol, acc))
-        if world > 1:
+        if dist_mode:
             eng.sync()
             exchange_seams(acc, plan, rank, dist, z0=slo)
         slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30, z0=slo)
@@ -265,7 +272,7 @@ def main():
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_mode:
             dist.barrier()
 
     def timed_steps(k):
@@ -275,7 +282,7 @@ def main():
             out = step()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_mode:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if same_device else eng.device)  # (gloo reduces host tensors)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -319,7 +326,7 @@ def main():
     stats_last.update(stats_timed)
     # the mask of the benchmark's own pass: foreground voxels and a position-weighted checksum (identical for every N up to
     # the voxels whose mean logit is within fp32 rounding of 0: the seam sums associate differently), summed over the ranks
-    own_lo = plan.z_owned[rank][0] if world > 1 else 0
+    own_lo = plan.z_owned[rank][0] if dist_mode else 0
     CK_MOD = (1 << 55) - 55  # per-rank residues of up to 16 ranks add up without leaving int64
     n_fg, ck = 0, 0
     for zc in range(0, int(slab.shape[0]), 32):  # plane blocks: torch's arange / int64 temporaries stay small
@@ -329,7 +336,7 @@ def main():
         ck = (ck + int((m64 * (((idx % 2147483629) * 48271) % 2147483629)).sum())) % CK_MOD
         del m64, idx
     mask_sig = torch.tensor([n_fg, ck], dtype=torch.int64, device=eng.device)
-    if world > 1:
+    if dist_mode:
         st = torch.tensor([stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)], dtype=torch.int64,
                           device=eng.device)
         if dist.get_backend() == "gloo":
@@ -342,7 +349,7 @@ def main():
     mask_voxels, mask_checksum = int(mask_sig[0]), int(mask_sig[1]) % CK_MOD
 
     if rank != 0:
-        if world > 1:
+        if dist_mode:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -519,6 +526,7 @@ def main():
             "lanes": int(os.environ.get("DLV_LANES", "3")), "cu_split_mem_cus_per_xcd": int(os.environ.get("DLV_CU_SPLIT", "0")),
             "mask_voxels": mask_voxels, "mask_checksum": mask_checksum,
             "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
+            "dist_backend": (dist.get_backend() + (" (forced at world size 1: DLV_BENCH_FORCE_DIST)" if world == 1 else "")) if dist_mode else None,
         },
         # `roofline` describes the dominant kernel itself: measured with HIP events in one extra step on a single lane
         # (DLV_LANES=1 reproduces it over the timed region; profiles/*_1lane_kernel_stats.csv is rocprofv3's view).
@@ -531,7 +539,7 @@ def main():
         "extras": extras,
     }
     print(json.dumps(out))
-    if world > 1:
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
     if cpu and cpu.get("agreement") and not cpu["agreement"]["ok"]:

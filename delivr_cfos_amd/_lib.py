@@ -115,6 +115,8 @@ SIGNATURES = {
     "dlv_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "dlv_comm_destroy": (C.c_int, [_P]),
     "dlv_comm_size": (C.c_int, [_P]),
+    "dlv_comm_uses_rccl": (C.c_int, [_P]),
+    "dlv_comm_selftest": (C.c_int, [_P, C.c_size_t]),
     "dlv_comm_ctx": (_P, [_P, C.c_int]),
     "dlv_comm_last_error": (C.c_char_p, [_P]),
     "dlv_bcast_weights": (C.c_int, [_P, C.c_int]),
@@ -152,6 +154,7 @@ SIGNATURES = {
                                        C.c_int]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
     "dlv_set_cu_split": (C.c_int, [_P, C.c_int]),
+    "dlv_set_conv_algo": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
     "dlv_prof_reset": (C.c_int, [_P]),
     "dlv_prof_report": (C.c_int, [_P, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),

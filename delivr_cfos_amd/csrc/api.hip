@@ -230,7 +230,9 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         uint16_t* wh = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
         uint16_t* wb16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         uint16_t* wh16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
+        uint16_t* ww = (i > 0 && cin[i] == 32 && cout[i] % 32 == 0) ? (uint16_t*)take((size_t)cout[i] * cin[i] * 36 * 2) : nullptr;
         if (base) {
+            ctx->conv[i].wwino_f16 = ww;
             ctx->conv[i].w16_bf16 = wb16;
             ctx->conv[i].w16_f16 = wh16;
             ctx->conv[i].w_f16 = wh;
@@ -506,6 +508,12 @@ int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
 int dlv_set_lanes(dlv_ctx* ctx, int lanes) {
     if (!ctx || lanes < 1 || lanes > DLV_MAX_LANES) return DLV_EINVAL;
     ctx->lanes_wanted = lanes;
+    return DLV_OK;
+}
+
+int dlv_set_conv_algo(dlv_ctx* ctx, int algo) {
+    if (!ctx || (algo != DLV_CONV_DIRECT && algo != DLV_CONV_WINOGRAD)) return DLV_EINVAL;
+    ctx->conv_algo = algo;
     return DLV_OK;
 }
 

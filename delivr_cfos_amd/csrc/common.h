@@ -37,6 +37,7 @@ struct DlvConvLayer {
     uint16_t* w_f16 = nullptr;  // same order, IEEE half
     uint16_t* w16_bf16 = nullptr;  // v_mfma_f32_16x16x32 A-fragment order (conv_zreg.hip): 16-channel output blocks
     uint16_t* w16_f16 = nullptr;
+    uint16_t* wwino_f16 = nullptr; // Winograd F(2,3)-x transformed weights, 36 fragments per 16 couts (conv_zwino.hip); Cin 32 only
 };
 struct DlvDeconvLayer {
     int cin = 0, cout = 0;
@@ -96,6 +97,7 @@ struct dlv_ctx {
     const float* blend_w = nullptr;
     float blend_min = 0.f;
     float* blend_wsum = nullptr;
+    int conv_algo = 0;          // dlv_set_conv_algo: 0 direct (default), 1 Winograd F(2,3) along x for the fp16 Cin-32 convs of levels 0/1
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
     void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
     void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads
@@ -196,6 +198,11 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
                           int* nparts);
 int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin);
 bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
+// Winograd F(2,3)-along-x variant of the same conv (conv_zwino.hip): fp16, Cin = 32, one final (activated) input
+int dlv_conv3_zwino_launch(dlv_ctx* ctx, int cin, int cout, const void* in1, const void* wwino, void* out, float* partials, int B, int D,
+                           int H, int W, int* nparts);
+int dlv_pack_conv_wino(dlv_ctx* ctx, const float* w_f32, uint16_t* out, int cout, int cin);
+bool dlv_conv3_zwino_supports(int cin, int cout, int c1, int c2, int W);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

@@ -234,7 +234,10 @@ int dlv_comm_init_all(int n, const int* devs, dlv_comm** out) {
             return rc;
         }
     }
-    if (n > 1 && distinct) {
+    // one rank: no transport is needed - unless DLV_FORCE_RCCL=1 asks for the real thing (a 1-rank communicator: every RCCL
+    // entry point of this file - ncclCommInitAll, ncclBroadcast, grouped ncclSend/ncclRecv - then runs on a one-GPU box)
+    const char* force = getenv("DLV_FORCE_RCCL");
+    if (distinct && (n > 1 || (force && force[0] == '1'))) {
         c->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!c->rccl) c->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!c->rccl) {
@@ -288,6 +291,92 @@ int dlv_comm_destroy(dlv_comm* c) {
 }
 
 int dlv_comm_size(dlv_comm* c) { return c ? c->n : 0; }
+int dlv_comm_uses_rccl(dlv_comm* c) { return (c && !c->comm.empty()) ? 1 : 0; }
+
+int dlv_comm_selftest(dlv_comm* c, size_t bytes) {
+    if (!c || bytes == 0 || bytes % 4) return DLV_EINVAL;
+    DLV_ABI_GUARD_BEGIN
+    const int n = c->n;
+    const size_t nw = bytes / 4;
+    std::vector<uint32_t*> snd(n, nullptr), rcv(n, nullptr);
+    std::vector<uint32_t> host(nw), back(nw);
+    struct Free {
+        dlv_comm* c;
+        std::vector<uint32_t*>&a, &b;
+        ~Free() {
+            for (int r = 0; r < c->n; ++r) {
+                (void)hipSetDevice(c->devs[r]);
+                if (a[r]) (void)hipFree(a[r]);
+                if (b[r]) (void)hipFree(b[r]);
+            }
+        }
+    } guard{c, snd, rcv};
+    for (int r = 0; r < n; ++r) {
+        DLV_CHIP(c, hipSetDevice(c->devs[r]));
+        DLV_CHIP(c, hipMalloc((void**)&snd[r], bytes));
+        DLV_CHIP(c, hipMalloc((void**)&rcv[r], bytes));
+        for (size_t i = 0; i < nw; ++i) host[i] = (uint32_t)(i * 2654435761u) ^ (uint32_t)(r * 0x9e3779b9u);
+        DLV_CHIP(c, hipMemcpy(snd[r], host.data(), bytes, hipMemcpyHostToDevice));
+        DLV_CHIP(c, hipMemset(rcv[r], 0, bytes));
+    }
+    const bool rccl = !c->comm.empty();
+    // (1) ring exchange rank r -> r+1 (one rank: to itself), grouped like the seam exchange of dlv_sw_infer_sharded
+    if (rccl) DLV_NCCL(c, c->GroupStart());
+    const int xrc = [&]() -> int {
+        for (int r = 0; r < n; ++r) {
+            const int to = (r + 1) % n, from = (r + n - 1) % n;
+            DLV_CHIP(c, hipSetDevice(c->devs[r]));
+            if (rccl) {
+                DLV_NCCL(c, c->Send(snd[r], nw, ncclFloat32, to, c->comm[r], c->ctx[r]->main_stream));
+                DLV_NCCL(c, c->Recv(rcv[r], nw, ncclFloat32, from, c->comm[r], c->ctx[r]->main_stream));
+            } else {
+                DLV_CHIP(c, hipMemcpyAsync(rcv[r], snd[from], bytes, hipMemcpyDeviceToDevice, c->ctx[r]->main_stream));
+            }
+        }
+        return DLV_OK;
+    }();
+    if (rccl) {
+        const ncclResult_t ge = c->GroupEnd();
+        if (xrc != DLV_OK) return xrc;
+        DLV_NCCL(c, ge);
+    } else if (xrc != DLV_OK) {
+        return xrc;
+    }
+    for (int r = 0; r < n; ++r) {
+        const int from = (r + n - 1) % n;
+        DLV_CHIP(c, hipSetDevice(c->devs[r]));
+        DLV_CHIP(c, hipStreamSynchronize(c->ctx[r]->main_stream));
+        DLV_CHIP(c, hipMemcpy(back.data(), rcv[r], bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nw; ++i)
+            if (back[i] != ((uint32_t)(i * 2654435761u) ^ (uint32_t)(from * 0x9e3779b9u)))
+                return comm_fail(c, DLV_ESTATE, "self-test: rank %d received a wrong word %zu from rank %d (%s transport)", r, i, from,
+                                 rccl ? "RCCL" : "device-copy");
+    }
+    // (2) broadcast of rank 0's buffer into every rank's receive buffer (ncclUint8, like the weight blob)
+    if (rccl) {
+        DLV_NCCL(c, c->GroupStart());
+        const int brc = [&]() -> int {
+            for (int r = 0; r < n; ++r) {
+                DLV_CHIP(c, hipSetDevice(c->devs[r]));
+                DLV_NCCL(c, c->Broadcast(snd[0], rcv[r], bytes, ncclUint8, 0, c->comm[r], c->ctx[r]->main_stream));
+            }
+            return DLV_OK;
+        }();
+        const ncclResult_t ge = c->GroupEnd();
+        if (brc != DLV_OK) return brc;
+        DLV_NCCL(c, ge);
+        for (int r = 0; r < n; ++r) {
+            DLV_CHIP(c, hipSetDevice(c->devs[r]));
+            DLV_CHIP(c, hipStreamSynchronize(c->ctx[r]->main_stream));
+            DLV_CHIP(c, hipMemcpy(back.data(), rcv[r], bytes, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nw; ++i)
+                if (back[i] != (uint32_t)(i * 2654435761u))
+                    return comm_fail(c, DLV_ESTATE, "self-test: rank %d holds a wrong word %zu after the broadcast", r, i);
+        }
+    }
+    return DLV_OK;
+    DLV_ABI_GUARD_END(c)
+}
 dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->ctx[rank] : nullptr; }
 const char* dlv_comm_last_error(dlv_comm* c) { return c ? c->err.c_str() : "null comm"; }
 

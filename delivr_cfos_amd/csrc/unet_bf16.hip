@@ -1190,6 +1190,19 @@ struct Net16 {
         DLV_TRY(use(DLV_K_MFMA, d));
         const uint4* in1 = a1.p;
         const uint4* in2 = a2 ? a2->p : nullptr;
+        if (zreg_runs(li, c1, c2, d) && P::IS_F16 && ctx->conv_algo == DLV_CONV_WINOGRAD && !a1.ss && L.wwino_f16 &&
+            dlv_conv3_zwino_supports(L.cin, L.cout, c1, c2, d.W)) {  // Winograd F(2,3) along x (conv_zwino.hip)
+            char zname[48];
+            snprintf(zname, sizeof(zname), "conv3_zwino_f16_c%dx%d_d%d", L.cin, L.cout, d.D);
+            // (flops: the DIRECT convolution's 2*27*Cin*Cout per voxel - what the layer computes, not what the MFMAs issue)
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
+            int np = 0;
+            if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
+                return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zwino)");
+            DLV_TRY(dlv_conv3_zwino_launch(ctx, L.cin, L.cout, in1, L.wwino_f16, out, partials, B, d.D, d.H, d.W, &np));
+            zp.end();
+            return stats(np, li, d);
+        }
         if (zreg_runs(li, c1, c2, d)) {
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d_d%d%s", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D, a1.ss ? "_act" : "");
@@ -1487,6 +1500,7 @@ int pack_weights_16(dlv_ctx* ctx) {
         hipLaunchKernelGGL(pack_conv_w_kernel<P>, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->conv[i]), L.cout, L.cin);
         DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
         DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cout, L.cin));
+        if (P::IS_F16 && L.wwino_f16) DLV_TRY(dlv_pack_conv_wino(ctx, L.w_f32, L.wwino_f16, L.cout, L.cin));
     }
     for (int j = 0; j < DLV_N_DECONV; ++j) {
         const DlvDeconvLayer& L = ctx->deconv[j];

@@ -74,6 +74,14 @@ class HipComm:
         if rc != 0:
             raise DelivrHipError(rc, self.lib.dlv_comm_last_error(self.handle).decode(errors="replace"))
 
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.dlv_comm_uses_rccl(self.handle))
+
+    def selftest(self, nbytes: int = 64 << 20) -> None:
+        """Ring exchange + broadcast of `nbytes` through the communicator's transport, compared word for word."""
+        self._check(self.lib.dlv_comm_selftest(self.handle, int(nbytes)))
+
     def bcast_weights(self, root: int = 0):
         self._check(self.lib.dlv_bcast_weights(self.handle, int(root)))
         for e in self.engines:
@@ -624,6 +632,11 @@ class HipEngine:
     # ---- kernel timer ------------------------------------------------------------------------------
     def set_lanes(self, lanes: int):
         self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))
+
+    def set_conv_algo(self, algo) -> None:
+        """"direct" (default) or "winograd" (opt-in: F(2,3) along x for the fp16 Cin-32 convs of levels 0/1; dlv_set_conv_algo)."""
+        code = {"direct": 0, "winograd": 1}.get(algo, algo)
+        self._check(self.lib.dlv_set_conv_algo(self.ctx, int(code)))
 
     def set_cu_split(self, mem_cus_per_xcd: int):
         """0 = off; m = the HBM-class kernels of the 16-bit forward run on m CUs of every XCD, the convs on the other 32 - m."""

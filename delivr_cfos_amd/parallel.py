@@ -226,6 +226,27 @@ def exchange_seams(acc, plan: ShardPlan, rank: int, dist, group=None, z0: int = 
         acc[lo - z0:hi - z0] += buf.to(acc.device) if stage else buf
 
 
+def p2p_selftest(dist, device, rank: int, world: int, nbytes: int = 64 << 20, group=None) -> None:
+    """One ring exchange (rank -> rank+1, at world size 1: to itself) of `nbytes` through the same batch_isend_irecv the seam
+    exchange uses, compared byte for byte.  Raises RuntimeError naming the backend when the transport delivers anything else."""
+    import torch
+
+    n = int(nbytes) // 8
+    base = torch.arange(n, dtype=torch.int64, device=device)
+    send = base * 2654435761 + rank
+    recv = torch.zeros_like(send)
+    stage = _needs_host_staging(send, dist)
+    sbuf, rbuf = (send.cpu(), recv.cpu()) if stage else (send, recv)
+    ops = [dist.P2POp(dist.isend, sbuf, (rank + 1) % world, group=group), dist.P2POp(dist.irecv, rbuf, (rank - 1) % world, group=group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if not stage:
+        torch.cuda.synchronize(device)
+    want = base * 2654435761 + (rank - 1) % world
+    if not torch.equal(rbuf.to(device), want):
+        raise RuntimeError(f"p2p self-test failed on backend {dist.get_backend()}: rank {rank} did not receive rank {(rank - 1) % world}'s buffer intact")
+
+
 def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]] = None, src: int = 0, group=None) -> None:
     """Rank `src` has called engine.load_state_dict(); the others receive the packed blob
     (fp32 + MFMA-packed bf16 parameters, ~35 MB) with ONE broadcast."""

@@ -186,6 +186,14 @@ int dlv_shard_slab(const dlv_shard_plan* plan, int rank, int Z, int erode_iters,
 int dlv_comm_init_all(int n, const int* devs, dlv_comm** out);
 int dlv_comm_destroy(dlv_comm* c);
 int dlv_comm_size(dlv_comm* c);
+/* 1 when the communicator moves data with RCCL (several distinct devices, or one device with DLV_FORCE_RCCL=1 in the
+ * environment of dlv_comm_init_all: a 1-rank ncclCommInitAll), 0 for the device-copy transport of ranks sharing a device */
+int dlv_comm_uses_rccl(dlv_comm* c);
+/* Transport check before a long job: every rank sends `bytes` (a multiple of 4) to the next rank of the ring - itself when
+ * there is one rank - with the grouped ncclSend/ncclRecv the seam exchange uses, then rank 0's buffer is broadcast
+ * (ncclBroadcast, like the weight blob); everything received is compared word for word on the host.  DLV_ESTATE + message
+ * on a mismatch.  Synchronous.  No reference counterpart (DataParallel has no such check). */
+int dlv_comm_selftest(dlv_comm* c, size_t bytes);
 dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank); /* owned by the communicator */
 const char* dlv_comm_last_error(dlv_comm* c);
 /* dlv_unet_load was called on rank `root`: every other rank allocates the blob and receives it with ONE ncclBroadcast */
@@ -348,6 +356,17 @@ int dlv_set_lanes(dlv_ctx* ctx, int lanes);
  * competing for the same SIMDs; lanes (dlv_set_lanes) = batches in flight, 1..6.  -1: no CU masks, but the two kinds of
  * kernels on a high- and a low-priority stream per lane.  Results are identical to the unsplit pass in every mode.  The DLV_CU_SPLIT environment variable sets the value a new context starts with.  No reference counterpart. */
 int dlv_set_cu_split(dlv_ctx* ctx, int mem_cus_per_xcd);
+/* Algorithm of the fp16 3x3x3 convolutions with 32 input channels at the two top levels (5 of the 7 convs that hold 91 % of
+ * the FLOPs).  DLV_CONV_DIRECT (default): the 27-tap implicit GEMM for every layer.  DLV_CONV_WINOGRAD (opt-in, fp16 only):
+ * Winograd F(2,3) along x, direct in y and z - 36 instead of 54 MFMAs per 32 voxels; weights transformed in fp32 and
+ * rounded to fp16 once, the input transform is one packed fp16 add per element, accumulation and the output transform
+ * are fp32.  Measured (round 4, profiles/README.md): 3-4.5 % faster per layer only - the staging of the halo planes, not
+ * the MFMAs, is what a z step pays for - at 706 instead of 529 flipped voxels of 16.8 M against the reference's arithmetic
+ * (mask IoU 0.99969 instead of 0.99977; north_star tolerance 0.999): not the default.  Replaces the cuDNN algorithm
+ * choice behind torch.nn.Conv3d (inference/inference.py:190-197); no reference counterpart for the switch. */
+#define DLV_CONV_DIRECT 0
+#define DLV_CONV_WINOGRAD 1
+int dlv_set_conv_algo(dlv_ctx* ctx, int algo);
 int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */

@@ -373,3 +373,38 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, p
         rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
         print(env, "rel rms vs default:", rel)
         assert rel < tol, (env, rel)
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in Winograd F(2,3)-along-x variant of the fp16 Cin-32 convs (dlv_set_conv_algo, conv_zwino_kernel.h)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("li,D,H,W", [(1, 6, 12, 40), (1, 24, 40, 64), (3, 33, 24, 96), (17, 40, 16, 64), (17, 70, 64, 64)])
+def test_conv_block_fp16_winograd(eng, net, li, D, H, W):
+    """The Winograd kernel against the same torch reference as test_conv_block_fp16 (fp16-rounded inputs and weights, fp32
+    math): ragged tiles in y and x, z segments, interior and edge steps.  Its extra roundings (U = G g and V = B^T d in
+    fp16) double the mean error of the direct kernel - tolerance 2x; and it must really have run (profile label)."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(li * 100 + D)
+    x1 = torch.randn((2, 32, D, H, W), generator=g).half().float()
+    blk = _conv_block(net, li)
+    with torch.no_grad():
+        raw = F.conv3d(x1, blk.conv.weight.half().float(), blk.conv.bias, padding=1)
+        ref = F.mish(F.instance_norm(raw, weight=blk.adn.N.weight, bias=blk.adn.N.bias, eps=1e-5))
+    eng.set_conv_algo("winograd")
+    eng.prof_reset()
+    eng.prof_enable(True)
+    try:
+        out = eng.debug_layer_bf16(0, li, x1.cuda(), None, precision="fp16").cpu()
+    finally:
+        eng.prof_enable(False)
+        eng.set_conv_algo("direct")
+    ran = [k for k, e in eng.prof_report().items() if e["launches"]]
+    if D * H * W > 32768:  # (smaller tensors take the generic kernel in either mode)
+        assert any(k.startswith("conv3_zwino_f16") for k in ran), ran
+    err = (out - ref).abs()
+    assert err.max() < 0.02, float(err.max())
+    assert err.mean() < 2e-3, float(err.mean())
+    base = eng.debug_layer_bf16(0, li, x1.cuda(), None, precision="fp16").cpu()
+    assert (out - base).abs().max() < 0.02
