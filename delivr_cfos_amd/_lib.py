@@ -23,7 +23,7 @@ if os.environ.get("DLV_LIB"):
                           "to time it (profiles/tools/zreg_abl.sh does)")
     LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), _name)
 
-DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP = 0, -1, -2, -3, -4, -5
+DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP, DLV_ERANGE = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 N_CONV, N_DECONV = 18, 4
 PROF_MAX = 64

@@ -327,6 +327,10 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     }
     ctx->main_stream = ctx->stream;
     if (hipMalloc(&ctx->zero_page, 256) == hipSuccess) (void)hipMemset(ctx->zero_page, 0, 256);
+    if (hipMalloc((void**)&ctx->range_flag, 256) != hipSuccess || hipMemset(ctx->range_flag, 0, 256) != hipSuccess) {
+        (void)dlv_ctx_destroy(ctx);
+        return DLV_ENOMEM;
+    }
     if (!getenv("DLV_ONE_LANE")) {
         bool ok = true;
         for (int k = 0; k < DLV_MAX_LANES - 1 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
@@ -360,6 +364,7 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->blob) (void)hipFree(ctx->blob);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+    if (ctx->range_flag) (void)hipFree(ctx->range_flag);
     for (int k = 0; k < DLV_MAX_LANES - 1; ++k)
         if (ctx->aux[k]) {
             (void)hipStreamSynchronize(ctx->aux[k]);

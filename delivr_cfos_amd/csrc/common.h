@@ -100,6 +100,7 @@ struct dlv_ctx {
     int conv_algo = 0;          // dlv_set_conv_algo: 0 direct (default), 1 Winograd F(2,3) along x for the fp16 Cin-32 convs of levels 0/1
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
     void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
+    int* range_flag = nullptr;  // device word: 0, or 100 - (first layer whose InstanceNorm sums were not finite; 18 = logits)
     void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads
     void* blob = nullptr;  // one allocation holding every packed parameter
     size_t blob_bytes = 0;
@@ -198,6 +199,9 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
                           int* nparts);
 int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin);
 bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
+// range guard of the 16-bit formats (unet_bf16.hip): reset before a pass / forward, check after it (synchronises the stream)
+int dlv_range_reset(dlv_ctx* ctx);
+int dlv_range_check(dlv_ctx* ctx, bool f16);
 // Winograd F(2,3)-along-x variant of the same conv (conv_zwino.hip): fp16, Cin = 32, one final (activated) input
 int dlv_conv3_zwino_launch(dlv_ctx* ctx, int cin, int cout, const void* in1, const void* wwino, void* out, float* partials, int B, int D,
                            int H, int W, int* nparts);

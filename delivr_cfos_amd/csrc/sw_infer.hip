@@ -536,6 +536,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                 if (m != l) DLV_HIP(ctx, hipStreamWaitEvent(parts[l], ctx->ev_lane[m], 0));
         return DLV_OK;
     };
+    if (p->precision != DLV_PREC_F32) DLV_TRY(dlv_range_reset(ctx));
     int rc = join_lanes();  // the aux lane starts after everything queued on the main stream so far
     int lane = 0;
     for (const Seg& s : segs) {
@@ -592,6 +593,9 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
         stats->n_skipped = n_skipped;
         stats->n_forward_launches = launches;
     }
+    // range guard of the 16-bit formats: every lane has been joined into the main stream; one read-back per pass (a pass is
+    // seconds of queued work, and the next one starts with the read-back of its window maxima anyway)
+    if (p->precision != DLV_PREC_F32 && launches > 0) return dlv_range_check(ctx, p->precision == DLV_PREC_F16);
     return DLV_OK;
 }
 

@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256) conv3_mfma_kernel(const uint4* __restrict
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restrict__ partials, int nparts, int C,
                                                             double inv_count, float eps, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float2* __restrict__ ss) {
+                                                            const float* __restrict__ beta, float2* __restrict__ ss,
+                                                            int* __restrict__ range_flag, int layer) {
     const int c = blockIdx.x % C, n = blockIdx.x / C;
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 64) {
@@ -620,6 +621,10 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
         q += __shfl_down(q, o, 64);
     }
     if (threadIdx.x == 0) {
+        // Range guard: a raw value beyond the 16-bit format's range is stored as Inf, the next normalisation pass turns it into
+        // Inf or NaN, and the next convolution's sums - these - stop being finite.  Detected here for free; without it the mask
+        // silently becomes zeros (NaN >= 0 is false).  The first such layer wins (atomicMax of 100 - layer).
+        if (!(fabs(s) <= 1.0e300 && fabs(q) <= 1.0e300)) atomicMax(range_flag, 100 - layer);
         const double mean = s * inv_count;
         double var = q * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -1023,8 +1028,9 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
                                                          float* __restrict__ logits, const int* __restrict__ starts,
                                                          int flip_dim, int Yp, int Xp, float scale, float* __restrict__ acc,
                                                          int D, int H, int W, const float* __restrict__ bw, float bmin,
-                                                         float* __restrict__ wsum) {
+                                                         float* __restrict__ wsum, int* __restrict__ range_flag) {
     const int n = blockIdx.y;
+    bool bad = false;  // range guard of the last block's raw tensor (no later InstanceNorm would see it): a non-finite logit
     // per-sample scale/shift and the 32 weights are uniform over the workgroup: scalar loads, SGPR operands
     f32x2_t sc[16], sh[16], ww[16];
 #pragma unroll
@@ -1057,6 +1063,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
             }
         }
         const float a = a2.x + a2.y;
+        bad |= !(fabsf(a) <= 3.0e38f);
         if (!BLEND) {
             logits[(long long)n * vox + i] = a;
         } else {
@@ -1074,6 +1081,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
             }
         }
     }
+    if (bad) atomicMax(range_flag, 100 - 18);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1173,7 +1181,7 @@ struct Net16 {
         // the fp16 format stores the raw stem output scaled by 2^-8: eps scales with its square (same normalised value)
         const float eps = li == 0 ? 1e-5f * P::STEM_SCALE * P::STEM_SCALE : 1e-5f;
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(B * L.cout), dim3(64), 0, ctx->stream, partials, nparts, L.cout,
-                           1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss_of(li));
+                           1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss_of(li), ctx->range_flag, li);
         DLV_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
         return DLV_OK;
     }
@@ -1479,10 +1487,10 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         if (acc)
             hipLaunchKernelGGL((final_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, cur.p, cur.ss, ctx->final_w,
                                ctx->final_b, nullptr, starts_dev, flip_dim, Yp, Xp, scale, acc, d, h, w, ctx->blend_w, ctx->blend_min,
-                               ctx->blend_wsum);
+                               ctx->blend_wsum, ctx->range_flag);
         else
             hipLaunchKernelGGL((final_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, cur.p, cur.ss, ctx->final_w,
-                               ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w, nullptr, 0.f, nullptr);
+                               ctx->final_b, logits, nullptr, -1, 0, 0, 1.f, nullptr, d, h, w, nullptr, 0.f, nullptr, ctx->range_flag);
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "final_conv_kernel");
     }
@@ -1570,9 +1578,35 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx) {
     return pack_weights_16<PF16>(ctx);
 }
 
+int dlv_range_reset(dlv_ctx* ctx) {
+    DLV_HIP(ctx, hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->main_stream));
+    return DLV_OK;
+}
+
+// after everything of the pass / forward has been ordered behind the main stream: read the guard word back
+int dlv_range_check(dlv_ctx* ctx, bool f16) {
+    int flag = 0;
+    DLV_HIP(ctx, hipMemcpyAsync(&flag, ctx->range_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->main_stream));
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    if (flag == 0) return DLV_OK;
+    const int layer = 100 - flag;
+    static const char* const names[DLV_N_CONV] = {"conv_0.conv_0", "conv_0.conv_1", "down_1.conv_0", "down_1.conv_1", "down_2.conv_0",
+                                                  "down_2.conv_1", "down_3.conv_0", "down_3.conv_1", "down_4.conv_0", "down_4.conv_1",
+                                                  "upcat_4.conv_0", "upcat_4.conv_1", "upcat_3.conv_0", "upcat_3.conv_1", "upcat_2.conv_0",
+                                                  "upcat_2.conv_1", "upcat_1.conv_0", "upcat_1.conv_1"};
+    if (layer >= 0 && layer < DLV_N_CONV)
+        return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: the InstanceNorm sums of conv block %d (%s) are not finite - a value of its input "
+                        "(the block before it or the transposed conv feeding it) left the format%s", f16 ? "fp16" : "bf16", layer, names[layer],
+                        f16 ? "; use precision bf16 (8 exponent bits) for this checkpoint" : "");
+    return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: non-finite logits (raw output of the last conv block, upcat_1.conv_1)%s",
+                    f16 ? "fp16" : "bf16", f16 ? "; use precision bf16 (8 exponent bits) for this checkpoint" : "");
+}
+
 int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16) {
-    if (f16) return forward_16<PF16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
-    return forward_16<PBf16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w);
+    DLV_TRY(dlv_range_reset(ctx));
+    if (f16) DLV_TRY(forward_16<PF16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w));
+    else DLV_TRY(forward_16<PBf16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w));
+    return dlv_range_check(ctx, f16 != 0);  // (dlv_unet_forward_dev is synchronous)
 }
 
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d, int h,

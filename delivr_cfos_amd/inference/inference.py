@@ -14,6 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from ..hostlogic import arrayterator_zblock, padded_shape, pass_schedule
+from .._lib import DLV_ERANGE, DelivrHipError
 from ..model import HipBasicUNet
 from .sliding_window_inferer import SlidingWindowInferer
 
@@ -153,12 +154,27 @@ def run_inference(
     # inference passes (reference :261-279)
     print(f"{datetime.datetime.now()} : Starting inference")
     if not sharded:
-        for flip_dim, repeat in pass_schedule(bool(tta)):
-            kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
-            if flip_dim is not None:
-                kw.update(tta=True, flip_dim=flip_dim)
-            inferer(dataset, model, **kw)
-        eng.sync()
+        def run_passes():
+            for flip_dim, repeat in pass_schedule(bool(tta)):
+                kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
+                if flip_dim is not None:
+                    kw.update(tta=True, flip_dim=flip_dim)
+                inferer(dataset, model, **kw)
+            eng.sync()
+
+        try:
+            run_passes()
+        except DelivrHipError as e:
+            # range guard (DLV_ERANGE): this checkpoint drives a raw activation beyond fp16's 65504 - the library reports it
+            # instead of painting a garbage mask; bf16 has fp32's exponent range and is the documented alternative
+            if e.code != DLV_ERANGE or model.precision != "fp16":
+                raise
+            print(f"WARNING: {e}\nWARNING: repeating the inference passes with bf16 operands")
+            model.precision = precision = "bf16"
+            output_image.zero_()
+            if count_map is not None:
+                count_map.zero_()
+            run_passes()
         # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
         print(f"{datetime.datetime.now()} : Creating binarized blob output")
         os.makedirs(binaries_path, exist_ok=True)
@@ -180,17 +196,38 @@ def run_inference(
             arrayterator_zblock((Z, Y, X)))
         output_image = torch.zeros((shi - slo,) + tuple(pad[3:]), dtype=torch.float32, device=eng.device)
         count_map = torch.zeros((shi - slo,) + tuple(pad[3:]), dtype=cm_dtype, device=eng.device) if need_count else None
-        for flip_dim, repeat in pass_schedule(bool(tta)):
-            wb, we = plan.win_ranges[rank]
-            if we > wb:
-                if gaussian:
-                    eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
-                                                    slab=(slo, shi - slo), repeat=repeat, blend="gaussian", wsum=count_map),
-                                 dataset, output_image)
-                else:
-                    eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, precision, win_range=(wb, we),
-                                                    slab=(slo, shi - slo), repeat=repeat), dataset, output_image, count_map)
-        eng.sync()
+        def run_passes(prec):
+            """-> 0, or 1 when this rank's passes left the 16-bit format's range (every rank must learn of it)"""
+            try:
+                for flip_dim, repeat in pass_schedule(bool(tta)):
+                    wb, we = plan.win_ranges[rank]
+                    if we > wb:
+                        if gaussian:
+                            eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, prec, win_range=(wb, we),
+                                                            slab=(slo, shi - slo), repeat=repeat, blend="gaussian", wsum=count_map),
+                                         dataset, output_image)
+                        else:
+                            eng.sw_infer(eng.make_sw_params(pad[2:], crop_size, overlap, flip_dim, 0, prec, win_range=(wb, we),
+                                                            slab=(slo, shi - slo), repeat=repeat), dataset, output_image, count_map)
+                eng.sync()
+            except DelivrHipError as e:
+                if e.code != DLV_ERANGE or prec != "fp16":
+                    raise
+                print(f"WARNING (rank {rank}): {e}")
+                return 1
+            return 0
+
+        bad = torch.tensor([run_passes(precision)], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else eng.device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):  # some rank left fp16's range: every rank repeats its passes in bf16 (one mask, one format)
+            if rank == 0:
+                print("WARNING: repeating the inference passes with bf16 operands on every rank")
+            precision = "bf16"
+            output_image.zero_()
+            if count_map is not None:
+                count_map.zero_()
+            if run_passes(precision):
+                raise RuntimeError("unreachable: bf16 range errors are raised")
         exchange_seams(output_image, plan, rank, dist, z0=slo)
         if count_map is not None:
             exchange_seams(count_map, plan, rank, dist, z0=slo)

@@ -36,6 +36,7 @@ extern "C" {
 #define DLV_ENOMEM (-3)   /* device allocation failed */
 #define DLV_ESTATE (-4)   /* call order violated (e.g. forward before dlv_unet_load) */
 #define DLV_EUNSUP (-5)   /* shape not supported by the kernels */
+#define DLV_ERANGE (-6)   /* a 16-bit forward produced a non-finite value: the format's range was exceeded (fp16: use bf16) */
 
 #define DLV_ABI_VERSION 1
 
