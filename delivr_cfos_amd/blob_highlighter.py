@@ -26,12 +26,9 @@ from .tiffio import write_tiff_plane
 
 def load_cached_stats(settings, brain):
     """reference :25-36"""
-    path_in = settings["postprocessing"]["output_location"]
-    result = False
-    for item in [x for x in os.listdir(path_in) if ".pickle" in x]:
-        if brain in item:
-            result = os.path.join(path_in, item)
-    return result
+    from .count_blobs import _find_cached
+
+    return _find_cached(settings["postprocessing"]["output_location"], ".pickle", brain)
 
 
 def read_cell_table(path: str) -> dict:

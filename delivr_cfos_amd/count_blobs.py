@@ -16,24 +16,21 @@ import numpy as np
 from .hostlogic import cells_csv_text, csv_name
 
 
+def _find_cached(path: str, suffix: str, brain: str):
+    """The LAST directory entry (os.listdir order, as the reference iterates) whose name holds `suffix` and `brain`; False
+    when there is none - what the reference's three cache look-ups return (count_blobs.py:10-34, blob_highlighter.py)."""
+    hits = [x for x in os.listdir(path) if suffix in x and brain in x]
+    return os.path.join(path, hits[-1]) if hits else False
+
+
 def load_cached_brain(settings, brain):
     """reference :10-21"""
-    path_in = settings["postprocessing"]["output_location"]
-    result = False
-    for item in [x for x in os.listdir(path_in) if ".npy" in x]:
-        if brain in item:
-            result = os.path.join(path_in, item)
-    return result
+    return _find_cached(settings["postprocessing"]["output_location"], ".npy", brain)
 
 
 def load_cached_stats(settings, brain):
     """reference :23-34"""
-    path_in = settings["postprocessing"]["output_location"]
-    result = False
-    for item in [x for x in os.listdir(path_in) if ".pickle" in x]:
-        if brain in item:
-            result = os.path.join(path_in, item)
-    return result
+    return _find_cached(settings["postprocessing"]["output_location"], ".pickle", brain)
 
 
 def _label_dtype(n: int):
@@ -69,13 +66,29 @@ def _count_blobs_sharded(eng, bin_img, dist, path_out, brain):
     dist.broadcast_object_list(err, src=0)
     if err[0] is not None:
         raise RuntimeError(f"count_blobs: rank 0 could not create {out_path}: {err[0]}")
-    if hi > lo:
-        mm = np.load(out_path, mmap_mode="r+")
-        mm[lo:hi] = labels.cpu().numpy().view(np.uint32).astype(_label_dtype(N), copy=False)
-        mm.flush()
-        del mm
-    dist.barrier()
+    # every rank writes ITS slab into the one file: path_out must be a directory all ranks share.  The outcome of every
+    # write is exchanged - a rank that cannot see or write the file (node-local path, ENOSPC) must not leave the others
+    # waiting in a barrier
+    mine = None
+    try:
+        if hi > lo:
+            mm = np.load(out_path, mmap_mode="r+")
+            mm[lo:hi] = labels.cpu().numpy().view(np.uint32).astype(_label_dtype(N), copy=False)
+            mm.flush()
+            del mm
+    except Exception as exc:
+        mine = f"rank {rank}: {exc!r}"
+    _raise_if_any_failed(dist, mine, f"count_blobs: writing the label slabs into {out_path} (path_out must be shared by all ranks)")
     return N, stats
+
+
+def _raise_if_any_failed(dist, mine, what: str):
+    """all_gather of every rank's error text (None = fine): all ranks raise together or none does"""
+    outcomes = [None] * dist.get_world_size()
+    dist.all_gather_object(outcomes, mine)
+    bad = [o for o in outcomes if o]
+    if bad:
+        raise RuntimeError(f"{what} failed: " + "; ".join(bad))
 
 
 def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max_size=-1, engine=None):
@@ -122,14 +135,18 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
             finally:
                 if own:
                     eng.close()
+            mine = None
             if rank == 0:
-                with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
-                    pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
-                with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
-                    fh.write(cells_csv_text(stats, N))
-                end = datetime.datetime.now()
-                print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
-            dist.barrier()
+                try:
+                    with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
+                        pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
+                    with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
+                        fh.write(cells_csv_text(stats, N))
+                    end = datetime.datetime.now()
+                    print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
+                except Exception as exc:
+                    mine = f"rank 0: {exc!r}"
+            _raise_if_any_failed(dist, mine, "count_blobs: writing the statistics / CSV")
             return N
         if rank != 0:
             # a cached labelling exists: rank 0 alone re-uses it (and writes the statistics / CSV), the others wait for
@@ -163,6 +180,30 @@ def _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start):
     labels_dev = None
     try:
         cached = load_cached_brain(settings, brain)
+        from .streaming import ccl_bytes_per_voxel, ccl_streamed, hbm_budget_bytes
+
+        budget = hbm_budget_bytes(eng, settings)
+        need = int(bin_img.size) * ccl_bytes_per_voxel()
+        if not cached and need > budget:
+            # the mask + its uint32 labels do not fit this GPU: Z-slabs through the device, seams merged on the host
+            # (streaming.py) - the reference's counterpart is cc3d writing into an out_file memmap (:59-64)
+            plane = int(bin_img.shape[1]) * int(bin_img.shape[2]) * ccl_bytes_per_voxel()
+            n_slabs = -(-need // max(budget, 1))
+            if plane > budget or n_slabs > bin_img.shape[0]:
+                raise MemoryError(f"delivr_cfos_amd (DLV_ENOMEM): one mask plane with its labels and scratch needs {plane / 2**20:.1f} MiB, "
+                                  f"the HBM budget is {budget / 2**20:.1f} MiB; raise settings['mi355x']['hbm_budget_gb']")
+            print(f"No cached brain found; mask + labels of {need / 2**30:.1f} GiB exceed the HBM budget of {budget / 2**30:.1f} GiB: "
+                  f"connected components on {n_slabs} Z-slabs...")
+            made = {}
+
+            def create_output(n):
+                made["path"] = os.path.join(path_out, f"{brain}-{n}-cc3d.npy")
+                return np.lib.format.open_memmap(made["path"], mode="w+", dtype=_label_dtype(n), shape=tuple(bin_img.shape))
+
+            N, stats = ccl_streamed(eng, bin_img, int(n_slabs), os.path.join(path_out, f".{brain}-provisional-u32.tmp"), create_output)
+            with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
+                pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
+            return N, stats
         if not cached:
             print("No cached brain found, performing connected components on the GPU...")
             mask_dev = eng.to_device(np.ascontiguousarray(bin_img))

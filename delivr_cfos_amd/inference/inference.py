@@ -123,8 +123,6 @@ def run_inference(
     stack_shape = tuple(int(v) for v in stack_shape)
     pad = (1, 1) + padded_shape(stack_shape[2:], crop_size)
     dataset_host = np.memmap(niftis[0], dtype=np.uint16, mode="r", shape=pad, offset=128)
-    if not sharded:
-        dataset = eng.upload_volume(dataset_host[0, 0])  # chunked through pinned staging buffers
     if rank == 0:
         os.makedirs(os.path.join(output_folder, comment), exist_ok=True)
     save_activated = bool(settings and settings.get("FLAGS", {}).get("SAVE_ACTIVATED_OUTPUT"))
@@ -133,8 +131,36 @@ def run_inference(
     # 0.5 (reference: mean = sum / count before the sigmoid, inference.py:295); at 0.5 the sign of the sum decides.
     need_count = save_activated or float(threshold) != 0.5
     cm_dtype = torch.float32 if gaussian else torch.uint8
-    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device) if not sharded else None
-    count_map = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device) if (need_count and not sharded) else None
+    # Does the volume fit this GPU?  The reference streams through memmaps and has no size limit (:240-247, :285-299); the
+    # resident path needs volume + fp32 sums (+ count map) + the finalize maps in HBM.  Beyond the budget
+    # (settings["mi355x"]["hbm_budget_gb"], default: what the device reports free) the slabs of the shard plan run one
+    # after another on this device (streaming.py); MemoryError when not even that fits.
+    stream_plan = None
+    if not sharded:
+        from ..streaming import forward_workspace_bytes, hbm_budget_bytes, inference_bytes_per_voxel, plan_slabs
+
+        budget = hbm_budget_bytes(eng, settings)
+        bpv = inference_bytes_per_voxel(need_count, gaussian, save_activated)
+        fixed = forward_workspace_bytes(crop_size, precision)
+        pad_vox = int(pad[2]) * int(pad[3]) * int(pad[4])
+        forced = int((settings or {}).get("mi355x", {}).get("stream_slabs", 0) or 0)  # explicit: exactly this many slabs
+        if forced > 0:
+            from ..parallel import plan_from_params
+
+            p_all = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
+            stream_plan, n_slabs = plan_from_params(p_all, forced, None), forced
+            print(f"settings['mi355x']['stream_slabs'] = {forced}: streaming {n_slabs} Z-slabs through the device")
+        elif pad_vox * bpv + fixed > budget:
+            p_all = eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision)
+            stream_plan, n_slabs = plan_slabs(eng, p_all, int(stack_shape[2]), int(pad[3]) * int(pad[4]), bpv, fixed, budget,
+                                              arrayterator_zblock(tuple(stack_shape[2:])))
+            print(f"volume of {pad_vox * bpv / 2**30:.1f} GiB (+ {fixed / 2**30:.1f} GiB workspace) exceeds the HBM budget of "
+                  f"{budget / 2**30:.1f} GiB: streaming {n_slabs} Z-slabs through the device")
+    resident = not sharded and stream_plan is None
+    if resident:
+        dataset = eng.upload_volume(dataset_host[0, 0])  # chunked through pinned staging buffers
+    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device) if resident else None
+    count_map = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device) if (need_count and resident) else None
     if need_count and cm_dtype == torch.uint8:
         # uint8 like the reference's LOAD_ALL_RAM map (:241): refuse geometries whose multiplicity cannot be held
         from ..hostlogic import max_window_multiplicity
@@ -153,7 +179,30 @@ def run_inference(
 
     # inference passes (reference :261-279)
     print(f"{datetime.datetime.now()} : Starting inference")
-    if not sharded:
+    if stream_plan is not None:
+        from ..streaming import run_inference_streamed
+
+        os.makedirs(binaries_path, exist_ok=True)
+        Z, Y, X = stack_shape[2:]
+        out_mask = np.lib.format.open_memmap(output_file, mode="w+", dtype=np.uint8, shape=(Z, Y, X))
+        out_prob = np.lib.format.open_memmap(network_output_file, mode="w+", dtype=np.float32, shape=(Z, Y, X)) if save_activated else None
+        args = (eng, dataset_host[0, 0], tuple(pad[2:]), (Z, Y, X), crop_size, overlap, bool(tta))
+        kw = dict(threshold=threshold, need_count=need_count, gaussian=gaussian, plan=stream_plan, out_mask=out_mask, out_prob=out_prob,
+                  verbose=bool(verbosity))
+        try:
+            run_inference_streamed(*args, precision=precision, **kw)
+        except DelivrHipError as e:
+            if e.code != DLV_ERANGE or precision != "fp16":
+                raise
+            print(f"WARNING: {e}\nWARNING: repeating the inference passes with bf16 operands")
+            precision = "bf16"
+            run_inference_streamed(*args, precision=precision, **kw)
+        print(f"{datetime.datetime.now()} : Creating binarized blob output")
+        out_mask.flush()
+        if out_prob is not None:
+            out_prob.flush()
+        del out_mask, out_prob
+    elif not sharded:
         def run_passes():
             for flip_dim, repeat in pass_schedule(bool(tta)):
                 kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
@@ -184,7 +233,6 @@ def run_inference(
                          network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
                          count_map=count_map, engine=eng)
     else:
-        from ..hostlogic import arrayterator_zblock
         from ..parallel import balanced_plan, exchange_seams, finalize_owned, gather_slabs
 
         # Slab-resident: every rank reads, uploads and accumulates only the planes of ITS Z-slab (its windows' planes and

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY, and usable ONLY in the build container (it reads /root/reference,
 which does not exist on the GPU box).  It is used by ``oracle/make_goldens.py`` to produce
-the committed fixtures under ``tests/golden/`` and by ``tests/test_oracle_vs_reference.py``
+the committed fixtures under ``tests/golden/`` and by ``tests/test_oracle_golden.py``
 (skipped automatically when /root/reference is absent).
 
 The stubs restate the six MONAI 1.2.0 helpers the reference imports (monai==1.2.0 is pinned at
