@@ -148,6 +148,9 @@ conv3_zwino_kernel(const uint4* __restrict__ in1, const uint4* __restrict__ wpk,
     u32x4 pre[C::NIT];
     const long long plane_b = (long long)plane * 16;
     auto load_piece = [&](int p, int it) __attribute__((always_inline)) {
+#ifdef ZW_DIAG
+        if (dbg & 4) return;
+#endif
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src + (long long)p * plane_b), 0, (int)plane_b, 0x00020000);
         pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[it], 0, 0);
     };
@@ -252,6 +255,9 @@ conv3_zwino_kernel(const uint4* __restrict__ in1, const uint4* __restrict__ wpk,
             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
             const u32x4 u = {s0[0], s1[0], s0[1], s1[1]};
             if constexpr (INT) {
+#ifdef ZW_DIAG  // timing-only diagnostics (wrong results): dbg bit 1 = no output stores, bit 2 = no global loads
+                if (!(dbg & 2))
+#endif
                 __builtin_amdgcn_raw_buffer_store_b128(u, ors, (int)ooff, (int)((unsigned)(oz * plane + r * W) * 16u), 0);
             } else {
                 char* const real = obase + ((long long)oz * plane + (long long)r * W) * 16 + ooff;

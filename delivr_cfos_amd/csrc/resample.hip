@@ -10,6 +10,8 @@
 // All HBM-bound: one coalesced pass over z-major slabs, X contiguous.
 #include <cstdlib>
 
+#include <cmath>
+
 #include "common.h"
 
 // Every resampler below is bit-exact against numpy / scipy arithmetic: no a*b+c may become an fma (HIP's default for device
@@ -270,6 +272,188 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_run16_kernel(const uint8_
     }
 }
 
+// The same values once more, organised by OUTPUT ROWS: one workgroup per (z, group of ZR_ROWS consecutive y).  What the run16
+// kernel re-derives per run - the tap range of the run along x (16 fp64 centre evaluations) and the comparison of up to
+// 9 x 8 input bytes - is hoisted: the tap ranges depend on x only (zoom_run_table_kernel, once per call), and whether the
+// nine input rows (3 kz x 3 ky) agree is decided per INPUT COLUMN once per distinct (cz, cy) of the group (`colval`: the
+// common value, or 0x100).  A run is uniform when colval is one valid value over its tap range: a few LDS reads and one
+// 16-byte store; the runs of all rows that share a centre row are spread over the 256 threads.  Runs at the mask's edge
+// are queued and evaluated afterwards, one output voxel per lane, with the arithmetic of the kernels above (bit-exact vs
+// scipy), screened by an fp32 evaluation that decides every voxel whose value is not within 4e-3 of a rounding tie.
+constexpr int ZR_ROWS = 32;
+__global__ void __launch_bounds__(256) zoom_run_table_kernel(short2* __restrict__ runk, int ix, int ox, double scx) {
+    const int runs = (ox + 15) / 16;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < runs; r += gridDim.x * blockDim.x) {
+        const int x0 = r * 16, nx = min(16, ox - x0);
+        int kmin = ix, kmax = -1;
+        for (int j = 0; j < nx; ++j) {
+            const int ci = spline2_centre(x0 + j, scx);
+#pragma unroll
+            for (int t = -1; t <= 1; ++t) {
+                const int k = mirror1(ci + t, ix);
+                kmin = min(kmin, k);
+                kmax = max(kmax, k);
+            }
+        }
+        runk[r] = make_short2((short)kmin, (short)kmax);
+    }
+}
+
+// weights and (mirrored) tap indices of output index i: spline2_taps with the centre / mirror helpers (same values)
+__device__ __forceinline__ Taps spline2_taps_m(int i, int n_in, double scale) {
+    Taps t;
+    const double x = __dmul_rn((double)i, scale);
+    const double c = floor(__dadd_rn(x, 0.5));
+    const double d = __dsub_rn(x, c);
+    const double w1 = __dsub_rn(0.75, __dmul_rn(d, d));
+    const double y = __dsub_rn(0.5, d);
+    const double w0 = __dmul_rn(__dmul_rn(0.5, y), y);
+    t.w[0] = w0;
+    t.w[1] = w1;
+    t.w[2] = __dsub_rn(__dsub_rn(1.0, w0), w1);
+    const int ci = (int)c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t.k[j] = mirror1(ci + j - 1, n_in);
+    return t;
+}
+
+// the fp32 screening form: centre from the fp64 coordinate (the same centre as the exact path), weights in fp32
+struct Taps32 {
+    int k[3];
+    float w[3];
+};
+__device__ __forceinline__ Taps32 spline2_taps32(int i, int n_in, double scale) {
+    Taps32 t;
+    const double x = __dmul_rn((double)i, scale);
+    const double c = floor(__dadd_rn(x, 0.5));
+    const float d = (float)__dsub_rn(x, c);
+    const float y = 0.5f - d, u = 0.5f + d;
+    t.w[0] = 0.5f * y * y;
+    t.w[1] = 0.75f - d * d;
+    t.w[2] = 0.5f * u * u;
+    const int ci = (int)c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t.k[j] = mirror1(ci + j - 1, n_in);
+    return t;
+}
+
+__global__ void __launch_bounds__(256) zoom_spline2_u8_rows_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
+                                                                   uint8_t* __restrict__ out, int oz, int oy, int ox, ZoomScales sc,
+                                                                   int aligned, const short2* __restrict__ runk, int nrows_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zr_smem[];
+    const int runs = (ox + 15) / 16;
+    unsigned short* colval = reinterpret_cast<unsigned short*>(zr_smem);                                       // [ix]
+    int* queue = reinterpret_cast<int*>(zr_smem + (((size_t)ix * 2 + 15) & ~(size_t)15));                      // [ZR_ROWS * runs]
+    short2* runl = reinterpret_cast<short2*>(queue + (size_t)ZR_ROWS * runs);    // [runs]: the tap ranges, from the table
+    uint8_t* tile = reinterpret_cast<uint8_t*>(runl + runs);  // [3 kz][nrows][ix]: the input rows the group's taps touch
+    __shared__ int qn;
+    const int ygroups = (oy + ZR_ROWS - 1) / ZR_ROWS;
+    const int z = blockIdx.x / ygroups, y0 = (blockIdx.x % ygroups) * ZR_ROWS;
+    const int y1 = min(y0 + ZR_ROWS, oy);
+    const int tid = threadIdx.x;
+    if (tid == 0) qn = 0;
+    int kz[3];
+    const int cz = spline2_centre(z, sc.z);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) kz[t] = mirror1(cz + t - 1, iz);
+    // the input rows (unmirrored index cy0 - 1 .. cyN + 1, three kz planes) the taps of this group's rows can touch: the
+    // edge voxels read their 27 inputs from LDS (27 scattered byte loads per voxel from global memory were the bottleneck)
+    const int cy0 = spline2_centre(y0, sc.y) - 1;
+    const int nrows = min(spline2_centre(y1 - 1, sc.y) + 1 - cy0 + 1, nrows_max);
+    for (int r = tid; r < runs; r += 256) runl[r] = runk[r];
+    for (int row = 0; row < 3 * nrows; ++row) {
+        const int a = row / nrows, rr = row - a * nrows;  // (workgroup-uniform)
+        const uint8_t* src = in + ((long long)kz[a] * iy + mirror1(cy0 + rr, iy)) * ix;
+        for (int k = tid; k < ix; k += 256) tile[(size_t)row * ix + k] = src[k];
+    }
+    for (int ya = y0; ya < y1;) {  // segments of rows with one centre row cy (workgroup-uniform)
+        const int cy = spline2_centre(ya, sc.y);
+        int yb = ya + 1;
+        while (yb < y1 && spline2_centre(yb, sc.y) == cy) ++yb;
+        const int lr = cy - 1 - cy0;  // local row of ky tap 0
+        __syncthreads();  // the tile is staged / the previous segment's readers are done with colval
+        for (int k = tid; k < ix; k += 256) {
+            const unsigned v0 = tile[(size_t)lr * ix + k];
+            bool same = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) same = same && (tile[((size_t)a * nrows + lr + b) * ix + k] == v0);
+            colval[k] = (unsigned short)(same ? v0 : 0x100u);
+        }
+        __syncthreads();
+        const int nitem = (yb - ya) * runs;
+        for (int it = tid; it < nitem; it += 256) {
+            const int yy = it / runs, r = it - yy * runs;
+            const short2 kk = runl[r];
+            const unsigned c = colval[kk.x];
+            bool uniform = c < 0x100u;
+            for (int k = kk.x + 1; k <= kk.y; ++k) uniform = uniform && (colval[k] == c);
+            if (uniform) {
+                uint8_t* const dst = out + ((long long)z * oy + ya + yy) * ox + r * 16;
+                if (aligned) {
+                    const unsigned w = c * 0x01010101u;
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(w, w, w, w);
+                } else {
+                    const int nx = min(16, ox - r * 16);
+                    for (int j = 0; j < nx; ++j) dst[j] = (uint8_t)c;
+                }
+            } else {
+                queue[atomicAdd(&qn, 1)] = ((ya + yy - y0) << 16) | r;
+            }
+        }
+        ya = yb;
+    }
+    __syncthreads();
+    // the queued runs (mask edges): 16 at a time, one output voxel per lane
+    const int nq = qn;
+    const int slot = tid >> 4, j = tid & 15;
+    for (int q0 = 0; q0 < nq; q0 += 16) {
+        const int qi = q0 + slot;
+        if (qi >= nq) continue;
+        const int e = queue[qi];
+        const int y = y0 + (e >> 16), x = (e & 0xffff) * 16 + j;
+        if (x >= ox) continue;
+        // fp32 first: the same centres (fp64, exact), weights and sum in fp32 (error < 2e-3 for uint8 inputs).  Unless
+        // t + 1/2 lands within 4e-3 of an integer the truncation is decided - identical to the fp64 evaluation; the few
+        // voxels near a tie (about one per crossing of the mask's edge) take the exact path below.
+        const Taps32 fz = spline2_taps32(z, iz, sc.z), fy = spline2_taps32(y, iy, sc.y), fx = spline2_taps32(x, ix, sc.x);
+        const int lrow = spline2_centre(y, sc.y) - 1 - cy0;  // local row of tap b = 0
+        float tf = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const uint8_t* rowp = tile + ((size_t)a * nrows + lrow + b) * ix;
+                const float p = fz.w[a] * fy.w[b];
+                tf = fmaf((float)rowp[fx.k[0]] * p, fx.w[0], tf);
+                tf = fmaf((float)rowp[fx.k[1]] * p, fx.w[1], tf);
+                tf = fmaf((float)rowp[fx.k[2]] * p, fx.w[2], tf);
+            }
+        const float sf = tf + 0.5f, rf = floorf(sf), fr = sf - rf;
+        if (fr > 4e-3f && fr < 1.f - 4e-3f) {
+            out[((long long)z * oy + y) * ox + x] = (uint8_t)fminf(fmaxf(rf, 0.f), 255.f);
+            continue;
+        }
+        const Taps tz = spline2_taps_m(z, iz, sc.z), ty = spline2_taps_m(y, iy, sc.y), tx = spline2_taps_m(x, ix, sc.x);
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const uint8_t* rowp = tile + ((size_t)a * nrows + lrow + b) * ix;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double val = (double)rowp[tx.k[c]];
+                    t = t + ((val * tz.w[a]) * ty.w[b]) * tx.w[c];
+                }
+            }
+        double rr = t > 0.0 ? t + 0.5 : 0.0;  // scipy CASE_INTERP_OUT_UINT
+        rr = rr > 255.0 ? 255.0 : rr;
+        out[((long long)z * oy + y) * ox + x] = (uint8_t)rr;
+    }
+}
+
 __global__ void __launch_bounds__(256) mask_pad_u16_kernel(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ mask,
                                                            int threshold, int Z, int Y, int X, uint16_t* __restrict__ out,
                                                            int Zp, int Yp, int Xp) {
@@ -396,9 +580,25 @@ int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy,
     if (getenv("DLV_RESAMPLE_SIMPLE"))  // the one-voxel-per-thread kernel (A/B and cross-check in tests)
         hipLaunchKernelGGL(zoom_spline2_u8_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev,
                            iz, iy, ix, out_dev, oz, oy, ox, sc);
-    else
-        hipLaunchKernelGGL(zoom_spline2_u8_run16_kernel, dim3(grid_for((long long)oz * oy * ((ox + 15) / 16))), dim3(256), 0,
-                           ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox, sc);
+    else {
+        // row-organised kernel whenever its tables fit LDS and 16-bit indices (always, for the pipeline's masks); the
+        // run-per-thread kernel otherwise (DLV_RESAMPLE_RUN16: A/B and cross-check in tests)
+        const int runs = (ox + 15) / 16;
+        const int nrows_max = (int)std::ceil((ZR_ROWS - 1) * sc.y) + 4;  // centre rows of a group's first and last output row, +-1, +1
+        const size_t lds = (((size_t)ix * 2 + 15) & ~(size_t)15) + (size_t)ZR_ROWS * runs * 4 + (size_t)runs * 4 + (size_t)3 * nrows_max * ix;
+        const long long groups = (long long)oz * ((oy + ZR_ROWS - 1) / ZR_ROWS);
+        if (ix <= 32767 && runs <= 32767 && lds <= 60 * 1024 && groups < (1ll << 31) && !getenv("DLV_RESAMPLE_RUN16")) {
+            const int aligned = (ox % 16 == 0) && ((reinterpret_cast<unsigned long long>(out_dev) & 15ull) == 0);
+            short2* runk;
+            DLV_TRY(dlv_ws_get(ctx, WS_MISC, (size_t)runs * sizeof(short2), (void**)&runk));
+            hipLaunchKernelGGL(zoom_run_table_kernel, dim3((runs + 255) / 256), dim3(256), 0, ctx->stream, runk, ix, ox, sc.x);
+            hipLaunchKernelGGL(zoom_spline2_u8_rows_kernel, dim3((unsigned)groups), dim3(256), lds, ctx->stream, in_dev, iz, iy, ix,
+                               out_dev, oz, oy, ox, sc, aligned, runk, nrows_max);
+        } else {
+            hipLaunchKernelGGL(zoom_spline2_u8_run16_kernel, dim3(grid_for((long long)oz * oy * ((ox + 15) / 16))), dim3(256), 0,
+                               ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox, sc);
+        }
+    }
     p.end();
     DLV_LAUNCH_CHECK(ctx, "zoom_spline2_u8_kernel");
     return DLV_OK;

@@ -427,3 +427,22 @@ def test_window_maxima_one_pass_and_general_path_vs_numpy(eng):
             z1 = int(wins[lo:hi, 0].max()) + d
             q = eng.make_sw_params(shape, roi, ov, None, 0, "fp16", win_range=(lo, hi), slab=(z0, z1 - z0))
             np.testing.assert_array_equal(eng.window_max(q, v[z0:z1].contiguous()), want[lo:hi])
+
+
+@pytest.mark.parametrize("in_shape,out_shape", [((12, 20, 24), (48, 300, 352)), ((9, 14, 30), (33, 207, 451)), ((255, 9, 137), (1024, 130, 2048))])
+def test_zoom_kernels_agree_bitwise(eng, in_shape, out_shape, monkeypatch):
+    """The three zoom kernels - row-organised (default), run-per-thread (DLV_RESAMPLE_RUN16), one voxel per thread
+    (DLV_RESAMPLE_SIMPLE) - on the same blobby mask incl. the production zoom factors (4, 15, 15) along a 2048-voxel row."""
+    rng = np.random.default_rng(in_shape[2])
+    m = (rng.random(in_shape) < 0.5).astype(np.uint8)
+    m[:, : in_shape[1] // 2] = 1
+    m[: in_shape[0] // 3, :, : in_shape[2] // 2] = 0
+    src = eng.to_device(m)
+    rows = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+    monkeypatch.setenv("DLV_RESAMPLE_RUN16", "1")
+    run16 = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+    monkeypatch.delenv("DLV_RESAMPLE_RUN16")
+    monkeypatch.setenv("DLV_RESAMPLE_SIMPLE", "1")
+    simple = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+    assert np.array_equal(rows, simple) and np.array_equal(run16, simple)
+    assert 0 < int(rows.sum()) < rows.size
