@@ -67,26 +67,60 @@ __device__ __forceinline__ unsigned mask_bits16(const uint8_t* __restrict__ mask
 
 // parents of the foreground voxels only (the background entries of L are never read: 17 GB of writes less on a
 // 2^32-voxel volume)
+// ... and the BIT MASK of the volume (one uint16 per 16 voxels): the only pass that reads the byte mask.  Every later
+// kernel scans 1/8 byte per voxel instead of 1 (five scans: 6 -> 1.6 bytes per voxel on top of the 4 of the labels).
 __global__ void __launch_bounds__(256) ccl_init_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n,
-                                                       bool aligned) {
+                                                       bool aligned, unsigned short* __restrict__ bm, u32* __restrict__ list,
+                                                       u32* __restrict__ list_n) {
+    // A workgroup owns a contiguous range of chunks.  The chunks that hold foreground are collected in LDS and appended to
+    // the global list with ONE atomic per flush (a per-wave atomic on the single counter serialised: 11 ms); the order of
+    // the list is whatever the flushes give - the unions do not depend on it.  The union / compress / relabel kernels
+    // then run over the list with every lane busy instead of a few per wave.
+    constexpr int CAP = 2048;
+    __shared__ u32 buf[CAP];
+    __shared__ u32 fill, gbase;
     const u64 nch = (n + 15) / 16;
-    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
-        unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+    const int lane = threadIdx.x & 63;
+    const u64 per = ((nch + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const u64 cb = (u64)blockIdx.x * per, ce = min(cb + per, nch);
+    if (threadIdx.x == 0) fill = 0;
+    __syncthreads();
+    auto flush = [&]() {  // (called by the whole workgroup)
+        __syncthreads();
+        const u32 cnt = fill;
+        if (threadIdx.x == 0 && cnt) gbase = atomicAdd(list_n, cnt);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < cnt; i += 256) list[gbase + i] = buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) fill = 0;
+        __syncthreads();
+    };
+    for (u64 c0 = cb; c0 < ce; c0 += 256) {  // (workgroup-uniform trip count)
+        const u64 c = c0 + threadIdx.x;
+        unsigned bits = c < ce ? mask_bits16(mask, c * 16, n, aligned) : 0u;
+        if (c < ce) bm[c] = (unsigned short)bits;
+        const unsigned long long hit = __ballot(bits != 0u);
+        if (hit) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&fill, (u32)__popcll(hit));
+            base = __shfl(base, 0, 64);
+            if (bits) buf[base + (u32)__popcll(hit & ((1ull << lane) - 1ull))] = (u32)c;
+        }
         while (bits) {
             const int k = __ffs((int)bits) - 1;
             bits &= bits - 1;
             L[c * 16 + k] = (u32)(c * 16 + k);
         }
+        __syncthreads();
+        if (fill > CAP - 256) flush();  // (uniform: every thread reads the same value behind the barrier)
     }
+    flush();
 }
 
 // one thread per 16 consecutive voxels (linear index; a chunk may straddle rows): for every foreground voxel the
 // 13 neighbours that precede it in raster order
-__global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, int Z,
-                                                        int Y, int X, u64 n, bool aligned) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c * 16 >= n) return;
-    unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+__device__ __forceinline__ void ccl_merge_chunk(const unsigned short* __restrict__ bm, u32* __restrict__ L, int Y, int X, u64 c) {
+    unsigned bits = bm[c];
     while (bits) {
         const int k = __ffs((int)bits) - 1;
         bits &= bits - 1;
@@ -106,7 +140,7 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restric
                     const int xx = x + dx;
                     if (xx < 0 || xx >= X) continue;
                     const u64 j = ((u64)zz * Y + yy) * X + xx;
-                    if (mask[j]) uf_union(L, (u32)i, (u32)j);
+                    if ((bm[j >> 4] >> (j & 15)) & 1u) uf_union(L, (u32)i, (u32)j);
                 }
             }
         }
@@ -120,25 +154,21 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restric
 // else the diagonal ones (x-1, x+1) that are.  (x-1, x, x+1) of one row are chained by that row's own left-neighbour
 // unions, so the centre stands for all three: the components are the same, with a third of the find/atomicMin traffic and
 // no per-voxel byte loads.
-__global__ void __launch_bounds__(256) ccl_merge_rows_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, int Z, int Y,
-                                                             int X, u64 n) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c * 16 >= n) return;
-    unsigned bits = mask_bits16(mask, c * 16, n, true);
-    if (!bits) return;
+__device__ __forceinline__ void ccl_merge_rows_chunk(const unsigned short* __restrict__ bm, u32* __restrict__ L, int Y, int X, u64 c,
+                                                     unsigned bits) {
     const int cpr = X / 16;  // chunks per row
     const int x0 = (int)(c % (u64)cpr) * 16;
     const u64 row = c / (u64)cpr;
     const int y = (int)(row % (u64)Y), z = (int)(row / (u64)Y);
     // 18-bit window of a row around this chunk: bit k+1 <-> voxel x0 + k, bit 0 <-> x0 - 1, bit 17 <-> x0 + 16
-    auto window = [&](u64 rbase, unsigned inner) -> unsigned {  // rbase = linear index of (row, x0)
-        unsigned w = inner << 1;
-        if (x0 > 0 && mask[rbase - 1]) w |= 1u;
-        if (x0 + 16 < X && mask[rbase + 16]) w |= 1u << 17;
+    auto window = [&](u64 cch) -> unsigned {  // cch = chunk index of (row, x0): its 16 bits, the last of the chunk before, the first of the one after
+        unsigned w = (unsigned)bm[cch] << 1;
+        if (x0 > 0) w |= (unsigned)bm[cch - 1] >> 15;
+        if (x0 + 16 < X) w |= ((unsigned)bm[cch + 1] & 1u) << 17;
         return w;
     };
     const u64 base = c * 16;
-    const unsigned cur = (bits << 1) | ((x0 > 0 && mask[base - 1]) ? 1u : 0u);
+    const unsigned cur = (bits << 1) | (x0 > 0 ? (unsigned)bm[c - 1] >> 15 : 0u);
     u64 nbase[4];
     unsigned nwin[4];
     const int dzs[4] = {-1, -1, -1, 0}, dys[4] = {-1, 0, 1, -1};
@@ -149,10 +179,7 @@ __global__ void __launch_bounds__(256) ccl_merge_rows_kernel(const uint8_t* __re
         nbase[r] = 0;
         if (zz >= 0 && yy >= 0 && yy < Y) {
             nbase[r] = ((u64)zz * Y + yy) * X + x0;
-            const uint4 u = *reinterpret_cast<const uint4*>(mask + nbase[r]);
-            unsigned inner = 0;
-            if (u.x | u.y | u.z | u.w) inner = mask_bits16(mask, nbase[r], n, true);
-            nwin[r] = window(nbase[r], inner);
+            nwin[r] = window(nbase[r] >> 4);
         }
     }
     while (bits) {
@@ -175,11 +202,24 @@ __global__ void __launch_bounds__(256) ccl_merge_rows_kernel(const uint8_t* __re
     }
 }
 
-__global__ void __launch_bounds__(256) ccl_compress_kernel(const uint8_t* __restrict__ mask, u32* __restrict__ L, u64 n,
-                                                           bool aligned) {
-    const u64 nch = (n + 15) / 16;
-    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
-        unsigned bits = mask_bits16(mask, c * 16, n, aligned);
+// one thread per listed (= foreground) chunk; ROWS: the row-window form above (X % 16 == 0), else the per-voxel form
+template <bool ROWS>
+__global__ void __launch_bounds__(256) ccl_merge_list_kernel(const unsigned short* __restrict__ bm, u32* __restrict__ L, int Y, int X,
+                                                             const u32* __restrict__ list, const u32* __restrict__ list_n) {
+    const u32 cnt = *list_n;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += gridDim.x * blockDim.x) {
+        const u64 c = list[t];
+        if (ROWS) ccl_merge_rows_chunk(bm, L, Y, X, c, bm[c]);
+        else ccl_merge_chunk(bm, L, Y, X, c);
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_compress_kernel(const unsigned short* __restrict__ bm, u32* __restrict__ L,
+                                                           const u32* __restrict__ list, const u32* __restrict__ list_n) {
+    const u32 cnt = *list_n;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += gridDim.x * blockDim.x) {
+        const u64 c = list[t];
+        unsigned bits = bm[c];
         while (bits) {
             const int k = __ffs((int)bits) - 1;
             bits &= bits - 1;
@@ -211,11 +251,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
     return base + incl - v;
 }
 
-__global__ void __launch_bounds__(256) ccl_count_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
-                                                              u64 n, u32* __restrict__ counts, bool aligned) {
+__global__ void __launch_bounds__(256) ccl_count_roots_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L,
+                                                              u64 n, u32* __restrict__ counts) {
     const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
     int c = 0;
-    unsigned bits = base < n ? mask_bits16(mask, base, n, aligned) : 0u;
+    unsigned bits = base < n ? (unsigned)bm[base >> 4] : 0u;
     while (bits) {
         const int k = __ffs((int)bits) - 1;
         bits &= bits - 1;
@@ -226,13 +266,25 @@ __global__ void __launch_bounds__(256) ccl_count_roots_kernel(const uint8_t* __r
     if (threadIdx.x == 0) counts[blockIdx.x] = (u32)total;
 }
 
-// single-block exclusive scan of the per-chunk root counts; counts[nb] receives the total
-__global__ void __launch_bounds__(1024) ccl_scan_counts_kernel(u32* __restrict__ counts, u64 nb) {
+// exclusive scan of the per-chunk root counts in three coalesced steps (a single block walking 500 k counts with one
+// strided stream per thread took 0.9 ms of a 9 ms labelling): sums of 1024-count groups, a one-block scan of the group sums
+// (counts[nb] receives the total), then every group scans its own counts
+constexpr int SGRP = 1024;
+__global__ void __launch_bounds__(256) ccl_scan_sums_kernel(const u32* __restrict__ counts, u64 nb, u32* __restrict__ gsum) {
+    const u64 g0 = (u64)blockIdx.x * SGRP;
+    u32 s = 0;
+    for (int i = threadIdx.x; i < SGRP; i += 256)
+        if (g0 + i < nb) s += counts[g0 + i];
+    int total;
+    block_excl_scan((int)s, &total);
+    if (threadIdx.x == 0) gsum[blockIdx.x] = (u32)total;
+}
+__global__ void __launch_bounds__(1024) ccl_scan_groups_kernel(u32* __restrict__ gsum, u64 ng, u32* __restrict__ total_out) {
     __shared__ u64 part[1024];
-    const u64 per = (nb + 1023) / 1024;
-    const u64 b0 = min((u64)threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+    const u64 per = (ng + 1023) / 1024;
+    const u64 b0 = min((u64)threadIdx.x * per, ng), b1 = min(b0 + per, ng);
     u64 s = 0;
-    for (u64 i = b0; i < b1; ++i) s += counts[i];
+    for (u64 i = b0; i < b1; ++i) s += gsum[i];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -242,24 +294,43 @@ __global__ void __launch_bounds__(1024) ccl_scan_counts_kernel(u32* __restrict__
             part[k] = run;
             run += v;
         }
-        counts[nb] = (u32)run;  // N <= 2^32-1 by construction (labels are uint32)
+        *total_out = (u32)run;  // N <= 2^32-1 by construction (labels are uint32)
     }
     __syncthreads();
     u64 run = part[threadIdx.x];
     for (u64 i = b0; i < b1; ++i) {
-        const u32 v = counts[i];
-        counts[i] = (u32)run;
+        const u32 v = gsum[i];
+        gsum[i] = (u32)run;
         run += v;
     }
 }
+__global__ void __launch_bounds__(256) ccl_scan_apply_kernel(u32* __restrict__ counts, u64 nb, const u32* __restrict__ gsum) {
+    const u64 g0 = (u64)blockIdx.x * SGRP;
+    u32 v[SGRP / 256];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < SGRP / 256; ++k) {  // thread t owns the 4 consecutive counts 4t .. 4t+3 of the group
+        const u64 i = g0 + (u64)threadIdx.x * (SGRP / 256) + k;
+        v[k] = i < nb ? counts[i] : 0u;
+        mine += (int)v[k];
+    }
+    int total;
+    u32 run = gsum[blockIdx.x] + (u32)block_excl_scan(mine, &total);
+#pragma unroll
+    for (int k = 0; k < SGRP / 256; ++k) {
+        const u64 i = g0 + (u64)threadIdx.x * (SGRP / 256) + k;
+        if (i < nb) counts[i] = run;
+        run += v[k];
+    }
+}
 
-__global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
+__global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L,
                                                                u64 n, const u32* __restrict__ offsets,
-                                                               u32* __restrict__ labels, bool aligned) {
+                                                               u32* __restrict__ labels) {
     const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
     int c = 0;
     unsigned roots = 0;
-    unsigned bits = base < n ? mask_bits16(mask, base, n, aligned) : 0u;
+    unsigned bits = base < n ? (unsigned)bm[base >> 4] : 0u;
     while (bits) {
         const int k = __ffs((int)bits) - 1;
         bits &= bits - 1;
@@ -279,12 +350,12 @@ __global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const uint8_t* __
 
 // every voxel of the label volume is written exactly once here (16 voxels = four 16-byte stores per thread): 0 for the
 // background, the root's label for the rest (roots already hold theirs)
-__global__ void __launch_bounds__(256) ccl_relabel_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L,
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L,
                                                           u64 n, u32* __restrict__ labels, bool aligned) {
     const u64 nch = (n + 15) / 16;
     for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
         const u64 base = c * 16;
-        const unsigned bits = mask_bits16(mask, base, n, aligned);
+        const unsigned bits = bm[c];
         u32 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -304,10 +375,34 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const uint8_t* __restr
     }
 }
 
+// The label volume was zeroed (hipMemsetAsync: the fill runs at 6.9 TB/s); only the listed chunks are written
+__global__ void __launch_bounds__(256) ccl_relabel_list_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L, u64 n,
+                                                               u32* __restrict__ labels, const u32* __restrict__ list,
+                                                               const u32* __restrict__ list_n, bool aligned) {
+    const u32 cnt = *list_n;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += gridDim.x * blockDim.x) {
+        const u64 c = list[t], base = c * 16;
+        const unsigned bits = bm[c];
+        u32 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = 0;
+            if (bits & (1u << k)) v[k] = labels[L[base + k]];  // (a root reads its own label: assigned by ccl_assign_roots_kernel)
+        }
+        if (aligned && base + 16 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(labels + base + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        } else {
+            for (int k = 0; k < 16 && base + k < n; ++k) labels[base + k] = v[k];
+        }
+    }
+}
+
 // The same label volume with whole-line stores: a wave owns 1024 consecutive voxels and writes them with four store
 // instructions of 64 x 16 contiguous bytes (the kernel above gives every lane 64 contiguous bytes, i.e. four instructions that
 // each touch a quarter of 64 lines).  Needs the 16-byte alignment; the last partial block is written voxel by voxel.
-__global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const uint8_t* __restrict__ mask, const u32* __restrict__ L, u64 n,
+__global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L, u64 n,
                                                                 u32* __restrict__ labels) {
     const int lane = threadIdx.x & 63;
     const u64 nblk = n / 1024;
@@ -317,19 +412,19 @@ __global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const uint8_t* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u64 o = base + (u64)q * 256 + (u64)lane * 4;
-            const unsigned m = *reinterpret_cast<const unsigned*>(mask + o);
+            const unsigned m = ((unsigned)bm[o >> 4] >> (o & 15)) & 15u;  // this lane's four voxels (four lanes share a word)
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (m) {
-                if (m & 0x000000ffu) v.x = labels[L[o]];  // a root's label was assigned by ccl_assign_roots_kernel (L[r] == r)
-                if (m & 0x0000ff00u) v.y = labels[L[o + 1]];
-                if (m & 0x00ff0000u) v.z = labels[L[o + 2]];
-                if (m & 0xff000000u) v.w = labels[L[o + 3]];
+                if (m & 1u) v.x = labels[L[o]];  // a root's label was assigned by ccl_assign_roots_kernel (L[r] == r)
+                if (m & 2u) v.y = labels[L[o + 1]];
+                if (m & 4u) v.z = labels[L[o + 2]];
+                if (m & 8u) v.w = labels[L[o + 3]];
             }
             *reinterpret_cast<uint4*>(labels + o) = v;
         }
     }
     if (wave0 == 0)
-        for (u64 i = nblk * 1024 + lane; i < n; i += 64) labels[i] = mask[i] ? labels[L[i]] : 0u;
+        for (u64 i = nblk * 1024 + lane; i < n; i += 64) labels[i] = ((bm[i >> 4] >> (i & 15)) & 1u) ? labels[L[i]] : 0u;
 }
 
 // ---- statistics -------------------------------------------------------------------------------------
@@ -348,41 +443,49 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
 __global__ void __launch_bounds__(256) cc_stats_kernel(const u32* __restrict__ labels, int Z, int Y, int X,
                                                        u32* __restrict__ counts, u64* __restrict__ sums,
                                                        u32* __restrict__ bbmin, u32* __restrict__ bbmax) {
+    // a workgroup walks whole rows (z, y): no per-thread 64-bit division, 16-byte loads when the rows allow it; the trip
+    // counts are workgroup-uniform so that the shuffles below are convergent
     const int segs = (X + SPT - 1) / SPT;
-    const u64 nitems = (u64)Z * Y * segs;
     const int lane = threadIdx.x & 63;
     u32 bmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, bmax[3] = {0, 0, 0};
     bool any_bg = false;
-    // wave-uniform trip count so that the shuffles below are convergent
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    const u64 first = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 rounds = (nitems + stride - 1) / stride;
-    for (u64 rd = 0; rd < rounds; ++rd) {
-        const u64 it = first + rd * stride;
-        const bool in_range = it < nitems;
+    const bool vec = (X % SPT == 0) && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0);
+    const u64 nrows = (u64)Z * Y;
+    const int sweeps = (segs + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (u64 row = blockIdx.x; row < nrows; row += gridDim.x)
+    for (int sw = 0; sw < sweeps; ++sw) {
+        const int sg = sw * (int)blockDim.x + (int)threadIdx.x;
+        const bool in_range = sg < segs;
         u32 l[SPT];
-        u32 z = 0, y = 0, x0 = 0;
+        const u32 z = (u32)(row / (u64)Y), y = (u32)(row % (u64)Y), x0 = (u32)sg * SPT;
         if (in_range) {
-            const u32 sg = (u32)(it % segs);
-            y = (u32)((it / segs) % Y);
-            z = (u32)(it / ((u64)segs * Y));
-            x0 = sg * SPT;
-            const u64 base = ((u64)z * Y + y) * X + x0;
+            const u64 base = row * (u64)X + x0;
+            if (vec) {
+                const uint4 u0 = *reinterpret_cast<const uint4*>(labels + base), u1 = *reinterpret_cast<const uint4*>(labels + base + 4);
+                l[0] = u0.x; l[1] = u0.y; l[2] = u0.z; l[3] = u0.w;
+                l[4] = u1.x; l[5] = u1.y; l[6] = u1.z; l[7] = u1.w;
+            } else {
 #pragma unroll
-            for (int k = 0; k < SPT; ++k) l[k] = (x0 + k < (u32)X) ? labels[base + k] : 0xffffffffu;  // pad = "no voxel"
+                for (int k = 0; k < SPT; ++k) l[k] = (x0 + k < (u32)X) ? labels[base + k] : 0xffffffffu;  // pad = "no voxel"
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < SPT; ++k) l[k] = 0xffffffffu;
         }
-        // background bookkeeping
+        // background bookkeeping: the thread's zero voxels as a bit mask, first / last of them along x
+        unsigned zm = 0, fgm = 0;
 #pragma unroll
-        for (int k = 0; k < SPT; ++k)
-            if (l[k] == 0) {
-                any_bg = true;
-                bmin[0] = min(bmin[0], z); bmax[0] = max(bmax[0], z);
-                bmin[1] = min(bmin[1], y); bmax[1] = max(bmax[1], y);
-                bmin[2] = min(bmin[2], x0 + k); bmax[2] = max(bmax[2], x0 + k);
-            }
+        for (int k = 0; k < SPT; ++k) {
+            zm |= (l[k] == 0 ? 1u : 0u) << k;
+            fgm |= ((l[k] != 0 && l[k] != 0xffffffffu) ? 1u : 0u) << k;
+        }
+        if (zm) {
+            any_bg = true;
+            bmin[0] = min(bmin[0], z); bmax[0] = max(bmax[0], z);
+            bmin[1] = min(bmin[1], y); bmax[1] = max(bmax[1], y);
+            bmin[2] = min(bmin[2], x0 + (u32)__ffs((int)zm) - 1u); bmax[2] = max(bmax[2], x0 + 31u - (u32)__clz((int)zm));
+        }
+        if (!__any(fgm != 0)) continue;  // (wave-uniform) nothing but background in this wave's 512 voxels
         // runs of equal foreground labels inside the thread's voxels, one run per pass of the loop below
         int k = 0;
         while (true) {
@@ -527,37 +630,53 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     const u64 nb = (n + RCHUNK - 1) / RCHUNK;
     char* ws;
     const size_t parent_bytes = (size_t)n * 4;
-    DLV_TRY(dlv_ws_get(ctx, WS_CCL, parent_bytes + (size_t)(nb + 1) * 4 + 256, (void**)&ws));
-    u32* L = (u32*)ws;
-    u32* counts = (u32*)(ws + ((parent_bytes + 255) & ~(size_t)255));
     const u64 nch = (n + 15) / 16;
+    const size_t counts_off = (parent_bytes + 255) & ~(size_t)255;
+    const size_t gsum_off = (counts_off + (size_t)(nb + 1) * 4 + 255) & ~(size_t)255;
+    const size_t bm_off = (gsum_off + (size_t)((nb + SGRP - 1) / SGRP + 1) * 4 + 255) & ~(size_t)255;
+    const size_t list_off = (bm_off + (size_t)(nch + 4) * 2 + 255) & ~(size_t)255;  // [list_n, pad, list[nch]]
+    DLV_TRY(dlv_ws_get(ctx, WS_CCL, list_off + 256 + (size_t)nch * 4 + 256, (void**)&ws));
+    u32* list_n = (u32*)(ws + list_off);
+    u32* list = (u32*)(ws + list_off + 256);
+    u32* L = (u32*)ws;
+    u32* counts = (u32*)(ws + counts_off);
+    u32* gsum = (u32*)(ws + gsum_off);
+    unsigned short* bm = (unsigned short*)(ws + bm_off);  // bit mask of the volume, one word per 16 voxels (ccl_init_kernel)
     const int gs = (int)std::min<u64>((nch + 255) / 256, (u64)256 * 64);
     // 16-byte accesses need the mask 16-byte and the labels 16-byte aligned (hipMalloc / torch allocations are)
     const bool aligned = ((reinterpret_cast<uintptr_t>(mask_dev) | reinterpret_cast<uintptr_t>(labels_dev)) & 15) == 0;
-    // algorithmic bytes: the mask is scanned by 6 kernels (1 B each), the labels are written once (4 B)
-    DlvProf pr(ctx, "ccl26", 0.0, (double)n * (6 + 4));
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned);
+    // bytes: the byte mask is read once (1 B), its bit mask written once and scanned by five kernels (6/8 B), the labels are
+    // written once (4 B)
+    DlvProf pr(ctx, "ccl26", 0.0, (double)n * (1 + 0.75 + 4));
+    static const bool simple = getenv("DLV_CCL_SIMPLE") != nullptr;  // A/B: whole-volume relabel stores instead of memset + list
+    DLV_HIP(ctx, hipMemsetAsync(list_n, 0, 4, ctx->stream));
+    if (!simple) DLV_HIP(ctx, hipMemsetAsync(labels_dev, 0, (size_t)n * 4, ctx->stream));
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned, bm, list, list_n);
     DLV_LAUNCH_CHECK(ctx, "ccl_init_kernel");
-    static const bool simple = getenv("DLV_CCL_SIMPLE") != nullptr;  // A/B: the per-voxel merge and the per-lane relabel stores
-    if (aligned && X % 16 == 0 && !simple)
-        hipLaunchKernelGGL(ccl_merge_rows_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, ctx->stream, mask_dev, L, Z, Y, X, n);
+    const int gl = 256 * 16;  // list kernels: grid-stride over the device-side count
+    if (aligned && X % 16 == 0)
+        hipLaunchKernelGGL(ccl_merge_list_kernel<true>, dim3(gl), dim3(256), 0, ctx->stream, bm, L, Y, X, list, list_n);
     else
-        hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, ctx->stream, mask_dev, L, Z, Y, X, n, aligned);
+        hipLaunchKernelGGL(ccl_merge_list_kernel<false>, dim3(gl), dim3(256), 0, ctx->stream, bm, L, Y, X, list, list_n);
     DLV_LAUNCH_CHECK(ctx, "ccl_merge_kernel");
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned);
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(gl), dim3(256), 0, ctx->stream, bm, L, list, list_n);
     DLV_LAUNCH_CHECK(ctx, "ccl_compress_kernel");
-    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts, aligned);
+    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, bm, L, n, counts);
     DLV_LAUNCH_CHECK(ctx, "ccl_count_roots_kernel");
-    hipLaunchKernelGGL(ccl_scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, nb);
+    const u64 ng = (nb + SGRP - 1) / SGRP;
+    hipLaunchKernelGGL(ccl_scan_sums_kernel, dim3((unsigned)ng), dim3(256), 0, ctx->stream, counts, nb, gsum);
+    hipLaunchKernelGGL(ccl_scan_groups_kernel, dim3(1), dim3(1024), 0, ctx->stream, gsum, ng, counts + nb);
+    hipLaunchKernelGGL(ccl_scan_apply_kernel, dim3((unsigned)ng), dim3(256), 0, ctx->stream, counts, nb, gsum);
     DLV_LAUNCH_CHECK(ctx, "ccl_scan_counts_kernel");
-    hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mask_dev, L, n, counts,
-                       labels_dev, aligned);
+    hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, bm, L, n, counts, labels_dev);
     DLV_LAUNCH_CHECK(ctx, "ccl_assign_roots_kernel");
-    if (aligned && !simple)
+    if (!simple)
+        hipLaunchKernelGGL(ccl_relabel_list_kernel, dim3(gl), dim3(256), 0, ctx->stream, bm, L, n, labels_dev, list, list_n, aligned);
+    else if (aligned)
         hipLaunchKernelGGL(ccl_relabel_lines_kernel, dim3((unsigned)std::min<u64>((n / 1024 + 3) / 4 + 1, (u64)256 * 32)), dim3(256), 0,
-                           ctx->stream, mask_dev, L, n, labels_dev);
+                           ctx->stream, bm, L, n, labels_dev);
     else
-        hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, labels_dev, aligned);
+        hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, bm, L, n, labels_dev, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_relabel_kernel");
     pr.end();
     u32 total = 0;
