@@ -190,6 +190,61 @@ __global__ void __launch_bounds__(256) erode_z_final_kernel(uint8_t* __restrict_
     }
 }
 
+// The same decision in ONE sweep along z (radius <= 31): the forward scan f(j) = min(d(j), f(j-1) + 1) alone decides, because
+// plane j removes exactly the planes z in [j - (radius - f(j)), j] (b(z) = min_k f(z+k) + k <= radius).  Every column keeps a
+// 32-bit shift register of "removed" flags for the `radius` + 1 planes that are still pending; the output plane lags the
+// distance plane by `radius` planes.  Reads the (x, y) distance once, the sums once, writes the mask once: 6 B per voxel
+// instead of 8, and the distance map is not rewritten.
+template <int V>
+__global__ void __launch_bounds__(256) erode_z_shift_kernel(const uint8_t* __restrict__ dist, const float* __restrict__ acc,
+                                                            const uint8_t* __restrict__ cnt, int Yp, int Xp, int Z,
+                                                            int Y, int X, int zblock, int zphase, int radius, float threshold,
+                                                            uint8_t* __restrict__ out, float* __restrict__ prob) {
+    const int xv = X / V;
+    const long long per_block = (long long)Y * xv;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = (Z + zphase + zblock - 1) / zblock;
+    if (t >= per_block * nblk) return;
+    const int blk = (int)(t / per_block);
+    const long long r = t % per_block;
+    const int x = (int)(r % xv) * V, y = (int)(r / xv);
+    const int zb0 = max(blk * zblock - zphase, 0), zb1 = min((blk + 1) * zblock - zphase, Z);
+    const long long plane = (long long)Y * X;
+    const uint8_t* col = dist + (long long)y * X + x;
+    unsigned f = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) f |= (unsigned)(radius + 1) << (8 * k);  // outside the block: foreground
+    unsigned kill[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) kill[k] = 0u;
+    for (int j = zb0; j < zb1 + radius; ++j) {
+        if (j < zb1) {
+            f = minplus1<V>(U8V<V>::ld(col + j * plane), f);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const unsigned fk = (f >> (8 * k)) & 0xffu;
+                if (fk <= (unsigned)radius) kill[k] |= (0xffffffffu >> (31 - (radius - (int)fk))) << fk;  // bits [fk, radius]
+            }
+        }
+        const int z = j - radius;
+        if (z >= zb0) {
+            unsigned res = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const long long po = ((long long)z * Yp + y) * Xp + x + k;
+                float m = acc[po];
+                if (cnt) m = m / (float)cnt[po];  // 0/0 -> NaN -> background, as in the reference
+                const float pr = 1.0f / (1.0f + expf(-m));
+                if (prob) prob[(long long)z * plane + (long long)y * X + x + k] = pr;
+                res |= ((pr >= threshold && !(kill[k] & 1u)) ? 1u : 0u) << (8 * k);
+            }
+            U8V<V>::st(out + (long long)z * plane + (long long)y * X + x, res);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) kill[k] >>= 1;
+    }
+}
+
 }  // namespace
 
 static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_dev, const uint16_t* raw_dev, int Yp, int Xp, int Z,
@@ -249,14 +304,25 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
     {
         const int nblk = (int)(((long long)Z + zphase + zblock - 1) / zblock);
         DlvProf p(ctx, "erode_z_final", 0.0, (4.0 + 4.0 + 1.0) * nvox);
-        if (v4)
+        static const bool two_sweeps = getenv("DLV_ERODE_Z_TWO_SWEEPS") != nullptr;  // A/B + cross-check in tests
+        if (erode_iters <= 31 && !two_sweeps) {  // one sweep with a shift register per column (the reference's 30 iterations)
+            if (v4)
+                hipLaunchKernelGGL(erode_z_shift_kernel<4>, dim3(dlv_cdiv((long long)nblk * Y * (X / 4), 256)), dim3(256), 0,
+                                   ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
+                                   out_dev, prob_dev);
+            else
+                hipLaunchKernelGGL(erode_z_shift_kernel<1>, dim3(dlv_cdiv((long long)nblk * Y * X, 256)), dim3(256), 0,
+                                   ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
+                                   out_dev, prob_dev);
+        } else if (v4) {
             hipLaunchKernelGGL(erode_z_final_kernel<4>, dim3(dlv_cdiv((long long)nblk * Y * (X / 4), 256)), dim3(256), 0,
                                ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
                                out_dev, prob_dev);
-        else
+        } else {
             hipLaunchKernelGGL(erode_z_final_kernel<1>, dim3(dlv_cdiv((long long)nblk * Y * X, 256)), dim3(256), 0,
                                ctx->stream, dist, acc_dev, cnt_dev, Yp, Xp, Z, Y, X, zblock, zphase, erode_iters, threshold,
                                out_dev, prob_dev);
+        }
         p.end();
         DLV_LAUNCH_CHECK(ctx, "erode_z_final_kernel");
     }
