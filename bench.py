@@ -467,11 +467,10 @@ def main():
         # guide prescribes).  The passes ran the 512^3 workload (25k launches of C3 under PMC exceed the time limit): same
         # kernels, same batch of 16 windows per launch; a launch of another batch is scaled by algorithmic bytes.
         try:
-            tfile = os.path.join(ROOT, "profiles", f"traffic_r03_{args.workload}.json")
-            scaled = False
-            if not os.path.isfile(tfile):
-                tfile = os.path.join(ROOT, "profiles", "traffic_r03_c2.json")
-                scaled = True
+            # (newest round first: the PMC passes are regenerated at the end of every round, profiles/run_r04.sh)
+            cands = [(f"traffic_{r}_{args.workload}.json", False) for r in ("r04", "r03")] + [(f"traffic_{r}_c2.json", True) for r in ("r04", "r03")]
+            tfile, scaled = next(((os.path.join(ROOT, "profiles", n), sc) for n, sc in cands if os.path.isfile(os.path.join(ROOT, "profiles", n))),
+                                 (os.path.join(ROOT, "profiles", "traffic_r03_c2.json"), True))
             if os.path.isfile(tfile) and args.sw_batch == 0:
                 tj = json.load(open(tfile))
                 if name in tj["kernels"] and tj.get("precision") == args.precision:

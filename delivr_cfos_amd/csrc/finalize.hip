@@ -9,6 +9,9 @@
 // transform: X by log-step min-plus doubling in LDS, Y and Z by forward/backward scans.  The
 // reference erodes per Arrayterator z-block (inference.py:53); `zblock` carries that block size.
 #include "common.h"
+#ifndef ZXY_PFR
+#define ZXY_PFR 1
+#endif
 
 namespace {
 
@@ -190,6 +193,148 @@ __global__ void __launch_bounds__(256) erode_z_final_kernel(uint8_t* __restrict_
     }
 }
 
+// X and Y distances fused: one workgroup per plane z marches down y.  Per row: the raw row -> zero-voxel bit mask in LDS
+// (double-buffered: one barrier per row) -> the x distance of the thread's 8 voxels by the count-leading / trailing-zeros trick
+// of erode_x_bits_kernel -> forward y scan against the carried previous row -> 8-byte store; then the backward y scan in
+// place.  The x distance never goes to HBM: raw 2 B + dist 1 B (forward) + dist 1 + 1 B (backward) = 5 B per voxel instead
+// of 3 + 4.  NC = 8-voxel chunks per thread (X <= 2048 * NC); cap <= 57.
+template <int NC>
+__global__ void __launch_bounds__(256) erode_xy_kernel(const uint16_t* __restrict__ raw, int Yp, int Xp, int Y, int X, int cap,
+                                                       uint8_t* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nchunk = (X + 7) / 8;
+    const int mstride = ((nchunk + 24 + 7) / 8) * 8;  // bytes per mask buffer: 8 zero bytes, the mask, >= 16 zero bytes
+    const int z = blockIdx.x;
+    const bool vec = (Xp % 8 == 0) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+    const bool ovec = (X % 8 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 7) == 0);
+    for (int i = threadIdx.x; i < 2 * mstride / 8; i += 256) reinterpret_cast<unsigned long long*>(smem)[i] = 0ull;
+    __syncthreads();
+    unsigned long long prev[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) prev[q] = 0x0101010101010101ull * (unsigned long long)cap;  // above the volume: foreground
+    auto bits_of = [](const uint4& u) -> unsigned {
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m |= ((w[k] & 0xffffu) == 0u ? 1u : 0u) << (2 * k);
+            m |= ((w[k] >> 16) == 0u ? 1u : 0u) << (2 * k + 1);
+        }
+        return m;
+    };
+    auto row_load = [&](int y, int c) -> uint4 {  // the 8 voxels of chunk c of row y (a ragged or unaligned row: voxel by voxel)
+        const uint16_t* row = raw + ((long long)z * Yp + y) * Xp;
+        if (vec && 8 * c + 8 <= X) return *reinterpret_cast<const uint4*>(row + 8 * c);
+        unsigned w[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // beyond X: foreground
+        for (int k = 0; k < 8; ++k)
+            if (8 * c + k < X) w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | ((unsigned)row[8 * c + k] << (16 * (k & 1)));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    constexpr int PFR = ZXY_PFR;  // rows y + 1 .. y + PFR are in flight while row y is processed (4 measured slower than 1 or 2)
+    uint4 nxt[PFR][NC];
+#pragma unroll
+    for (int r = 0; r < PFR; ++r)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            nxt[r][q] = (c < nchunk && r < Y) ? row_load(r, c) : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+    auto minplus8 = [](unsigned long long cur, unsigned long long pv) -> unsigned long long {
+        return (unsigned long long)minplus1<4>((unsigned)cur, (unsigned)pv) |
+               ((unsigned long long)minplus1<4>((unsigned)(cur >> 32), (unsigned)(pv >> 32)) << 32);
+    };
+    for (int y0 = 0; y0 < Y; y0 += PFR) {
+#pragma unroll
+      for (int r = 0; r < PFR; ++r) {
+        const int y = y0 + r;
+        if (y >= Y) break;  // (workgroup-uniform)
+        unsigned char* zm = smem + (y & 1) * mstride + 8;
+        const unsigned long long* zm64 = reinterpret_cast<const unsigned long long*>(smem + (y & 1) * mstride);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c < nchunk) {
+                zm[c] = (unsigned char)bits_of(nxt[r][q]);
+                if (y + PFR < Y) nxt[r][q] = row_load(y + PFR, c);
+            }
+        }
+        __syncthreads();  // (the other buffer is rewritten only after the NEXT barrier: every reader of it has passed this one)
+        uint8_t* o = dist + ((long long)z * Y + y) * X;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c >= nchunk) continue;
+            const int off = c + 1;
+            const int a = off >> 3, sh = (off & 7) * 8;
+            const unsigned long long w0 = zm64[a], w1 = zm64[a + 1], w2 = zm64[a + 2];
+            const unsigned long long left = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+            const unsigned long long right = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+            const unsigned long long own = left >> 56;
+            const unsigned long long rwin = own | (right << 8);
+            unsigned long long dx = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned long long L = left & (~0ull >> (7 - k));
+                const unsigned long long R = rwin >> k;
+                int d = cap;
+                if (L) d = min(d, __clzll((long long)L) - (7 - k));
+                if (R) d = min(d, (int)__ffsll((long long)R) - 1);
+                dx |= (unsigned long long)(unsigned)d << (8 * k);
+            }
+            const unsigned long long fwd = minplus8(dx, prev[q]);
+            prev[q] = fwd;
+            if (ovec && 8 * c + 8 <= X) {
+                *reinterpret_cast<unsigned long long*>(o + 8 * c) = fwd;
+            } else {
+                for (int k = 0; k < 8 && 8 * c + k < X; ++k) o[8 * c + k] = (uint8_t)(fwd >> (8 * k));
+            }
+        }
+      }
+    }
+    // backward y scan (prev holds row Y-1), rows prefetched PFR ahead
+    if (ovec) {
+        unsigned long long bq[PFR][NC];
+#pragma unroll
+        for (int r = 0; r < PFR; ++r)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = threadIdx.x + 256 * q, y = Y - 2 - r;
+                bq[r][q] = (c < nchunk && y >= 0) ? *reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + y) * X + 8 * c) : 0ull;
+            }
+        for (int yb = Y - 2; yb >= 0; yb -= PFR) {
+#pragma unroll
+            for (int r = 0; r < PFR; ++r) {
+                const int y = yb - r;
+                if (y < 0) break;
+                uint8_t* o = dist + ((long long)z * Y + y) * X;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int c = threadIdx.x + 256 * q;
+                    if (c >= nchunk) continue;
+                    const unsigned long long cur = minplus8(bq[r][q], prev[q]);
+                    if (y - PFR >= 0) bq[r][q] = *reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + (y - PFR)) * X + 8 * c);
+                    prev[q] = cur;
+                    *reinterpret_cast<unsigned long long*>(o + 8 * c) = cur;
+                }
+            }
+        }
+        return;
+    }
+    for (int y = Y - 2; y >= 0; --y) {
+        uint8_t* o = dist + ((long long)z * Y + y) * X;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c >= nchunk) continue;
+            unsigned long long cur = 0;
+            for (int k = 0; k < 8; ++k) cur |= (unsigned long long)(8 * c + k < X ? o[8 * c + k] : cap) << (8 * k);
+            cur = minplus8(cur, prev[q]);
+            prev[q] = cur;
+            for (int k = 0; k < 8 && 8 * c + k < X; ++k) o[8 * c + k] = (uint8_t)(cur >> (8 * k));
+        }
+    }
+}
+
 // The same decision in ONE sweep along z (radius <= 31): the forward scan f(j) = min(d(j), f(j-1) + 1) alone decides, because
 // plane j removes exactly the planes z in [j - (radius - f(j)), j] (b(z) = min_k f(z+k) + k <= radius).  Every column keeps a
 // 32-bit shift register of "removed" flags for the `radius` + 1 planes that are still pending; the output plane lags the
@@ -217,31 +362,69 @@ __global__ void __launch_bounds__(256) erode_z_shift_kernel(const uint8_t* __res
     unsigned kill[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) kill[k] = 0u;
-    for (int j = zb0; j < zb1 + radius; ++j) {
-        if (j < zb1) {
-            f = minplus1<V>(U8V<V>::ld(col + j * plane), f);
+    // software pipeline: the distance word of plane j + PF and the sums of output plane z + PF are in flight while plane j /
+    // z is processed (without it every iteration exposes a full memory latency: 3.5 TB/s instead of ~5)
+    constexpr int PF = 4;
+    unsigned dq[PF];
+    float aq[PF][V];
+    unsigned cq[PF];  // count bytes (V <= 4 per word)
+    auto ld_dist = [&](int j) -> unsigned { return j < zb1 ? U8V<V>::ld(col + (long long)j * plane) : 0u; };
+    auto ld_acc = [&](int z, float (&a)[V], unsigned& c) {
+        c = 0u;
+        if (z >= zb0 && z < zb1) {
+            const long long po = ((long long)z * Yp + y) * Xp + x;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                const unsigned fk = (f >> (8 * k)) & 0xffu;
-                if (fk <= (unsigned)radius) kill[k] |= (0xffffffffu >> (31 - (radius - (int)fk))) << fk;  // bits [fk, radius]
+                a[k] = acc[po + k];
+                if (cnt) c |= (unsigned)cnt[po + k] << (8 * k);
             }
-        }
-        const int z = j - radius;
-        if (z >= zb0) {
-            unsigned res = 0;
+        } else {
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                const long long po = ((long long)z * Yp + y) * Xp + x + k;
-                float m = acc[po];
-                if (cnt) m = m / (float)cnt[po];  // 0/0 -> NaN -> background, as in the reference
-                const float pr = 1.0f / (1.0f + expf(-m));
-                if (prob) prob[(long long)z * plane + (long long)y * X + x + k] = pr;
-                res |= ((pr >= threshold && !(kill[k] & 1u)) ? 1u : 0u) << (8 * k);
+            for (int k = 0; k < V; ++k) a[k] = 0.f;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        dq[q] = ld_dist(zb0 + q);
+        ld_acc(zb0 - radius + q, aq[q], cq[q]);
+    }
+    const int jend = zb1 + radius;
+    for (int j0 = zb0; j0 < jend; j0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int j = j0 + q;
+            if (j >= jend) break;
+            const unsigned dcur = dq[q];
+            float acur[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) acur[k] = aq[q][k];
+            const unsigned ccur = cq[q];
+            dq[q] = ld_dist(j + PF);
+            ld_acc(j + PF - radius, aq[q], cq[q]);
+            if (j < zb1) {
+                f = minplus1<V>(dcur, f);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const unsigned fk = (f >> (8 * k)) & 0xffu;
+                    if (fk <= (unsigned)radius) kill[k] |= (0xffffffffu >> (31 - (radius - (int)fk))) << fk;  // bits [fk, radius]
+                }
             }
-            U8V<V>::st(out + (long long)z * plane + (long long)y * X + x, res);
-        }
+            const int z = j - radius;
+            if (z >= zb0) {
+                unsigned res = 0;
 #pragma unroll
-        for (int k = 0; k < V; ++k) kill[k] >>= 1;
+                for (int k = 0; k < V; ++k) {
+                    float m = acur[k];
+                    if (cnt) m = m / (float)((ccur >> (8 * k)) & 0xffu);  // 0/0 -> NaN -> background, as in the reference
+                    const float pr = 1.0f / (1.0f + expf(-m));
+                    if (prob) prob[(long long)z * plane + (long long)y * X + x + k] = pr;
+                    res |= ((pr >= threshold && !(kill[k] & 1u)) ? 1u : 0u) << (8 * k);
+                }
+                U8V<V>::st(out + (long long)z * plane + (long long)y * X + x, res);
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) kill[k] >>= 1;
+        }
     }
 }
 
@@ -278,6 +461,22 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
     uint8_t* dist;
     const long long nvox = (long long)Z * Y * X;
     DLV_TRY(dlv_ws_get(ctx, WS_ERODE, (size_t)nvox, (void**)&dist));
+    const bool v4 = (X % 4 == 0);
+    static const bool split_xy = getenv("DLV_ERODE_XY_SPLIT") != nullptr;  // A/B + cross-check in tests: separate x and y passes
+    const int nchunk8 = (X + 7) / 8;
+    if (cap <= 57 && nchunk8 <= 1024 && !split_xy) {
+        // x and y fused: the x distance never reaches HBM
+        DlvProf p(ctx, "erode_xy_u8", 0.0, 5.0 * nvox);
+        const size_t lds = 2 * (size_t)(((nchunk8 + 24 + 7) / 8) * 8);
+        if (nchunk8 <= 256)
+            hipLaunchKernelGGL(erode_xy_kernel<1>, dim3((unsigned)Z), dim3(256), lds, ctx->stream, raw_dev, Yp, Xp, Y, X, cap, dist);
+        else if (nchunk8 <= 512)
+            hipLaunchKernelGGL(erode_xy_kernel<2>, dim3((unsigned)Z), dim3(256), lds, ctx->stream, raw_dev, Yp, Xp, Y, X, cap, dist);
+        else
+            hipLaunchKernelGGL(erode_xy_kernel<4>, dim3((unsigned)Z), dim3(256), lds, ctx->stream, raw_dev, Yp, Xp, Y, X, cap, dist);
+        p.end();
+        DLV_LAUNCH_CHECK(ctx, "erode_xy_kernel");
+    } else {
     {
         DlvProf p(ctx, "erode_x_u8", 0.0, 3.0 * nvox);
         if (cap <= 57)
@@ -289,7 +488,6 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
         p.end();
         DLV_LAUNCH_CHECK(ctx, "erode_x_kernel");
     }
-    const bool v4 = (X % 4 == 0);
     {
         DlvProf p(ctx, "erode_y_u8", 0.0, 4.0 * nvox);
         if (v4)
@@ -300,6 +498,7 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
                                Z, Y, X);
         p.end();
         DLV_LAUNCH_CHECK(ctx, "erode_y_kernel");
+    }
     }
     {
         const int nblk = (int)(((long long)Z + zphase + zblock - 1) / zblock);
