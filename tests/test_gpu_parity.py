@@ -446,3 +446,56 @@ def test_zoom_kernels_agree_bitwise(eng, in_shape, out_shape, monkeypatch):
     simple = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
     assert np.array_equal(rows, simple) and np.array_equal(run16, simple)
     assert 0 < int(rows.sum()) < rows.size
+
+
+_FINALIZE_SNIPPET = """
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from delivr_cfos_amd.engine import HipEngine
+from delivr_cfos_amd.synth import synth_volume_np
+eng = HipEngine(0)
+shape = (70, 90, int(sys.argv[3]))
+vol = synth_volume_np(shape, seed=5, dense=True)
+vol[:, :7] = 0
+vol[20:50, 30:60, 25:70] = 0
+rng = np.random.default_rng(1)
+acc = rng.normal(0.2, 1.0, size=shape).astype(np.float32)
+v, a = eng.to_device(vol), eng.to_device(acc)
+out = {}
+for er in (2, 7, 30):
+    for nb in (0, 24):
+        out[f"m_{er}_{nb}"] = eng.finalize(a, None, v, shape, 0.5, er, nb).cpu().numpy()
+cells = (vol > 3200).astype(np.uint8)
+lab, n = eng.ccl26(eng.to_device(cells))
+out["labels"] = lab.cpu().numpy()
+out["n"] = np.int64(n)
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.parametrize("X", [96, 100])
+def test_finalize_and_ccl_kernel_switches_give_identical_results(tmp_path, X):
+    """The A/B switches of round 4 select kernels, never results: fused x+y distance pass vs separate passes
+    (DLV_ERODE_XY_SPLIT), one-sweep z decision vs forward + backward sweeps (DLV_ERODE_Z_TWO_SWEEPS), zero fill + listed
+    chunks vs whole-volume label stores (DLV_CCL_SIMPLE) - erosion radii 2 / 7 / 30, with and without z-blocks, rows that
+    are / are not multiples of 8.  One process per setting (the switches are read once)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env):
+        out = str(tmp_path / ("r_" + "_".join(env) + ".npz"))
+        e = dict(os.environ)
+        e.update({k: "1" for k in env})
+        subprocess.check_call([sys.executable, "-c", _FINALIZE_SNIPPET, root, out, str(X)], env=e, timeout=600)
+        return np.load(out)
+
+    base = run(())
+    assert base["m_30_0"].any() and int(base["n"]) > 10
+    for env in (("DLV_ERODE_XY_SPLIT",), ("DLV_ERODE_Z_TWO_SWEEPS",), ("DLV_ERODE_XY_SPLIT", "DLV_ERODE_Z_TWO_SWEEPS"), ("DLV_CCL_SIMPLE",)):
+        other = run(env)
+        for k in base.files:
+            assert np.array_equal(other[k], base[k]), (env, k)
