@@ -91,6 +91,13 @@ int dlv_split_prepare(dlv_ctx* ctx, int nlanes) {
         ctx->split_built = m;
         return DLV_OK;
     }
+    // the masks below address 8 XCDs x 32 CUs ("bit b = CU b/8 of XCD b%8"): refuse any other part / partition mode
+    // instead of silently selecting the wrong CUs
+    hipDeviceProp_t prop;
+    DLV_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (prop.multiProcessorCount != 256 || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return dlv_fail(ctx, DLV_EUNSUP, "CU split: written for gfx950 with 256 CUs in 8 XCDs; this device is %s with %d CUs", prop.gcnArchName,
+                        prop.multiProcessorCount);
     auto masked = [&](int cu_lo, int cu_hi, hipStream_t* out) -> int {
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int b = 8 * cu_lo; b < 8 * cu_hi; ++b) mask[b / 32] |= 1u << (b % 32);

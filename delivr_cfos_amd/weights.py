@@ -54,8 +54,20 @@ def random_state_dict(seed: int = 0, features: Sequence[int] = FEATURES, module_
     return sd
 
 
-TRAINED_LIKE_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                                    "trained_like_weights.npz")
+def _find_trained_like_fixture() -> str:
+    """The trained-like checkpoint is TEST DATA (tests/golden/, regenerable with oracle/train_weights.py), not part of the
+    product; an installed package finds it through DLV_TRAINED_LIKE_FIXTURE or a copy under delivr_cfos_amd/data/.  Callers
+    that need it (bench.py --weights trained, tests) fail when it is absent - nothing falls back to other weights."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    cands = [os.environ.get("DLV_TRAINED_LIKE_FIXTURE"), os.path.join(here, "data", "trained_like_weights.npz"),
+             os.path.join(os.path.dirname(here), "tests", "golden", "trained_like_weights.npz")]
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return cands[-1]
+
+
+TRAINED_LIKE_FIXTURE = _find_trained_like_fixture()
 
 
 def trained_like_state_dict(fixture: Optional[str] = None, module_prefix: bool = True) -> Dict[str, "object"]:

@@ -350,7 +350,9 @@ typedef struct dlv_prof_entry {
 /* 1 = run batches back to back on the ctx stream; 2 .. 6 (default 3) = rotate consecutive batches over that many HIP
  * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
 int dlv_set_lanes(dlv_ctx* ctx, int lanes);
-/* CU split: spatial partition of the chip for dlv_sw_infer_dev's 16-bit path.  mem_cus_per_xcd = 0 (off): every kernel may
+/* EXPERIMENTAL / diagnostic: slower than the default pipeline in every measured configuration; gfx950 with
+ * 256 CUs in 8 XCDs only (DLV_EUNSUP on anything else).
+ * CU split: spatial partition of the chip for dlv_sw_infer_dev's 16-bit path.  mem_cus_per_xcd = 0 (off): every kernel may
  * use all 256 CUs.  1..31: the 3x3x3 convs of a forward run on the first 32 - m CUs of every XCD, its HBM-class kernels
  * (stem, InstanceNorm+Mish passes, transposed convs, final conv + blend) on the remaining m, on CU-masked streams
  * (hipExtStreamCreateWithCUMask) - the two kinds of work of neighbouring batches then run side by side instead of

@@ -63,6 +63,48 @@ def scan(raw_lines):
     return findings, n_mfma
 
 
+def scan_readback(raw_lines, min_states=12):
+    """The opposite hazard: a NON-MFMA instruction (v_accvgpr_read, a VALU operand, a store) that reads a register an asm MFMA
+    wrote fewer than `min_states` wait states earlier (an 8-pass XDL result needs ~11 before anything but an MFMA may read it;
+    every instruction in between counts as one state, s_nop N as N + 1).  -> findings [(line_mfma, mfma, line_reader, reader, states)]"""
+    lines = []
+    for i, l in enumerate(raw_lines):
+        t = l.split("//")[0].strip()
+        if t and not t.startswith((";", ".")) and not t.endswith(":"):
+            lines.append((i + 1, t))
+    findings = []
+    for idx, (ln, t) in enumerate(lines):
+        if not t.startswith("v_mfma"):
+            continue
+        dst = _regs(t.split(None, 1)[1].split(",")[0])
+        states = 0
+        for fwd in range(1, min_states + 1):
+            if idx + fwd >= len(lines):
+                break
+            pl, pt = lines[idx + fwd]
+            parts = pt.split(None, 1)
+            op = parts[0]
+            if op == "s_nop":
+                states += int(parts[1]) + 1
+            else:
+                if not op.startswith("v_mfma") and len(parts) > 1:
+                    ops = parts[1].split(",")
+                    # sources: every operand but the first of VALU / accvgpr instructions, every operand of stores
+                    srcs = ops if op.startswith(("ds_write", "buffer_store", "global_store", "flat_store")) else ops[1:]
+                    reads = set()
+                    for x in srcs:
+                        reads |= _regs(x)
+                    if reads & dst and states < min_states:
+                        findings.append((ln, t, pl, pt, states))
+                        break
+                if op.startswith("v_mfma") and _regs(parts[1].split(",")[0]) & dst:
+                    break  # rewritten by a later MFMA: that one is checked on its own
+                states += 1
+            if states >= min_states:
+                break
+    return findings
+
+
 def code_objects(lib_path, workdir):
     """gfx950 code objects inside the library's .hip_fatbin (one clang offload bundle per translation unit) -> file paths"""
     data = open(lib_path, "rb").read()
@@ -107,12 +149,14 @@ def _kernel_metadata(elf):
     return meta
 
 
-def library_report(lib_path, name_filter="conv3_zreg_kernel"):
+def library_report(lib_path, name_filter=("conv3_zreg_kernel", "conv3_zwino_kernel")):
+    if isinstance(name_filter, str):
+        name_filter = (name_filter,)
     rep = {}
     with tempfile.TemporaryDirectory() as wd:
         for elf in code_objects(lib_path, wd):
             syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "--wide", elf], capture_output=True, text=True).stdout
-            names = [l.split()[-1] for l in syms.split("\n") if name_filter in l and " FUNC " in l]
+            names = [l.split()[-1] for l in syms.split("\n") if any(nf in l for nf in name_filter) and " FUNC " in l]
             if not names:
                 continue
             meta = _kernel_metadata(elf)
@@ -128,7 +172,9 @@ def library_report(lib_path, name_filter="conv3_zreg_kernel"):
                     body[cur].append(line)
             for nm in names:
                 findings, n_mfma = scan(body.get(nm, []))
-                rep[nm] = {"hazards": len(findings), "first": findings[:3], "mfma": n_mfma, **meta.get(nm, {})}
+                back = scan_readback(body.get(nm, []))
+                rep[nm] = {"hazards": len(findings), "first": findings[:3], "mfma": n_mfma, "readback_hazards": len(back),
+                           "first_readback": back[:3], **meta.get(nm, {})}
     return rep
 
 

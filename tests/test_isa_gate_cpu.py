@@ -17,6 +17,28 @@ def _tool():
     return mod
 
 
+def _need_tools():
+    import pytest
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.isfile(os.path.join(llvm, "llvm-readelf")) and os.path.isfile(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("ROCm LLVM tools (llvm-readelf / llvm-objdump) are not installed on this host")
+    if not os.path.isfile(LIB):
+        pytest.skip("libdelivr_hip.so is not built (make -C delivr_cfos_amd/csrc)")
+
+
+def test_scanner_finds_a_planted_readback_hazard():
+    hs = _tool()
+    mf = "v_mfma_f32_16x16x32_f16 a[0:3], a[10:13], v[4:7], a[0:3]"
+    planted = [mf, "v_add_u32 v9, v9, v9", "v_accvgpr_read_b32 v20, a1"]
+    padded = [mf, "s_nop 7", "s_nop 3", "v_accvgpr_read_b32 v20, a1"]
+    other = [mf, "v_accvgpr_read_b32 v20, a9"]
+    chained = [mf, "v_mfma_f32_16x16x32_f16 a[0:3], a[14:17], v[4:7], a[0:3]"]
+    assert len(hs.scan_readback(planted)) == 1 and hs.scan_readback(planted)[0][4] == 1
+    assert hs.scan_readback(padded) == [] and hs.scan_readback(other) == [] and hs.scan_readback(chained) == []
+    assert len(hs.scan_readback(["v_mfma_f32_16x16x32_f16 v[0:3], a[10:13], v[4:7], v[0:3]", "buffer_store_dwordx4 v[0:3], v9, s[0:3], 0 offen"])) == 1
+
+
 def test_scanner_finds_a_planted_hazard():
     hs = _tool()
     clean = ["v_mov_b32 v5, v1", "s_nop 1", "v_mfma_f32_16x16x32_f16 a[0:3], a[10:13], v[4:7], a[0:3]"]
@@ -33,11 +55,21 @@ EXPECTED_MFMA = {("Li32E", "Li16E"): 2592, ("Li32E", "Li8E"): 1296, ("Li64E", "L
 
 
 def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd():
+    _need_tools()
     hs = _tool()
     rep = hs.library_report(LIB)
+    wino = {k: v for k, v in rep.items() if "zwino" in k}
+    rep = {k: v for k, v in rep.items() if "zwino" not in k}
     assert len(rep) == 10, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0; Cin 64: t8 a0/a1)
+    assert len(wino) == 1, sorted(wino)  # the opt-in Winograd F(2,3)-x variant: 36 weight fragments = 144 AGPRs
+    for name, r in wino.items():
+        assert r["hazards"] == 0 and r["readback_hazards"] == 0, (name, r["first"], r["first_readback"])
+        assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, name
+        assert 144 <= r["agpr_count"] < r["vgpr_count"] <= 512, (name, r["vgpr_count"], r["agpr_count"])
+        assert r["mfma"] == 864, (name, r["mfma"])  # 2 x 3 steps x 144
     for name, r in rep.items():
         assert r["hazards"] == 0, (name, r["first"])
+        assert r["readback_hazards"] == 0, (name, r["first_readback"])  # asm MFMA result read too early by non-MFMA code
         assert r.get("private_segment_fixed_size", 0) == 0, (name, "scratch")
         assert r.get("vgpr_spill_count", 0) == 0, name
         # unified register file: 512 per lane and SIMD; the metadata's vgpr_count is the unified total (arch VGPRs rounded up
