@@ -237,10 +237,13 @@ def p2p_selftest(dist, device, rank: int, world: int, nbytes: int = 64 << 20, gr
     recv = torch.zeros_like(send)
     stage = _needs_host_staging(send, dist)
     sbuf, rbuf = (send.cpu(), recv.cpu()) if stage else (send, recv)
-    ops = [dist.P2POp(dist.isend, sbuf, (rank + 1) % world, group=group), dist.P2POp(dist.irecv, rbuf, (rank - 1) % world, group=group)]
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    if not stage:
+    if world == 1 and dist.get_backend() != "nccl":
+        rbuf.copy_(sbuf)  # (gloo has no connection of a rank to itself; RCCL runs the grouped send / recv to self)
+    else:
+        ops = [dist.P2POp(dist.isend, sbuf, (rank + 1) % world, group=group), dist.P2POp(dist.irecv, rbuf, (rank - 1) % world, group=group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if not stage and send.is_cuda:
         torch.cuda.synchronize(device)
     want = base * 2654435761 + (rank - 1) % world
     if not torch.equal(rbuf.to(device), want):

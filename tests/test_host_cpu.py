@@ -513,3 +513,66 @@ def test_native_tiff_reader_survives_corrupt_files(tmp_path, golden_dir):
         fh.write(struct.pack("<I", 0))
     with pytest.raises(NotImplementedError):
         read_tiff_plane(p)
+
+
+def _gloo_round4_worker(rank, world, port, tmp):
+    """p2p self-test of the seam transport and the all-ranks error exchange of the sharded count_blobs (gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    from delivr_cfos_amd.count_blobs import _raise_if_any_failed
+    from delivr_cfos_amd.parallel import p2p_selftest
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p2p_selftest(dist, torch.device("cpu"), rank, world, 1 << 16)
+    _raise_if_any_failed(dist, None, "nothing")  # nobody failed: returns on every rank
+    try:
+        _raise_if_any_failed(dist, "rank 1: disk full" if rank == 1 else None, "writing the label slabs")
+        outcome = "no error"
+    except RuntimeError as e:
+        outcome = str(e)
+    with open(os.path.join(tmp, f"outcome_{rank}.txt"), "w") as fh:
+        fh.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_p2p_selftest_and_error_exchange_over_gloo(tmp_path, world):
+    """Round 4: (i) the ring exchange that bench.py / run_inference run before a multi-rank job delivers every word (at one
+    rank: to itself); (ii) a failure on ONE rank of the sharded count_blobs' file writes reaches EVERY rank as the same
+    error instead of leaving the others in a barrier."""
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_gloo_round4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [open(tmp_path / f"outcome_{r}.txt").read() for r in range(world)]
+    if world == 1:
+        assert outs == ["no error"]
+    else:
+        assert all("writing the label slabs failed: rank 1: disk full" in o for o in outs), outs
+
+
+def test_find_cached_returns_the_last_matching_entry_like_the_reference(tmp_path, monkeypatch):
+    """count_blobs.py:10-34 of the reference: the LAST directory entry (os.listdir order) that holds the suffix and the brain
+    name, False without a match - one helper now serves the three look-ups."""
+    from delivr_cfos_amd import count_blobs as cb
+
+    names = ["zz_other-3-cc3d.npy", "brainA-7-cc3d.npy", "brainA-stats.pickle", "brainA-9-cc3d.npy", "notes.txt"]
+    monkeypatch.setattr(cb.os, "listdir", lambda p: list(names))
+    settings = {"postprocessing": {"output_location": str(tmp_path)}}
+    assert cb.load_cached_brain(settings, "brainA") == os.path.join(str(tmp_path), "brainA-9-cc3d.npy")
+    assert cb.load_cached_stats(settings, "brainA") == os.path.join(str(tmp_path), "brainA-stats.pickle")
+    assert cb.load_cached_brain(settings, "brainB") is False
+
+
+def test_streaming_host_arithmetic():
+    from delivr_cfos_amd import streaming as st
+
+    assert st.even_slabs(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    assert st.inference_bytes_per_voxel(False, False, False) == 9 and st.inference_bytes_per_voxel(True, True, True) == 17
+    assert st.forward_workspace_bytes((128, 128, 128), "fp16") > 30 * 2**30  # 3 lanes x 2^25 patch voxels x 340 B
+    assert st.forward_workspace_bytes((32, 32, 32), "fp16") < 4 * 2**30
+    assert st.hbm_budget_bytes(None, {"mi355x": {"hbm_budget_gb": 1.5}}) == int(1.5 * 2**30)
