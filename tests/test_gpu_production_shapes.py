@@ -252,3 +252,21 @@ def test_mask_vs_reference_accumulate_arithmetic(eng, crop, tta):
         assert rep["iou"] >= REF_ARITH_TOL[prec], (prec, rep)
         if prec == "fp32":  # only voxels whose mean logit is at rounding level may differ
             assert rep["max_abs_mean_at_flip"] < 2e-3, rep
+
+
+
+@pytest.mark.xfail(strict=True, reason="bf16 (8 significant bits) does NOT meet the north_star tolerance (mask IoU >= 0.999 vs the "
+                                       "reference arithmetic) on the margin-free logits of seeded random weights: measured 0.998 / 0.9988. "
+                                       "It does on realistic logits (tests/test_gpu_trained_like.py: 0.9998); fp16 is the default format")
+@pytest.mark.parametrize("tta", [False, True], ids=["1pass", "13pass_tta"])
+def test_bf16_meets_the_north_star_tolerance_on_margin_free_logits(eng, crop, tta):
+    """The statement the suite makes about bf16 (BASELINE.json's configs name it): an EXPECTED failure, strict - should a
+    later build lift bf16 above 0.999 on this crop the test turns red until the claim is updated."""
+    from oracle.parity import flip_report, reference_arithmetic
+    from oracle import delivr_oracle as orc
+
+    ref = reference_arithmetic(orc, crop["vol"], ROI, crop["cache"], tta)
+    _acc, _cnt, mask = _hip_mask(eng, eng.to_device(crop["vol"]), "bf16", tta)
+    rep = flip_report(mask, ref["mask"], ref["mean"])
+    print(f"bf16 vs reference arithmetic ({'13 passes' if tta else '1 pass'}): IoU {rep['iou']:.5f}, {rep['flipped']} flipped voxels")
+    assert rep["iou"] >= 0.999, rep
