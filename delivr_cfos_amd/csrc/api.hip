@@ -238,7 +238,19 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         uint16_t* wb16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         uint16_t* wh16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         uint16_t* ww = (i > 0 && cin[i] == 32 && cout[i] % 32 == 0) ? (uint16_t*)take((size_t)cout[i] * cin[i] * 36 * 2) : nullptr;
+        // conv 16 = upcat_1.conv_0 when its inputs are a 32-channel skip + the 32 channels of a 32->32 transposed conv
+        const bool fold = (i == 16 && cin[i] == 64 && cout[i] == 32 && dcin[3] == 32 && dcout[3] == 32);
+        uint16_t* wsb = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
+        uint16_t* wsh = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
+        uint16_t* wub = fold ? (uint16_t*)take((size_t)2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
+        uint16_t* wuh = fold ? (uint16_t*)take((size_t)2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
+        float* ucr = fold ? (float*)take((size_t)8 * 8 * 32 * 4) : nullptr;
         if (base) {
+            ctx->conv[i].wskip_bf16 = wsb;
+            ctx->conv[i].wskip_f16 = wsh;
+            ctx->conv[i].wup_bf16 = wub;
+            ctx->conv[i].wup_f16 = wuh;
+            ctx->conv[i].up_corr = ucr;
             ctx->conv[i].wwino_f16 = ww;
             ctx->conv[i].w16_bf16 = wb16;
             ctx->conv[i].w16_f16 = wh16;
@@ -319,6 +331,9 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     if (const char* e = getenv("DLV_ZM_VARIANT")) ctx->zm_variant = atoi(e);
 #endif
     ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
+    ctx->upconv_simple = getenv("DLV_UPCONV_SIMPLE") ? 1 : 0;
+    ctx->upconv_dbg = getenv("DLV_UPCONV_DBG") ? atoi(getenv("DLV_UPCONV_DBG")) : 0;
+    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;        // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return DLV_EHIP;

@@ -5,6 +5,7 @@
 struct dlv_ctx;
 struct ZrArgs {
     const void *in1, *ss1, *in2, *ss2, *wpk16;
+    const void* addend = nullptr;  // ADD instantiations: 16-bit tensor in the layout of `out`, added before statistics and pack
     void* out;
     float* partials;
     char* trash;
@@ -25,3 +26,8 @@ ZR_DECLARE(dlv_zr_bf16_c32_t8_a1);
 ZR_DECLARE(dlv_zr_bf16_c32_t16_a0);
 ZR_DECLARE(dlv_zr_bf16_c64_t8_a0);
 ZR_DECLARE(dlv_zr_bf16_c64_t8_a1);
+// Cin 32 with an addend (the up half of an UpCat conv, upconv.hip)
+ZR_DECLARE(dlv_zr_f16_c32_t8_add);
+ZR_DECLARE(dlv_zr_f16_c32_t16_add);
+ZR_DECLARE(dlv_zr_bf16_c32_t8_add);
+ZR_DECLARE(dlv_zr_bf16_c32_t16_add);

@@ -345,7 +345,8 @@ np.save(sys.argv[2], acc.cpu().numpy())
 def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, prec):
     """Every environment switch the product library reads selects kernels, never results: the activation fused into the
     z-reg conv's staging (DLV_FUSE_LEVELS), edge-step code on every plane (DLV_ZREG_DBG), the LDS-weights z-march instead
-    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes.  The switches are read once
+    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes, upcat_1 unfolded
+    (DLV_NO_UPCONV) or folded with the one-tile kernel (DLV_UPCONV_SIMPLE).  The switches are read once
     per process, hence one process per setting; 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1)."""
     import os
     import subprocess
@@ -368,7 +369,7 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, p
     # same values up to the rounding of one 16-bit store (activation applied while staging: the activated tensor is never
     # rounded through HBM differently, but the InstanceNorm partial sums are taken over other tiles) / another kernel
     tol = 2e-3 if prec == "fp16" else 2e-2
-    for env in ({"DLV_FUSE_LEVELS": "1"}, {"DLV_FUSE_LEVELS": "3"}, {"DLV_ZREG_MASK": "0"}):
+    for env in ({"DLV_FUSE_LEVELS": "1"}, {"DLV_FUSE_LEVELS": "3"}, {"DLV_ZREG_MASK": "0"}, {"DLV_NO_UPCONV": "1"}, {"DLV_UPCONV_SIMPLE": "1"}):
         a = run(env)
         rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
         print(env, "rel rms vs default:", rel)
@@ -408,3 +409,70 @@ def test_conv_block_fp16_winograd(eng, net, li, D, H, W):
     assert err.mean() < 2e-3, float(err.mean())
     base = eng.debug_layer_bf16(0, li, x1.cuda(), None, precision="fp16").cpu()
     assert (out - base).abs().max() < 0.02
+
+
+# ---------------------------------------------------------------------------------------------------
+# upcat_1 folded: transposed conv + first conv = skip-half conv + 8-tap conv of the COARSE tensor (upconv.hip)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("roi,shape,kernel", [
+    ((64, 64, 64), (64, 64, 160), "upconv2m"),    # coarse 32^3: the persistent kernel; windows that overlap
+    ((48, 80, 96), (48, 80, 192), "upconv2m"),    # coarse 24 x 40 x 48: full tiles, not a cube
+    ((48, 48, 80), (48, 96, 80), "upconv2_"),     # coarse width 40: not a multiple of the 16-voxel tile -> the one-tile kernel
+    ((128, 128, 128), (128, 128, 128), "upconv2m"),
+])
+def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, shape, kernel):
+    """The folded path (default) must agree with the unfolded one (DLV_NO_UPCONV=1: ConvTranspose kernel + 64-channel conv) to
+    the rounding of the 16-bit format, both kernels of the folded path with each other, and each with the fp32 VALU path of
+    the library within the tolerance of the other 16-bit tests; the profile labels prove which kernel ran.  The switches are
+    read when a context is created."""
+    import os
+
+    import torch
+
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_np
+
+    engs = {}
+    try:
+        for tag, env in (("folded", {}), ("simple", {"DLV_UPCONV_SIMPLE": "1"}), ("unfolded", {"DLV_NO_UPCONV": "1"})):
+            for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            e = HipEngine(0)
+            e.load_state_dict({"state_dict": net.state_dict()})
+            engs[tag] = e
+    finally:
+        for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
+            os.environ.pop(k, None)
+    vol = synth_volume_np(shape, seed=13, dense=True)
+    dvol = engs["folded"].to_device(vol)
+    out, ran = {}, {}
+    for tag, p in (("fp32", "fp32"), ("folded", prec), ("simple", prec), ("unfolded", prec)):
+        e = engs["folded" if tag == "fp32" else tag]
+        acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        e.prof_reset()
+        e.prof_enable(True)
+        e.sw_infer(e.make_sw_params(shape, roi, 0.5, None, 0, p), dvol, acc)
+        e.sync()
+        e.prof_enable(False)
+        ran[tag] = [k for k, v in e.prof_report().items() if v["launches"]]
+        out[tag] = acc.cpu().numpy()
+    for e in engs.values():
+        e.close()
+    assert any(k.startswith(kernel) for k in ran["folded"]), ran["folded"]
+    assert any(k.startswith("upconv2_") for k in ran["simple"]) and not any(k.startswith("upconv2m") for k in ran["simple"]), ran["simple"]
+    assert not any(k.startswith("upconv") for k in ran["unfolded"]) and any(k.startswith("deconv2") for k in ran["unfolded"]), ran["unfolded"]
+    assert not any(k.endswith("_add") for k in ran["unfolded"]) and any(k.endswith("_add") for k in ran["folded"])
+    std = float(out["fp32"].std())
+    rel = {t: float(np.sqrt(np.mean((out[t] - out["fp32"]) ** 2)) / std) for t in ("folded", "simple", "unfolded")}
+    between = {t: float(np.sqrt(np.mean((out[t] - out["unfolded"]) ** 2)) / std) for t in ("folded", "simple")}
+    kernels = float(np.sqrt(np.mean((out["folded"] - out["simple"]) ** 2)) / std)
+    print(prec, roi, "vs fp32:", rel, "vs unfolded:", between, "persistent vs one-tile kernel:", kernels)
+    tol32, tol16 = (1e-2, 2e-3) if prec == "fp16" else (5e-2, 2e-2)
+    for t, r in rel.items():
+        assert r < tol32, (t, r)
+        assert r < 1.1 * rel["unfolded"] + 1e-4, (t, r, rel["unfolded"])  # folding does not cost accuracy (one rounding less)
+    for t, r in between.items():
+        assert r < tol16, (t, r)
+    assert kernels < tol16 / 4, kernels  # same products, the face correction enters the fp32 sum first instead of last

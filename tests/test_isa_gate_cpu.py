@@ -60,7 +60,7 @@ def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd()
     rep = hs.library_report(LIB)
     wino = {k: v for k, v in rep.items() if "zwino" in k}
     rep = {k: v for k, v in rep.items() if "zwino" not in k}
-    assert len(rep) == 10, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0; Cin 64: t8 a0/a1)
+    assert len(rep) == 14, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with addend; Cin 64: t8 a0/a1)
     assert len(wino) == 1, sorted(wino)  # the opt-in Winograd F(2,3)-x variant: 36 weight fragments = 144 AGPRs
     for name, r in wino.items():
         assert r["hazards"] == 0 and r["readback_hazards"] == 0, (name, r["first"], r["first_readback"])
@@ -81,3 +81,17 @@ def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd()
         assert a >= 27 * (cin // 32) * 4, (name, a)
         key = [k for k in EXPECTED_MFMA if k[0] in name and k[1] in name]
         assert key and r["mfma"] == EXPECTED_MFMA[key[0]], (name, r["mfma"])
+
+
+def test_persistent_upconv_kernel_has_no_mfma_hazard_and_keeps_its_weights_in_agprs():
+    """upconv.hip's persistent kernel: asm MFMAs like the z-reg conv, 32 A-fragments (128 AGPRs) per wave for the whole walk over
+    the tiles, one tile's 32 iterations x 32 MFMAs unrolled, the halo tile staged by LDS-DMA (no scratch, no spills)."""
+    _need_tools()
+    hs = _tool()
+    rep = hs.library_report(LIB, name_filter=("upconv2m_kernel",))
+    assert len(rep) == 2, sorted(rep)  # fp16, bf16
+    for name, r in rep.items():
+        assert r["hazards"] == 0 and r["readback_hazards"] == 0, (name, r["first"], r["first_readback"])
+        assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, name
+        assert r["agpr_count"] == 128 and r["vgpr_count"] <= 512, (name, r["vgpr_count"], r["agpr_count"])
+        assert r["mfma"] == 32 * 32, (name, r["mfma"])
