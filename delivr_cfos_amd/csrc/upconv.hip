@@ -384,14 +384,8 @@ upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, con
         auto epi_store = [&](int T, int py) __attribute__((always_inline)) {
             const int cz = T >> 3, cy = T & 7;
             const int fz = 2 * (cur.z0 + cz) + pz, fy = 2 * (cur.y0 + cy) + py;
-#ifdef UC_EXP_LINEAR  // timing experiment (WRONG results): every store instruction writes one contiguous KiB, tile after tile
-            const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out), 0, (int)0x7ffffff0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, lrs, lane * 16,
-                                                   (int)((((unsigned)(t * 32 + T) * 2u + py) * 4u + wave) * 1024u), 0);
-#else
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, ors, (int)lane_out,
                                                    (int)((unsigned)((fz * H + fy) * W + 2 * cur.x0) * 16u), 0);
-#endif
         };
         ring_read(0, 0);
         ring_read(0, 1);
