@@ -49,6 +49,10 @@ constexpr int ZR_HX = 34;
 #endif
 // wait states in front of every asm MFMA: a compiler-generated VALU write of an MFMA operand (register copy, spill
 // reload) right before the asm would otherwise be read stale - hipcc pads nothing for an asm statement
+// addend rows in flight (ADD instantiations): the fetch of a row waits, through the in-order vmcnt, for every store issued before it
+#ifndef ZR_ADD_AHEAD
+#define ZR_ADD_AHEAD 4
+#endif
 #ifndef ZR_NOP
 #define ZR_NOP "s_nop 1"
 #endif
@@ -118,7 +122,7 @@ using IC = std::integral_constant<int, N>;
 
 // ADD: `addend` (16-bit, the layout of `out`) is added to the accumulators in the epilogue, before the statistics and the
 // pack: the "up" half of an UpCat block's first conv, computed from the COARSE tensor by upconv.hip - the 64-channel conv
-// becomes this 32-channel one and the up-sampled tensor never exists.  The addend of an output row is fetched two epilogue
+// becomes this 32-channel one and the up-sampled tensor never exists.  The addend of an output row is fetched ZR_ADD_AHEAD epilogue
 // rows ahead (the rows of a z column form one sequence: plane by plane, row by row).
 template <class P, int CIN, int TYT, bool ACT, bool ADD = false>
 __global__ void __launch_bounds__(256, 1)
@@ -259,17 +263,19 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)(2u * (unsigned)vox * 16u), 0x00020000);
     const bool xok[2] = {x0 + l16 < W, x0 + 16 + l16 < W};
     // ADD: the addend's two chunks through a buffer resource with the output's offsets (an offset outside it - a plane of a
-    // masked step - reads zeros); pbuf[slot][block]: slot = row & 1 (RW is even: the sequence of rows alternates slots)
+    // masked step - reads zeros); pbuf[slot][block]: slot = row % AHEAD
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
         ADD ? const_cast<char*>(reinterpret_cast<const char*>(addend + ((long long)n * cout8 + cb * 4 + half * 2) * vox)) : obase, 0,
         (int)(2u * (unsigned)vox * 16u), 0x00020000);
-    u32x2 pbuf[2][2] = {{{0u, 0u}, {0u, 0u}}, {{0u, 0u}, {0u, 0u}}};
+    constexpr int AHEAD = ZR_ADD_AHEAD;  // rows between an addend's fetch and its use (RW % AHEAD == 0: a row's slot is r % AHEAD)
+    static_assert(RW % AHEAD == 0, "addend slots");
+    u32x2 pbuf[AHEAD][2] = {};
     auto add_fetch = [&](bool valid, int r, int b, int oz) __attribute__((always_inline)) {  // row r (0..RW-1) of plane oz
         // (the scalar offset is not part of the buffer's range check: a row / plane that does not exist reads row 0 of plane 0
         // instead - its value is never used)
         if constexpr (ADD)
-            pbuf[r & 1][b] = __builtin_amdgcn_raw_buffer_load_b64(ars, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, 0);
+            pbuf[r % AHEAD][b] = __builtin_amdgcn_raw_buffer_load_b64(ars, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, 0);
     };
     const unsigned toff = (unsigned)(threadIdx.x * 8u + (blockIdx.x & 31u) * 2048u);  // masked-out stores land here (64 KB)
 
@@ -327,14 +333,14 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
         if constexpr (ADD) {
             if (k == 0) {  // accumulator + addend -> the copy every later micro-op of this (row, block) uses
                 f32x4 a = r < RA ? epi_v[b] : accv[set][r >= RA ? r - RA : 0][b];
-                const u32x2 pv = pbuf[r & 1][b];
+                const u32x2 pv = pbuf[r % AHEAD][b];
                 a[0] += P::lo(pv[0]);
                 a[1] += P::hi(pv[0]);
                 a[2] += P::lo(pv[1]);
                 a[3] += P::hi(pv[1]);
                 epi_v[b] = a;
-                // the row two further on in the sequence (plane by plane, row by row): same slot, now free
-                const int r2 = (r + 2) % RW, oz2 = oz + ((r + 2) >= RW ? 1 : 0);
+                // the row AHEAD further on in the sequence (plane by plane, row by row): same slot, now free
+                const int r2 = (r + AHEAD) % RW, oz2 = oz + ((r + AHEAD) >= RW ? 1 : 0);
                 add_fetch(INT || (oz2 >= 0 && oz2 < D && y0 + rg * RW + r2 < H), r2, b, oz2);
             }
         }
