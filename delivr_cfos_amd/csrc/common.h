@@ -185,6 +185,33 @@ static inline void dlv_attr_mark(dlv_attr_bits& bits, int device) { bits.fetch_o
 // is blockIdx.x % 8; every XCD gets a contiguous run of tiles instead of every 8th one, neighbouring tiles run at the same
 // time and find each other's halo lines in their L2 (z-reg conv, PMC: 1.27x / 1.47x -> 1.06x / 1.08x of the algorithmic bytes)
 #ifdef __HIPCC__
+// Non-temporal accesses for tensors that are streamed once and are far larger than L2 + MALL (the level-0 tensors of a batch:
+// 2.1 GB): `nt` keeps them from displacing the lines other kernels - or the same kernel's halo - will re-read.  Measured
+// (profiles/microbench/nt_probe.hip): the in-place norm + Mish pass over 2.15 GB 743 -> 642 us, upconv's P stores 602 -> 540 us.
+#ifndef DLV_NT
+#define DLV_NT 1
+#endif
+typedef unsigned dlv_u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned dlv_u32x2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ uint4 dlv_ld16(const uint4* p) {
+    if constexpr (NT && DLV_NT) {
+        const dlv_u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const dlv_u32x4_t*>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void dlv_st16(uint4* p, uint4 v) {
+    if constexpr (NT && DLV_NT) __builtin_nontemporal_store(dlv_u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<dlv_u32x4_t*>(p));
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void dlv_st8(uint2* p, uint2 v) {
+    if constexpr (NT && DLV_NT) __builtin_nontemporal_store(dlv_u32x2_t{v.x, v.y}, reinterpret_cast<dlv_u32x2_t*>(p));
+    else *p = v;
+}
 __device__ __forceinline__ int dlv_xcd_tile(unsigned bx, unsigned gx) {
     return (gx % 8 == 0) ? (int)((bx % 8) * (gx / 8) + bx / 8) : (int)bx;
 }

@@ -53,6 +53,13 @@ constexpr int ZR_HX = 34;
 #ifndef ZR_ADD_AHEAD
 #define ZR_ADD_AHEAD 4
 #endif
+// cache policy of the addend loads (read once) and of the interior steps' output stores (2 = nt)
+#ifndef ZR_ADD_AUX
+#define ZR_ADD_AUX (DLV_NT ? 2 : 0)
+#endif
+#ifndef ZR_STORE_AUX
+#define ZR_STORE_AUX 0
+#endif
 #ifndef ZR_NOP
 #define ZR_NOP "s_nop 1"
 #endif
@@ -275,7 +282,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
         // (the scalar offset is not part of the buffer's range check: a row / plane that does not exist reads row 0 of plane 0
         // instead - its value is never used)
         if constexpr (ADD)
-            pbuf[r % AHEAD][b] = __builtin_amdgcn_raw_buffer_load_b64(ars, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, 0);
+            pbuf[r % AHEAD][b] = __builtin_amdgcn_raw_buffer_load_b64(ars, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, ZR_ADD_AUX);
     };
     const unsigned toff = (unsigned)(threadIdx.x * 8u + (blockIdx.x & 31u) * 2048u);  // masked-out stores land here (64 KB)
 
@@ -359,7 +366,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             u.y = P::pack2(v[2], v[3]);
             if constexpr (INT) {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{u.x, u.y}, ors, (int)ooff_b[b], (int)((unsigned)(oz * plane + r * W) * 16u), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{u.x, u.y}, ors, (int)ooff_b[b], (int)((unsigned)(oz * plane + r * W) * 16u), ZR_STORE_AUX);
             } else {  // per-lane address: the real voxel or this lane's slot of the trash line
                 char* const real = obase + ((long long)oz * plane + (long long)r * W) * 16 + ooff + (unsigned)b * 256u;
                 *reinterpret_cast<uint2*>(ok ? real : trash + toff) = u;

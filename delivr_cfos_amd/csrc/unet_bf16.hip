@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const uint16_t* __restri
                     u.x = P::pack2(val[4 * g + 0], val[4 * g + 1]);
                     u.y = P::pack2(val[4 * g + 2], val[4 * g + 3]);
                     uint2* dst = reinterpret_cast<uint2*>(out + ((long long)n * 4 + g) * vox + o);
-                    dst[h] = u;
+                    dlv_st8<true>(dst + h, u);
                 }
             }
         }
@@ -661,7 +661,7 @@ __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const floa
 // WB: write the activated tensor back in place.  POOL && !WB: only the pooled tensor is produced - the full-resolution
 // tensor stays raw and every consumer applies scale/shift + Mish while it loads (conv_zreg.hip's staging, the
 // transposed conv below, the final 1x1x1 conv)
-template <class P, bool POOL, bool WB>
+template <class P, bool POOL, bool WB, bool NT = false>
 __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C,
                                                         int D, int H, int W, uint4* __restrict__ pooled) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
     uint4* p = x + ((long long)n * (C / 8) + c8) * vox;
     if (!POOL) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256)
-            p[i] = norm_mish8<P>(p[i], sc, sh, nullptr);
+            dlv_st16<NT>(p + i, norm_mish8<P>(dlv_ld16<NT>(p + i), sc, sh, nullptr));
     } else {
         const int d2 = D / 2, h2 = H / 2, w2 = W / 2;
         const long long pv = (long long)d2 * h2 * w2;
@@ -691,6 +691,8 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const long long o = ((long long)(2 * zz + a) * H + (2 * yy + b)) * W + 2 * xx;
+                    // (default cache policy here: a wave's two loads / stores each touch every other 16 bytes of the same lines -
+                    // with `nt` the second one misses again: 1060 -> 1340 us per forward)
                     const uint4 r0 = norm_mish8<P>(p[o], sc, sh, mx), r1 = norm_mish8<P>(p[o + 1], sc, sh, mx);
                     if (WB) {
                         p[o] = r0;
@@ -703,6 +705,55 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
             r.z = P::pack2(mx[4], mx[5]);
             r.w = P::pack2(mx[6], mx[7]);
             q[i] = r;
+        }
+    }
+}
+
+// The pooling pass by full lines (W % 64 == 0: levels 0 and 1): a wave owns 64 consecutive fine voxels of the four rows
+// (2 planes x 2 rows) under 32 pooled voxels - every load / store instruction covers one contiguous KiB (the kernel above reads
+// every other 16 bytes per instruction and needs the lines to survive in cache between its two loads), so the non-temporal policy
+// applies; the x pair is reduced with one DPP max per value, even lanes store the pooled voxel.  Same values bit for bit (max and
+// the 16-bit rounding commute).
+template <class P, bool WB, bool NT>
+__global__ void __launch_bounds__(256) norm_mish_pool_rows_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C, int D, int H,
+                                                                  int W, uint4* __restrict__ pooled) {
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 v = ss[n * C + c8 * 8 + k];
+        sc[k] = v.x;
+        sh[k] = v.y;
+    }
+    const long long vox = (long long)D * H * W;
+    const int d2 = D / 2, h2 = H / 2, w2 = W / 2, nseg = W / 64;
+    uint4* p = x + ((long long)n * (C / 8) + c8) * vox;
+    uint4* q = pooled + ((long long)n * (C / 8) + c8) * ((long long)d2 * h2 * w2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long items = (long long)d2 * h2 * nseg;
+    for (long long it = (long long)blockIdx.x * 4 + wave; it < items; it += (long long)gridDim.x * 4) {
+        const int xs = (int)(it % nseg), yy = (int)((it / nseg) % h2), zz = (int)(it / ((long long)nseg * h2));
+        uint4 u[4];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) u[ab] = dlv_ld16<NT>(p + ((long long)(2 * zz + (ab >> 1)) * H + (2 * yy + (ab & 1))) * W + xs * 64 + lane);
+        float mx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx[k] = -INFINITY;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const uint4 r = norm_mish8<P>(u[ab], sc, sh, mx);
+            if (WB) dlv_st16<NT>(p + ((long long)(2 * zz + (ab >> 1)) * H + (2 * yy + (ab & 1))) * W + xs * 64 + lane, r);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)  // the neighbour of the x pair: quad_perm [1,0,3,2]
+            mx[k] = fmaxf(mx[k], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx[k]), 0xB1, 0xf, 0xf, true)));
+        if (!(lane & 1)) {
+            uint4 r;
+            r.x = P::pack2(mx[0], mx[1]);
+            r.y = P::pack2(mx[2], mx[3]);
+            r.z = P::pack2(mx[4], mx[5]);
+            r.w = P::pack2(mx[6], mx[7]);
+            dlv_st16<NT>(q + ((long long)zz * h2 + yy) * w2 + xs * 32 + (lane >> 1), r);
         }
     }
 }
@@ -1054,7 +1105,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
         f32x2_t a2 = {b0, 0.f};
 #pragma unroll
         for (int c8 = 0; c8 < 4; ++c8) {
-            const uint4 u = x[((long long)n * 4 + c8) * vox + i];
+            const uint4 u = dlv_ld16<true>(x + ((long long)n * 4 + c8) * vox + i);  // (read once, 64 B per voxel)
             const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1329,16 +1380,36 @@ struct Net16 {
     int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
         DLV_TRY(use(DLV_K_MEM, d));
         const long long work = pooled ? d.vox() / 8 : d.vox();
-        dim3 grid(std::max(1, std::min(grid1d(work), 2048)), C / 8, B);
+        // a tensor far beyond L2 + MALL is streamed with the non-temporal policy and two grid-stride iterations per thread
+        // (profiles/microbench/nt_probe.hip: 2.15 GB in place 743 us at 2048 x default, 642 us at 4096 x nt); the small levels
+        // keep the default policy - their tensors are still on chip when the consumer starts
+        const bool nt = (double)d.vox() * B * C * 2 > 768.0 * (1 << 20);
+        dim3 grid(std::max(1, std::min(grid1d(work), nt && !pooled ? 4096 : 2048)), C / 8, B);
         DlvProf pr(ctx, pooled ? (writeback ? (P::IS_F16 ? "norm_mish_pool_f16" : "norm_mish_pool_bf16") : (P::IS_F16 ? "pool_act_f16" : "pool_act_bf16"))
                                : (P::IS_F16 ? "norm_mish_f16" : "norm_mish_bf16"), 0.0,
                    (double)d.vox() * B * C * 2 * (writeback ? 2 : 1) + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
-        if (pooled && writeback)
-            hipLaunchKernelGGL((norm_mish_kernel<P, true, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
-        else if (pooled)
-            hipLaunchKernelGGL((norm_mish_kernel<P, true, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
-        else
-            hipLaunchKernelGGL((norm_mish_kernel<P, false, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled);
+#define DLV_NM_LAUNCH(POOL_, WB_)                                                                                                  \
+    do {                                                                                                                           \
+        if (nt)                                                                                                                    \
+            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
+    } while (0)
+        static const bool pool_rows_off = getenv("DLV_POOL_ROWS_OFF") != nullptr;  // A/B + tests: the pooled-voxel-per-thread kernel everywhere
+        if (pooled && d.W % 64 == 0 && !pool_rows_off) {
+            const long long items = (long long)(d.D / 2) * (d.H / 2) * (d.W / 64);
+            dim3 g2((unsigned)std::max<long long>(1, std::min<long long>((items + 7) / 8, 4096)), C / 8, B);
+#define DLV_NP_LAUNCH(WB_, NT_) \
+    hipLaunchKernelGGL((norm_mish_pool_rows_kernel<P, WB_, NT_>), g2, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled)
+            if (writeback && nt) DLV_NP_LAUNCH(true, true);
+            else if (writeback) DLV_NP_LAUNCH(true, false);
+            else if (nt) DLV_NP_LAUNCH(false, true);
+            else DLV_NP_LAUNCH(false, false);
+#undef DLV_NP_LAUNCH
+        } else if (pooled && writeback) DLV_NM_LAUNCH(true, true);
+        else if (pooled) DLV_NM_LAUNCH(true, false);
+        else DLV_NM_LAUNCH(false, true);
+#undef DLV_NM_LAUNCH
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "norm_mish_kernel");
         return DLV_OK;

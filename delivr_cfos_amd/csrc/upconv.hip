@@ -227,6 +227,9 @@ __global__ void __launch_bounds__(256) upconv2_kernel(const uint4* __restrict__ 
 // a ring slot is overwritten by a ds_read issued after the slot's last MFMA; "s_nop 1" in front of every MFMA covers a
 // compiler-generated VALU write of an operand.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#ifndef UC_STORE_AUX
+#define UC_STORE_AUX (DLV_NT ? 2 : 0)  // cache policy of the P stores: nt (602 -> 540 us per 16 windows, profiles/README.md)
+#endif
 constexpr int UM_NP = UC_CS / 64;  // staged pieces per chunk (17)
 constexpr int UM_DEP = 4;          // staged pieces in flight
 
@@ -385,7 +388,7 @@ upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, con
             const int cz = T >> 3, cy = T & 7;
             const int fz = 2 * (cur.z0 + cz) + pz, fy = 2 * (cur.y0 + cy) + py;
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y}, ors, (int)lane_out,
-                                                   (int)((unsigned)((fz * H + fy) * W + 2 * cur.x0) * 16u), 0);
+                                                   (int)((unsigned)((fz * H + fy) * W + 2 * cur.x0) * 16u), UC_STORE_AUX);
         };
         ring_read(0, 0);
         ring_read(0, 1);

@@ -345,7 +345,8 @@ np.save(sys.argv[2], acc.cpu().numpy())
 def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, prec):
     """Every environment switch the product library reads selects kernels, never results: the activation fused into the
     z-reg conv's staging (DLV_FUSE_LEVELS), edge-step code on every plane (DLV_ZREG_DBG), the LDS-weights z-march instead
-    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes, upcat_1 unfolded
+    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes, the pooling pass by pooled voxels
+    instead of by full lines (DLV_POOL_ROWS_OFF), upcat_1 unfolded
     (DLV_NO_UPCONV) or folded with the one-tile kernel (DLV_UPCONV_SIMPLE).  The switches are read once
     per process, hence one process per setting; 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1)."""
     import os
@@ -364,7 +365,7 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, p
     base = run({})
     std = float(base.std())
     # bit-identical: same arithmetic in another order of execution / another code path of the same kernel
-    for env in ({"DLV_LANES": "1"}, {"DLV_ZREG_DBG": "1"}, {"DLV_GENERIC_NCB": "1"}):
+    for env in ({"DLV_LANES": "1"}, {"DLV_ZREG_DBG": "1"}, {"DLV_GENERIC_NCB": "1"}, {"DLV_POOL_ROWS_OFF": "1"}):
         np.testing.assert_array_equal(run(env), base, err_msg=str(env))
     # same values up to the rounding of one 16-bit store (activation applied while staging: the activated tensor is never
     # rounded through HBM differently, but the InstanceNorm partial sums are taken over other tiles) / another kernel
