@@ -113,8 +113,9 @@ struct U8V<1> {
 };
 template <>
 struct U8V<4> {
-    static __device__ __forceinline__ unsigned ld(const uint8_t* p) { return *reinterpret_cast<const unsigned*>(p); }
-    static __device__ __forceinline__ void st(uint8_t* p, unsigned v) { *reinterpret_cast<unsigned*>(p) = v; }
+    // (non-temporal: the distance and mask volumes are streamed once per kernel and are far larger than L2 + MALL)
+    static __device__ __forceinline__ unsigned ld(const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); }
+    static __device__ __forceinline__ void st(uint8_t* p, unsigned v) { __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p)); }
 };
 
 // per-byte min(a, b+1) for V packed bytes (values <= 254)
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) erode_xy_kernel(const uint16_t* __restric
     };
     auto row_load = [&](int y, int c) -> uint4 {  // the 8 voxels of chunk c of row y (a ragged or unaligned row: voxel by voxel)
         const uint16_t* row = raw + ((long long)z * Yp + y) * Xp;
-        if (vec && 8 * c + 8 <= X) return *reinterpret_cast<const uint4*>(row + 8 * c);
+        if (vec && 8 * c + 8 <= X) return dlv_ld16<true>(reinterpret_cast<const uint4*>(row + 8 * c));  // (nt: every byte of these volumes is touched once per kernel)
         unsigned w[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // beyond X: foreground
         for (int k = 0; k < 8; ++k)
             if (8 * c + k < X) w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | ((unsigned)row[8 * c + k] << (16 * (k & 1)));
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(256) erode_xy_kernel(const uint16_t* __restric
             const unsigned long long fwd = minplus8(dx, prev[q]);
             prev[q] = fwd;
             if (ovec && 8 * c + 8 <= X) {
-                *reinterpret_cast<unsigned long long*>(o + 8 * c) = fwd;
+                __builtin_nontemporal_store(fwd, reinterpret_cast<unsigned long long*>(o + 8 * c));
             } else {
                 for (int k = 0; k < 8 && 8 * c + k < X; ++k) o[8 * c + k] = (uint8_t)(fwd >> (8 * k));
             }
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256) erode_xy_kernel(const uint16_t* __restric
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const int c = threadIdx.x + 256 * q, y = Y - 2 - r;
-                bq[r][q] = (c < nchunk && y >= 0) ? *reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + y) * X + 8 * c) : 0ull;
+                bq[r][q] = (c < nchunk && y >= 0) ? __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + y) * X + 8 * c)) : 0ull;
             }
         for (int yb = Y - 2; yb >= 0; yb -= PFR) {
 #pragma unroll
@@ -312,9 +313,9 @@ __global__ void __launch_bounds__(256) erode_xy_kernel(const uint16_t* __restric
                     const int c = threadIdx.x + 256 * q;
                     if (c >= nchunk) continue;
                     const unsigned long long cur = minplus8(bq[r][q], prev[q]);
-                    if (y - PFR >= 0) bq[r][q] = *reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + (y - PFR)) * X + 8 * c);
+                    if (y - PFR >= 0) bq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(dist + ((long long)z * Y + (y - PFR)) * X + 8 * c));
                     prev[q] = cur;
-                    *reinterpret_cast<unsigned long long*>(o + 8 * c) = cur;
+                    __builtin_nontemporal_store(cur, reinterpret_cast<unsigned long long*>(o + 8 * c));
                 }
             }
         }
@@ -356,6 +357,7 @@ __global__ void __launch_bounds__(256) erode_z_shift_kernel(const uint8_t* __res
     const int zb0 = max(blk * zblock - zphase, 0), zb1 = min((blk + 1) * zblock - zphase, Z);
     const long long plane = (long long)Y * X;
     const uint8_t* col = dist + (long long)y * X + x;
+    const bool acc_vec = (Xp % 4 == 0) && ((reinterpret_cast<uintptr_t>(acc) & 15) == 0);  // (x is a multiple of V)
     unsigned f = 0;
 #pragma unroll
     for (int k = 0; k < V; ++k) f |= (unsigned)(radius + 1) << (8 * k);  // outside the block: foreground
@@ -373,10 +375,18 @@ __global__ void __launch_bounds__(256) erode_z_shift_kernel(const uint8_t* __res
         c = 0u;
         if (z >= zb0 && z < zb1) {
             const long long po = ((long long)z * Yp + y) * Xp + x;
+            if (V == 4 && acc_vec) {  // one 16-byte load per lane: a wave instruction covers whole lines (the compiler's 4 + 12 byte
+                typedef float f4_t __attribute__((ext_vector_type(4)));  // split touches every line twice)
+                const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(acc + po));
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                a[k] = acc[po + k];
-                if (cnt) c |= (unsigned)cnt[po + k] << (8 * k);
+                for (int k = 0; k < V; ++k) a[k] = t[k % 4];
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) a[k] = __builtin_nontemporal_load(acc + po + k);
+            }
+            if (cnt) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) c |= (unsigned)cnt[po + k] << (8 * k);
             }
         } else {
 #pragma unroll
