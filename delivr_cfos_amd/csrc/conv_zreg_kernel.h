@@ -60,6 +60,9 @@ constexpr int ZR_HX = 34;
 #ifndef ZR_STORE_AUX
 #define ZR_STORE_AUX 0
 #endif
+#ifndef ZR_LOAD_AUX
+#define ZR_LOAD_AUX 0  // the staged halo planes (2 = nt: measured, profiles/README.md)
+#endif
 #ifndef ZR_NOP
 #define ZR_NOP "s_nop 1"
 #endif
@@ -219,7 +222,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
         if constexpr (BUF) {  // (the lane offset goes into the instruction as it is: no address arithmetic in the VALU)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src[s] + (long long)p * plane_b), 0,
                                                                                 (int)plane_b, 0x00020000);
-            pre[s][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[it], 0, 0);
+            pre[s][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[it], 0, ZR_LOAD_AUX);
         } else {
             unsigned o = goff[it];
             asm volatile("" : "+v"(o));  // keeps the zero-extension next to the load: SGPR base + 32-bit VGPR offset form
