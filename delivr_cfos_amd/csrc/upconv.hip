@@ -216,7 +216,11 @@ __global__ void __launch_bounds__(256) upconv2_kernel(const uint4* __restrict__ 
 // matrix pipe busy 0.29 - profiles/r04t_upconv_pmc.txt).  Here, in the manner of conv_zreg_kernel.h:
 //   * one workgroup per CU walks over tiles: the 32 A-fragments of a wave are loaded ONCE and live in AGPRs (asm MFMAs),
 //   * the halo tile of the NEXT tile is staged while this one is multiplied (two LDS tiles; wave w stages chunk w: 17 pieces
-//     of 64 voxels, buffer loads whose out-of-window lanes read zeros, 4 in flight, written to LDS 4 iterations later),
+//     of 64 voxels by LDS-DMA - `buffer_load_dwordx4 ... lds`, one per iteration: a lane outside the window carries an offset
+//     beyond the resource and the hardware writes zeros (profiles/microbench/lds_dma_oob.hip); no staging registers, one counted
+//     vmcnt + one barrier per tile.  Register staging with 4 pieces in flight measured the same: the kernel is bound by its HBM
+//     mix, profiles/r04u_upconv_diag.txt),
+//   * XCD k walks over a contiguous eighth of the tile sequence, its workgroups over consecutive tiles of it,
 //   * an iteration = one coarse row segment (cz, cy) = 32 MFMAs, all 32 iterations of a tile unrolled; the B fragments sit in
 //     a ring of 4 row sets (row = 2 planes x 3 x offsets), the row set of the next iteration is read one iteration ahead;
 //     where the plane changes (cy = 7) the three new row sets go into the slots as the MFMA order (rows yy = 0, 1, 2) frees them,
