@@ -333,9 +333,10 @@ from delivr_cfos_amd.synth import synth_volume_np
 from delivr_cfos_amd.weights import random_state_dict
 eng = HipEngine(0)
 eng.load_state_dict({"state_dict": random_state_dict(0)})
-vol = synth_volume_np((64, 96, 128), seed=9, dense=True)
+big = len(sys.argv) > 4 and sys.argv[4] == "128"
+vol = synth_volume_np((128, 128, 256) if big else (64, 96, 128), seed=9, dense=True)
 acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
-eng.sw_infer(eng.make_sw_params(vol.shape, (64, 64, 64), 0.5, None, 0, sys.argv[3]), eng.to_device(vol), acc)
+eng.sw_infer(eng.make_sw_params(vol.shape, (128, 128, 128) if big else (64, 64, 64), 0.5, None, 0, sys.argv[3]), eng.to_device(vol), acc)
 eng.sync()
 np.save(sys.argv[2], acc.cpu().numpy())
 """
@@ -477,3 +478,22 @@ def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, sh
     for t, r in between.items():
         assert r < tol16, (t, r)
     assert kernels < tol16 / 4, kernels  # same products, the face correction enters the fp32 sum first instead of last
+
+
+def test_pooling_pass_by_full_lines_is_bit_identical_at_128(tmp_path):
+    """Windows of 128^3: the full-line pooling kernel runs on levels 0 and 1 (W = 128 / 64, two / one 64-voxel segments per row) with
+    the non-temporal policy on level 0; DLV_POOL_ROWS_OFF=1 runs the pooled-voxel-per-thread kernel instead.  Same bits."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, env in (("rows", {}), ("voxels", {"DLV_POOL_ROWS_OFF": "1"})):
+        out = str(tmp_path / f"acc_{tag}.npy")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([sys.executable, "-c", _SWITCH_SNIPPET, root, out, "fp16", "128"], env=e, timeout=600)
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and outs[0].std() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
