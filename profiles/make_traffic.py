@@ -22,9 +22,10 @@ root, wl, precision = sys.argv[1], sys.argv[2], sys.argv[3]
 # label prefix -> the kernel(s) a bracketed launch of that label dispatches, in order (a|b: either template)
 # (the stem is two launches of one template under one bracket: statistics pass, then the pass that writes)
 FAMILY = [("conv3_zreg_", ["conv3_zreg_kernel"]), ("conv3_zmarch_", ["conv3_zmarch_kernel"]), ("conv3_mfma_", ["conv3_mfma_kernel"]),
-          ("norm_mish_", ["norm_mish_kernel"]), ("pool_act_", ["norm_mish_kernel"]), ("deconv2_mfma_", ["deconv2_rows_kernel|deconv2_regw_kernel|deconv2_wst_kernel"]),
+          ("norm_mish_", ["norm_mish_kernel|norm_mish_pool_rows_kernel"]), ("pool_act_", ["norm_mish_kernel|norm_mish_pool_rows_kernel"]),
+          ("upconv2", ["upconv2m_kernel|upconv2_kernel"]), ("deconv2_mfma_", ["deconv2_rows_kernel|deconv2_regw_kernel|deconv2_wst_kernel"]),
           ("stem_mfma_", ["stem_mfma_kernel", "stem_mfma_kernel"]), ("final_conv_", ["final_conv_kernel"]), ("erode_x_", ["erode_x_kernel|erode_x_bits_kernel"]),
-          ("erode_y_", ["erode_y_kernel"]), ("erode_z_", ["erode_z_final_kernel"]), ("window_max_", ["cell_max_kernel|window_max_kernel"]),
+          ("erode_y_", ["erode_y_kernel"]), ("erode_xy_", ["erode_xy_kernel"]), ("erode_z_", ["erode_z_final_kernel|erode_z_shift_kernel"]), ("window_max_", ["cell_max_kernel|window_max_kernel"]),
           ("skip_fill_", ["fill_add_kernel"])]
 
 
