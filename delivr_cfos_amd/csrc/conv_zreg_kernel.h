@@ -88,9 +88,9 @@ struct ZrCfg {
 
 // y * tanh(softplus(y)) exactly as unet_bf16.hip's mish_fast (one v_exp + one v_rcp)
 __device__ __forceinline__ float zr_mish(float y) {
-    const float n = __builtin_amdgcn_exp2f(fminf(y, 20.f) * 1.44269504f);
-    const float t = n * (n + 2.f);
-    return y * (t * __builtin_amdgcn_rcpf(t + 2.f));
+    const float n = __builtin_amdgcn_exp2f(y * 1.44269504f);
+    const float d = fmaf(n, n + 2.f, 2.f);
+    return fmaf(-2.f * y, __builtin_amdgcn_rcpf(d), y);
 }
 
 // sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): every lane of the row ends up with the total

@@ -27,25 +27,25 @@ namespace {
 #define AS_FRAG(x) (x)
 
 __device__ __forceinline__ float mish_fast(float y) {
-    // y * tanh(softplus(y)) = y * t / (t + 2), t = n^2 + 2n, n = e^y.  The exponent is clamped at torch's softplus
-    // threshold (20): there t ~ 2e17 and t / (t + 2) rounds to exactly 1, i.e. the identity, without a select.
-    // One v_exp_f32 + one v_rcp_f32 (1 ulp) and five plain VALU ops; __fdividef would expand to the 10-instruction
-    // IEEE division sequence, which made the normalisation kernels VALU-bound instead of HBM-bound.
-    const float n = __builtin_amdgcn_exp2f(fminf(y, 20.f) * 1.44269504f);
-    const float t = n * (n + 2.f);
-    return y * (t * __builtin_amdgcn_rcpf(t + 2.f));
+    // y * tanh(softplus(y)) = y * t / (t + 2) = y - 2y / d,  d = t + 2 = n (n + 2) + 2,  n = e^y.
+    // In this form nothing has to be clamped: for large y, n and d overflow to +inf, 1/d = 0 and the result is y exactly (torch's
+    // softplus threshold does the same from y = 20).  For very negative y the difference cancels to |y| * 1e-7 absolute - below
+    // half an ulp of the 16-bit store for every value the formats can hold.  One v_exp_f32 + one v_rcp_f32 (1 ulp) and four plain
+    // VALU ops; __fdividef would expand to the 10-instruction IEEE division sequence.
+    const float n = __builtin_amdgcn_exp2f(y * 1.44269504f);
+    const float d = fmaf(n, n + 2.f, 2.f);
+    return fmaf(-2.f * y, __builtin_amdgcn_rcpf(d), y);
 }
 
 // two values at once: the plain operations become packed-f32 instructions (v_pk_mul/add/fma_f32, two lanes' worth of
 // work per issue slot); element for element the same operations as mish_fast, i.e. the same bits
 __device__ __forceinline__ f32x2_t mish_fast2(f32x2_t y) {
-    const f32x2_t c20 = {20.f, 20.f}, l2e = {1.44269504f, 1.44269504f}, two = {2.f, 2.f};
-    const f32x2_t e = __builtin_elementwise_min(y, c20) * l2e;
+    const f32x2_t l2e = {1.44269504f, 1.44269504f}, two = {2.f, 2.f}, m2 = {-2.f, -2.f};
+    const f32x2_t e = y * l2e;
     const f32x2_t n = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-    const f32x2_t t = n * (n + two);
-    const f32x2_t d = t + two;
+    const f32x2_t d = __builtin_elementwise_fma(n, n + two, two);
     const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    return y * (t * r);
+    return __builtin_elementwise_fma(m2 * y, r, y);
 }
 __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -1101,35 +1101,76 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
         y0 = starts[3 * n + 1];
         x0 = starts[3 * n + 2];
     }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256) {
-        f32x2_t a2 = {b0, 0.f};
+    // Software pipeline: the four chunk words and (plain blend) the accumulator word of iteration i + 1 are in flight while the 32
+    // Mish evaluations of iteration i run.  Without it a wave alternates between waiting for its loads and ~1700 cycles of
+    // arithmetic, and neither the VALU (408 us of work per 16 windows) nor HBM (420 us) is kept busy: 588 us
+    // (profiles/microbench/final_probe.hip: 447 us pipelined at 8 iterations per thread).
+    // (32-bit voxel indices - the launcher refuses windows of 2^31 voxels - and the window coordinates advanced by the grid
+    // stride with carries instead of three 64-bit divisions per voxel: those were a third of the loop's instructions)
+    const unsigned nvox = (unsigned)vox, step = gridDim.x * 256u;
+    const unsigned sx = step % (unsigned)W, sy = (step / (unsigned)W) % (unsigned)H, sz = step / ((unsigned)W * (unsigned)H);
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nvox) {
+        unsigned xx = i % (unsigned)W, yy = (i / (unsigned)W) % (unsigned)H, zz = i / ((unsigned)W * (unsigned)H);
+        auto out_index = [&](unsigned z, unsigned y, unsigned xc) -> long long {
+            const int zf = flip_dim == 2 ? D - 1 - (int)z : (int)z, yf = flip_dim == 3 ? H - 1 - (int)y : (int)y,
+                      xf = flip_dim == 4 ? W - 1 - (int)xc : (int)xc;
+            return ((long long)(z0 + zf) * Yp + (y0 + yf)) * Xp + (x0 + xf);
+        };
+        const bool plain = BLEND && !bw;  // (Gaussian weights: two read-modify-writes per voxel, not prefetched)
+        const uint4* xb = x + (long long)n * 4 * vox;
+        uint4 u[4];
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
-            const uint4 u = dlv_ld16<true>(x + ((long long)n * 4 + c8) * vox + i);  // (read once, 64 B per voxel)
-            const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+        for (int c8 = 0; c8 < 4; ++c8) u[c8] = dlv_ld16<true>(xb + (long long)c8 * vox + i);  // (read once, 64 B per voxel)
+        long long o = BLEND ? out_index(zz, yy, xx) : 0;
+        float av = plain ? acc[o] : 0.f;
+        for (; i < nvox; i += step) {
+            uint4 un[4] = {u[0], u[1], u[2], u[3]};
+            long long on = o;
+            float avn = 0.f;
+            const unsigned zc = zz, yc = yy, xc = xx;  // this iteration's coordinates (Gaussian weights)
+            const unsigned in = i + step;
+            if (in < nvox && in > i) {
+                xx += sx;
+                const unsigned cx = xx >= (unsigned)W ? 1u : 0u;
+                xx -= cx ? (unsigned)W : 0u;
+                yy += sy + cx;
+                const unsigned cy = yy >= (unsigned)H ? 1u : 0u;
+                yy -= cy ? (unsigned)H : 0u;
+                zz += sz + cy;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x2_t v = {P::lo(uu[k]), P::hi(uu[k])};
-                a2 = fma2(mish_fast2(fma2(v, sc[4 * c8 + k], sh[4 * c8 + k])), ww[4 * c8 + k], a2);
+                for (int c8 = 0; c8 < 4; ++c8) un[c8] = dlv_ld16<true>(xb + (long long)c8 * vox + in);
+                if (BLEND) on = out_index(zz, yy, xx);
+                if (plain) avn = acc[on];
             }
-        }
-        const float a = a2.x + a2.y;
-        bad |= !(fabsf(a) <= 3.0e38f);
-        if (!BLEND) {
-            logits[(long long)n * vox + i] = a;
-        } else {
-            int xx = (int)(i % W), yy = (int)((i / W) % H), zz = (int)(i / ((long long)W * H));
-            if (flip_dim == 2) zz = D - 1 - zz;
-            if (flip_dim == 3) yy = H - 1 - yy;
-            if (flip_dim == 4) xx = W - 1 - xx;
-            const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
-            if (bw) {  // Gaussian importance map, indexed in volume orientation (after the un-flip)
-                const float wgt = fmaxf(bw[zz] * bw[D + yy] * bw[D + H + xx], bmin) * scale;
+            f32x2_t a2 = {b0, 0.f};
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                const unsigned uu[4] = {u[c8].x, u[c8].y, u[c8].z, u[c8].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2_t v = {P::lo(uu[k]), P::hi(uu[k])};
+                    a2 = fma2(mish_fast2(fma2(v, sc[4 * c8 + k], sh[4 * c8 + k])), ww[4 * c8 + k], a2);
+                }
+            }
+            const float a = a2.x + a2.y;
+            bad |= !(fabsf(a) <= 3.0e38f);
+            if (!BLEND) {
+                logits[(long long)n * vox + i] = a;
+            } else if (bw) {  // Gaussian importance map, indexed in volume orientation (after the un-flip)
+                const int zf = flip_dim == 2 ? D - 1 - (int)zc : (int)zc, yf = flip_dim == 3 ? H - 1 - (int)yc : (int)yc,
+                          xf = flip_dim == 4 ? W - 1 - (int)xc : (int)xc;
+                const float wgt = fmaxf(bw[zf] * bw[D + yf] * bw[D + H + xf], bmin) * scale;
                 acc[o] += wgt * a;
                 if (wsum) wsum[o] += wgt;
             } else {
-                acc[o] += scale * a;
+                acc[o] = av + scale * a;
             }
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) u[c8] = un[c8];
+            o = on;
+            av = avn;
+            if (in <= i) break;  // (32-bit wrap-around of the index)
         }
     }
     if (bad) atomicMax(range_flag, 100 - 18);
@@ -1587,7 +1628,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         cur = o;
     }
     {
-        dim3 grid(std::min(net.grid1d(dm[0].vox()), 2048), B);
+        dim3 grid(std::min(net.grid1d(dm[0].vox()), 1024), B);  // (8 iterations per thread at 128^3: the software pipeline's depth)
         DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
