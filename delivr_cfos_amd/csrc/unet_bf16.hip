@@ -1088,9 +1088,13 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
     for (int c = 0; c < 16; ++c) {
         const float2 v0 = ss[n * 32 + 2 * c], v1 = ss[n * 32 + 2 * c + 1];
         sc[c] = f32x2_t{v0.x, v1.x};
-        sh[c] = f32x2_t{v0.y, v1.y};
+        // 96 uniform values exceed the SGPR file, and a packed FMA reads at most ONE scalar pair (constant bus): the scales stay
+        // in SGPRs, shifts and weights live in VGPRs - no per-use v_mov_b64 / v_readlane of a spilled pair in the loop
+        float h0 = v0.y, h1 = v1.y;
+        asm volatile("" : "+v"(h0), "+v"(h1));
+        sh[c] = f32x2_t{h0, h1};
         float w0 = wf[2 * c], w1 = wf[2 * c + 1];
-        asm volatile("" : "+v"(w0), "+v"(w1));  // 96 uniform values exceed the SGPR file: the weights live in VGPRs
+        asm volatile("" : "+v"(w0), "+v"(w1));
         ww[c] = f32x2_t{w0, w1};
     }
     const long long vox = (long long)D * H * W;
