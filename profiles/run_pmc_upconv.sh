@@ -23,7 +23,7 @@ for sub in ("sq", "sq2", "fetch", "write"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(fs[0])):
-        m = re.search(r"(upconv2m?_kernel<\w+>|conv3_zreg_kernel<[^>]+>|deconv2_regw_kernel<[^>]+>|norm_mish_kernel<[^>]+>)", r["Kernel_Name"])
+        m = re.search(r"(upconv2m?_kernel<\w+>|conv3_zreg_kernel<[^>]+>|deconv2_regw_kernel<[^>]+>|norm_mish_kernel<[^>]+>|norm_mish_pool_rows_kernel<[^>]+>|final_conv_kernel<[^>]+>|stem_mfma_kernel<[^>]+>)", r["Kernel_Name"])
         if not m:
             continue
         agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[m.group(1)].add(r["Dispatch_Id"])
@@ -32,6 +32,7 @@ for sub in ("sq", "sq2", "fetch", "write"):
 for k, v in sorted(res.items()):
     wc = v.get("SQ_WAVE_CYCLES", 1); mf = max(v.get("SQ_INSTS_MFMA", 1), 1)
     print(k, "n=%d" % v["n"])
+    print("   valu_busy %.3f" % (v.get("SQ_ACTIVE_INST_VALU", 0) / wc), end="")
     print("   mfma_busy %.3f wait_any %.2f wait_inst_any %.2f active %.2f | per MFMA: VALU %.2f SALU %.2f LDS %.2f VMEM %.3f (MFMA %.3g)" % (
         v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * wc), v.get("SQ_WAIT_ANY", 0) / wc, v.get("SQ_WAIT_INST_ANY", 0) / wc, v.get("SQ_ACTIVE_INST_ANY", 0) / wc,
         v.get("SQ_INSTS_VALU", 0) / mf, v.get("SQ_INSTS_SALU", 0) / mf, v.get("SQ_INSTS_LDS", 0) / mf, (v.get("SQ_INSTS_VMEM_RD", 0) + v.get("SQ_INSTS_VMEM_WR", 0)) / mf, mf))
