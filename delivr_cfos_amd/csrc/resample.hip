@@ -281,7 +281,19 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_run16_kernel(const uint8_
 // are queued and evaluated afterwards, one output voxel per lane, with the arithmetic of the kernels above (bit-exact vs
 // scipy), screened by an fp32 evaluation that decides every voxel whose value is not within 4e-3 of a rounding tie.
 constexpr int ZR_ROWS = 32;
-__global__ void __launch_bounds__(256) zoom_run_table_kernel(short2* __restrict__ runk, int ix, int ox, double scx) {
+struct Taps32 {
+    int k[3];
+    float w[3];
+};
+__device__ __forceinline__ Taps32 spline2_taps32(int i, int n_in, double scale);
+// fp32 screening taps of every output x and y (spline2_taps32 evaluated once per call instead of once per edge voxel: two fp64
+// centre computations and six mirrored indices per voxel were a third of the edge loop): .k = k0 | k1 << 16, k2; .w = weights
+struct TapsRow {
+    unsigned k01, k2;
+    float w0, w1, w2, pad;
+};
+__global__ void __launch_bounds__(256) zoom_run_table_kernel(short2* __restrict__ runk, int ix, int ox, double scx, TapsRow* __restrict__ xt,
+                                                             TapsRow* __restrict__ yt, int iy, int oy, double scy) {
     const int runs = (ox + 15) / 16;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < runs; r += gridDim.x * blockDim.x) {
         const int x0 = r * 16, nx = min(16, ox - x0);
@@ -296,6 +308,18 @@ __global__ void __launch_bounds__(256) zoom_run_table_kernel(short2* __restrict_
             }
         }
         runk[r] = make_short2((short)kmin, (short)kmax);
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ox + oy; i += gridDim.x * blockDim.x) {
+        const bool isx = i < ox;
+        const Taps32 t = isx ? spline2_taps32(i, ix, scx) : spline2_taps32(i - ox, iy, scy);
+        TapsRow e;
+        e.k01 = (unsigned)t.k[0] | ((unsigned)t.k[1] << 16);
+        e.k2 = (unsigned)t.k[2];
+        e.w0 = t.w[0];
+        e.w1 = t.w[1];
+        e.w2 = t.w[2];
+        e.pad = 0.f;
+        (isx ? xt[i] : yt[i - ox]) = e;
     }
 }
 
@@ -318,10 +342,6 @@ __device__ __forceinline__ Taps spline2_taps_m(int i, int n_in, double scale) {
 }
 
 // the fp32 screening form: centre from the fp64 coordinate (the same centre as the exact path), weights in fp32
-struct Taps32 {
-    int k[3];
-    float w[3];
-};
 __device__ __forceinline__ Taps32 spline2_taps32(int i, int n_in, double scale) {
     Taps32 t;
     const double x = __dmul_rn((double)i, scale);
@@ -339,7 +359,8 @@ __device__ __forceinline__ Taps32 spline2_taps32(int i, int n_in, double scale) 
 
 __global__ void __launch_bounds__(256) zoom_spline2_u8_rows_kernel(const uint8_t* __restrict__ in, int iz, int iy, int ix,
                                                                    uint8_t* __restrict__ out, int oz, int oy, int ox, ZoomScales sc,
-                                                                   int aligned, const short2* __restrict__ runk, int nrows_max) {
+                                                                   int aligned, const short2* __restrict__ runk, int nrows_max,
+                                                                   const TapsRow* __restrict__ xt, const TapsRow* __restrict__ yt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zr_smem[];
     const int runs = (ox + 15) / 16;
     unsigned short* colval = reinterpret_cast<unsigned short*>(zr_smem);                                       // [ix]
@@ -408,6 +429,7 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_rows_kernel(const uint8_t
     // the queued runs (mask edges): 16 at a time, one output voxel per lane
     const int nq = qn;
     const int slot = tid >> 4, j = tid & 15;
+    const Taps32 fz = spline2_taps32(z, iz, sc.z);
     for (int q0 = 0; q0 < nq; q0 += 16) {
         const int qi = q0 + slot;
         if (qi >= nq) continue;
@@ -417,7 +439,11 @@ __global__ void __launch_bounds__(256) zoom_spline2_u8_rows_kernel(const uint8_t
         // fp32 first: the same centres (fp64, exact), weights and sum in fp32 (error < 2e-3 for uint8 inputs).  Unless
         // t + 1/2 lands within 4e-3 of an integer the truncation is decided - identical to the fp64 evaluation; the few
         // voxels near a tie (about one per crossing of the mask's edge) take the exact path below.
-        const Taps32 fz = spline2_taps32(z, iz, sc.z), fy = spline2_taps32(y, iy, sc.y), fx = spline2_taps32(x, ix, sc.x);
+        const TapsRow ex = xt[x], ey = yt[y];  // (the values spline2_taps32 gives: tabulated once per call)
+        Taps32 fx, fy;
+        fx.k[0] = (int)(ex.k01 & 0xffffu); fx.k[1] = (int)(ex.k01 >> 16); fx.k[2] = (int)ex.k2;
+        fx.w[0] = ex.w0; fx.w[1] = ex.w1; fx.w[2] = ex.w2;
+        fy.w[0] = ey.w0; fy.w[1] = ey.w1; fy.w[2] = ey.w2;
         const int lrow = spline2_centre(y, sc.y) - 1 - cy0;  // local row of tap b = 0
         float tf = 0.f;
 #pragma unroll
@@ -589,11 +615,16 @@ int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy,
         const long long groups = (long long)oz * ((oy + ZR_ROWS - 1) / ZR_ROWS);
         if (ix <= 32767 && runs <= 32767 && lds <= 60 * 1024 && groups < (1ll << 31) && !getenv("DLV_RESAMPLE_RUN16")) {
             const int aligned = (ox % 16 == 0) && ((reinterpret_cast<unsigned long long>(out_dev) & 15ull) == 0);
-            short2* runk;
-            DLV_TRY(dlv_ws_get(ctx, WS_MISC, (size_t)runs * sizeof(short2), (void**)&runk));
-            hipLaunchKernelGGL(zoom_run_table_kernel, dim3((runs + 255) / 256), dim3(256), 0, ctx->stream, runk, ix, ox, sc.x);
+            char* wsp;
+            const size_t runk_b = ((size_t)runs * sizeof(short2) + 31) & ~(size_t)31;
+            DLV_TRY(dlv_ws_get(ctx, WS_MISC, runk_b + (size_t)(ox + oy) * sizeof(TapsRow), (void**)&wsp));
+            short2* runk = reinterpret_cast<short2*>(wsp);
+            TapsRow* xt = reinterpret_cast<TapsRow*>(wsp + runk_b);
+            TapsRow* yt = xt + ox;
+            hipLaunchKernelGGL(zoom_run_table_kernel, dim3((std::max(runs, ox + oy) + 255) / 256), dim3(256), 0, ctx->stream, runk, ix, ox, sc.x,
+                               xt, yt, iy, oy, sc.y);
             hipLaunchKernelGGL(zoom_spline2_u8_rows_kernel, dim3((unsigned)groups), dim3(256), lds, ctx->stream, in_dev, iz, iy, ix,
-                               out_dev, oz, oy, ox, sc, aligned, runk, nrows_max);
+                               out_dev, oz, oy, ox, sc, aligned, runk, nrows_max, xt, yt);
         } else {
             hipLaunchKernelGGL(zoom_spline2_u8_run16_kernel, dim3(grid_for((long long)oz * oy * ((ox + 15) / 16))), dim3(256), 0,
                                ctx->stream, in_dev, iz, iy, ix, out_dev, oz, oy, ox, sc);
