@@ -195,6 +195,21 @@ __global__ void __launch_bounds__(256) fill_add_kernel(const int* __restrict__ s
     const int b = blockIdx.y;
     const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
     const long long n = (long long)d * h * w;
+    // the plain case (constant weights, no count map: 8 B of read-modify-write per window voxel, 5400 windows per C3 pass): four
+    // voxels per thread as one 16-byte non-temporal word, 32-bit row arithmetic
+    if (!cnt && !bw && !wsum && value != 0.f && w % 4 == 0 && Xp % 4 == 0 && x0 % 4 == 0 && (reinterpret_cast<uintptr_t>(acc) & 15) == 0 &&
+        n < (1ll << 31)) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const unsigned w4 = (unsigned)w / 4u, n4 = (unsigned)(n / 4);
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+            const unsigned xq = i % w4, r = i / w4, yy = r % (unsigned)h, zz = r / (unsigned)h;
+            f4_t* p = reinterpret_cast<f4_t*>(acc + ((long long)(z0 + (int)zz) * Yp + (y0 + (int)yy)) * Xp + x0 + 4 * (int)xq);
+            f4_t v = __builtin_nontemporal_load(p);
+            v += value;
+            __builtin_nontemporal_store(v, p);
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int xx = (int)(i % w), yy = (int)((i / w) % h), zz = (int)(i / ((long long)w * h));
         const long long o = ((long long)(z0 + zz) * Yp + (y0 + yy)) * Xp + (x0 + xx);
