@@ -239,13 +239,19 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         uint16_t* wh16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         uint16_t* ww = (i > 0 && cin[i] == 32 && cout[i] % 32 == 0) ? (uint16_t*)take((size_t)cout[i] * cin[i] * 36 * 2) : nullptr;
         // conv 16 = upcat_1.conv_0 when its inputs are a 32-channel skip + the 32 channels of a 32->32 transposed conv
-        const bool fold = (i == 16 && cin[i] == 64 && cout[i] == 32 && dcin[3] == 32 && dcout[3] == 32);
+        // ... and conv 14 = upcat_2.conv_0 (32-channel skip + the 32 channels of a 64->32 transposed conv): the same fold with the
+        // coarse tensor's 64 input channels as two 32-channel K-slices (two packs, two correction tables, two addends)
+        const int slices = (i == 16 && cin[i] == 64 && cout[i] == 32 && dcin[3] == 32 && dcout[3] == 32)   ? 1
+                           : (i == 14 && cin[i] == 64 && cout[i] == 32 && dcin[2] == 64 && dcout[2] == 32) ? 2
+                                                                                                           : 0;
+        const bool fold = slices > 0;
         uint16_t* wsb = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
         uint16_t* wsh = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
-        uint16_t* wub = fold ? (uint16_t*)take((size_t)2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
-        uint16_t* wuh = fold ? (uint16_t*)take((size_t)2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
-        float* ucr = fold ? (float*)take((size_t)8 * 8 * 32 * 4) : nullptr;
+        uint16_t* wub = fold ? (uint16_t*)take((size_t)slices * 2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
+        uint16_t* wuh = fold ? (uint16_t*)take((size_t)slices * 2 * 2 * 4 * 8 * 64 * 8 * 2) : nullptr;
+        float* ucr = fold ? (float*)take((size_t)slices * 8 * 8 * 32 * 4) : nullptr;
         if (base) {
+            ctx->conv[i].up_slices = slices;
             ctx->conv[i].wskip_bf16 = wsb;
             ctx->conv[i].wskip_f16 = wsh;
             ctx->conv[i].wup_bf16 = wub;
@@ -333,7 +339,8 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
     ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
     ctx->upconv_simple = getenv("DLV_UPCONV_SIMPLE") ? 1 : 0;
     ctx->upconv_dbg = getenv("DLV_UPCONV_DBG") ? atoi(getenv("DLV_UPCONV_DBG")) : 0;
-    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;        // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
+    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;
+    ctx->fold_up2 = getenv("DLV_UPCONV2") ? 1 : 0;  // opt-in: measured break-even (profiles/README.md)        // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return DLV_EHIP;

@@ -44,6 +44,7 @@ struct DlvConvLayer {
     uint16_t* wup_bf16 = nullptr;
     uint16_t* wup_f16 = nullptr;
     float* up_corr = nullptr;
+    int up_slices = 0;          // 32-channel K-slices of the folded transposed conv (1: upcat_1, 2: upcat_2): packs / corr tables are consecutive
     uint16_t* wwino_f16 = nullptr; // Winograd F(2,3)-x transformed weights, 36 fragments per 16 couts (conv_zwino.hip); Cin 32 only
 };
 struct DlvDeconvLayer {
@@ -106,6 +107,8 @@ struct dlv_ctx {
     float* blend_wsum = nullptr;
     int upconv_dbg = 0;         // DLV_UPCONV_DBG (diagnostic timing only, WRONG results): 1 = no stores, 2 = no halo loads
     int upconv_simple = 0;      // DLV_UPCONV_SIMPLE=1: the one-tile-per-workgroup upconv kernel for every shape (A/B, tests)
+    int fold_up2 = 0;           // ... and of upcat_2 (two K-slices, two launches, two addends): opt-in with DLV_UPCONV2=1 - measured
+                                // break-even (448 us unfolded, 239 + 2 x 88 us folded per 16 windows)
     int fold_up = 1;            // fold the transposed conv into the first conv of upcat_1 (upconv.hip); DLV_NO_UPCONV=1: A/B, the unfolded path
     int conv_algo = 0;          // dlv_set_conv_algo: 0 direct (default), 1 Winograd F(2,3) along x for the fp16 Cin-32 convs of levels 0/1
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
@@ -233,13 +236,15 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
 // InstanceNorm scale/shift of the layer that produced in1 / in2 (applied with Mish while staging) or nullptr
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,
                           int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
-                          int* nparts, const void* addend = nullptr);
+                          int* nparts, const void* addend = nullptr, const void* addend2 = nullptr);
 int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin, int ctot = 0, int c0 = 0);
 // folded up half of an UpCat block's first conv (upconv.hip): Weff / corr from the conv's and the transposed conv's fp32
 // tensors; P = conv3(up-sampled tensor) - const, computed from the ACTIVATED coarse tensor
-int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr);
+int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr,
+                    int ci0 = 0, int with_corr = 1);
 bool dlv_upconv2_persistent(const dlv_ctx* ctx, int Dc, int Hc, int Wc);
-int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, const float* corr, void* out, int B, int Dc, int Hc, int Wc);
+int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, const float* corr, void* out, int B, int Dc, int Hc, int Wc,
+                       int cstride = 4, int c0 = 0);
 bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
 // range guard of the 16-bit formats (unet_bf16.hip): reset before a pass / forward, check after it (synchronises the stream)
 int dlv_range_reset(dlv_ctx* ctx);

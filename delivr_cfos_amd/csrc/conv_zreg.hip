@@ -54,7 +54,7 @@ bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W) {
 // output).  Returns the number of partial-sum rows per sample in *nparts.
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,
                           int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
-                          int* nparts, const void* addend) {
+                          int* nparts, const void* addend, const void* addend2) {
     if (!dlv_conv3_zreg_supports(cin, cout, c1, c2, W))
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: needs Cout %% 32 == 0, W >= 32 and inputs of 32, 32+32 or 64 channels");
     if (addend && (cin != 32 || ss1 != nullptr)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: an addend needs Cin 32 and a final input");
@@ -86,11 +86,15 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     DLV_TRY(dlv_ws_get(ctx, WS_MISC, 65536, (void**)&trash));
     static const int dbg = getenv("DLV_ZREG_DBG") ? atoi(getenv("DLV_ZREG_DBG")) : 0;  // development: 1 = no interior steps
     ZrArgs a;
-    a.in1 = in1; a.ss1 = ss1; a.in2 = in2; a.ss2 = ss2; a.wpk16 = wpk16; a.addend = addend;
+    a.in1 = in1; a.ss1 = ss1; a.in2 = in2; a.ss2 = ss2; a.wpk16 = wpk16; a.addend = addend; a.addend2 = addend2;
     a.out = out; a.partials = partials; a.trash = trash;
     a.c1_8 = c1 / 8; a.c2_8 = c2 / 8; a.D = D; a.H = H; a.W = W; a.tilesX = tilesX; a.zseg = zseg; a.nseg = nseg; a.cout8 = cout / 8;
     a.dbg = dbg;
     a.gx = (unsigned)(tilesY * tilesX); a.gy = (unsigned)(nseg * ncb); a.gz = (unsigned)B;
+    if (addend && addend2) {
+        if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_add2(ctx, a) : dlv_zr_f16_c32_t8_add2(ctx, a);
+        return tyt == 16 ? dlv_zr_bf16_c32_t16_add2(ctx, a) : dlv_zr_bf16_c32_t8_add2(ctx, a);
+    }
     if (addend) {
         if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_add(ctx, a) : dlv_zr_f16_c32_t8_add(ctx, a);
         return tyt == 16 ? dlv_zr_bf16_c32_t16_add(ctx, a) : dlv_zr_bf16_c32_t8_add(ctx, a);

@@ -1285,29 +1285,34 @@ struct Net16 {
     // is conv `li` (the first conv of an UpCat block) run as skip-half conv + folded up half?
     bool folds_up(int li, int cskip, Dims d) const {
         const DlvConvLayer& L = ctx->conv[li];
-        return ctx->fold_up && L.up_corr != nullptr && cskip == 32 && (ctx->zm_variant == 0 || ctx->zm_variant == 50) && !ctx->no_zmarch &&
-               d.vox() > 32768 && dlv_conv3_zreg_supports(32, L.cout, 32, 0, d.W) && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0;
+        if (!(ctx->fold_up && L.up_corr != nullptr && cskip == 32 && (ctx->zm_variant == 0 || ctx->zm_variant == 50) && !ctx->no_zmarch &&
+              d.vox() > 32768 && dlv_conv3_zreg_supports(32, L.cout, 32, 0, d.W) && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0))
+            return false;
+        // two K-slices (upcat_2): only the persistent kernel takes a chunk offset into a wider coarse tensor
+        return L.up_slices == 1 || (ctx->fold_up2 && dlv_upconv2_persistent(ctx, d.D / 2, d.H / 2, d.W / 2));
     }
-    int conv_folded(int li, Act& sk, Act& coarse, uint4* pbuf, uint4* out, Dims d, Dims dc) {
+    int conv_folded(int li, Act& sk, Act& coarse, uint4* pbuf, uint4* pbuf2, uint4* out, Dims d, Dims dc) {
         const DlvConvLayer& L = ctx->conv[li];
         DLV_TRY(materialise(coarse, dc));  // the folded weights multiply the ACTIVATED coarse tensor
         DLV_TRY(materialise(sk, d));
-        {
+        if (coarse.C != 32 * L.up_slices) return dlv_fail(ctx, DLV_ESTATE, "folded conv %d: %d coarse channels, %d slices", li, coarse.C, L.up_slices);
+        for (int sl = 0; sl < L.up_slices; ++sl) {
             DLV_TRY(use(DLV_K_MFMA, d));
             char nm[48];
             snprintf(nm, sizeof(nm), "upconv2%s_%s_c32x32_d%d", dlv_upconv2_persistent(ctx, dc.D, dc.H, dc.W) ? "m" : "", P::IS_F16 ? "f16" : "bf16", dc.D);
             DlvProf pr(ctx, nm, 2.0 * 8 * 32 * 32 * (double)d.vox() * B, 2.0 * 32 * ((double)dc.vox() + (double)d.vox()) * B);
-            DLV_TRY(dlv_upconv2_launch(ctx, P::IS_F16, coarse.p, P::IS_F16 ? L.wup_f16 : L.wup_bf16, L.up_corr, pbuf, B, dc.D, dc.H, dc.W));
+            DLV_TRY(dlv_upconv2_launch(ctx, P::IS_F16, coarse.p, (P::IS_F16 ? L.wup_f16 : L.wup_bf16) + (size_t)sl * (2 * 2 * 4 * 8 * 64 * 8),
+                                       L.up_corr + (size_t)sl * (8 * 8 * 32), sl == 0 ? pbuf : pbuf2, B, dc.D, dc.H, dc.W, coarse.C / 8, 4 * sl));
             pr.end();
         }
         char zname[48];
-        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add", P::IS_F16 ? "f16" : "bf16", L.cout, d.D);
-        DlvProf zp(ctx, zname, 2.0 * 27 * 32 * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (32 + 2 * L.cout));
+        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add%s", P::IS_F16 ? "f16" : "bf16", L.cout, d.D, L.up_slices == 2 ? "2" : "");
+        DlvProf zp(ctx, zname, 2.0 * 27 * 32 * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (32 + (1 + L.up_slices) * L.cout));
         int np = 0;
         if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
             return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zreg)");
         DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, 32, L.cout, sk.p, 32, nullptr, nullptr, 0, nullptr, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, out,
-                                      partials, B, d.D, d.H, d.W, &np, pbuf));
+                                      partials, B, d.D, d.H, d.W, &np, pbuf, L.up_slices == 2 ? pbuf2 : nullptr));
         zp.end();
         return stats(np, li, d);
     }
@@ -1619,7 +1624,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         if (net.folds_up(li, skip[l].C, dm[l])) {
             // upcat_1: the transposed conv folded into the conv (upconv.hip): P from the activated coarse tensor, then the
             // 32-channel conv of the skip half with P as its addend - no up-sampled tensor, 8 coarse taps instead of 27 fine ones
-            DLV_TRY(net.conv_folded(li, skip[l], cur, buf(l, U), b.p, dm[l], dm[l + 1]));
+            DLV_TRY(net.conv_folded(li, skip[l], cur, buf(l, U), buf(l, A), b.p, dm[l], dm[l + 1]));  // (A: the next conv's output, free until then)
         } else {
             DLV_TRY(net.deconv(j, cur, buf(l, U), dm[l + 1]));
             Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
@@ -1661,10 +1666,13 @@ int pack_weights_16(dlv_ctx* ctx) {
         DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
         DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cout, L.cin));
         if (P::IS_F16 && L.wwino_f16) DLV_TRY(dlv_pack_conv_wino(ctx, L.w_f32, L.wwino_f16, L.cout, L.cin));
-        if (L.up_corr) {  // upcat_1.conv_0: skip half as a 32-channel pack, up half folded with the transposed conv (upconv.hip)
-            const DlvDeconvLayer& Dl = ctx->deconv[DLV_N_DECONV - 1];
+        if (L.up_corr) {  // upcat_1 / upcat_2 .conv_0: skip half as a 32-channel pack, up half folded with the transposed conv (upconv.hip)
+            const DlvDeconvLayer& Dl = ctx->deconv[i == 16 ? 3 : 2];
             DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, L.cout, 32, L.cin, 0));
-            DLV_TRY(dlv_pack_upconv(ctx, P::IS_F16, L.w_f32, L.cin, 32, Dl.w_f32, Dl.bias, P::IS_F16 ? L.wup_f16 : L.wup_bf16, L.up_corr));
+            for (int sl = 0; sl < L.up_slices; ++sl)  // 32 input channels of the transposed conv per pack; the bias terms in the first table
+                DLV_TRY(dlv_pack_upconv(ctx, P::IS_F16, L.w_f32, L.cin, 32, Dl.w_f32, Dl.bias,
+                                        (P::IS_F16 ? L.wup_f16 : L.wup_bf16) + (size_t)sl * (2 * 2 * 4 * 8 * 64 * 8), L.up_corr + (size_t)sl * (8 * 8 * 32),
+                                        32 * sl, sl == 0 ? 1 : 0));
         }
     }
     for (int j = 0; j < DLV_N_DECONV; ++j) {

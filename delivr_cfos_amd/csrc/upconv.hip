@@ -35,12 +35,14 @@ constexpr int UC_HZ = UC_TZ + 2, UC_HY = UC_TY + 2, UC_HX = UC_TX + 2;
 constexpr int UC_CS = ((UC_HZ * UC_HY * UC_HX + 15) / 16) * 16;  // chunk stride (uint4): a multiple of 16 keeps the 16-lane groups apart
 
 // Weff / corr from the fp32 checkpoint tensors.  wc: (Cout, Ctot, 27) of the conv, wd: (Cin, Cup, 8) of the transposed conv, bd: (Cup).
+// One pack covers 32 input channels [ci0, ci0 + 32) of the transposed conv: a 64-channel coarse tensor (upcat_2) is two packs, two
+// launches and two addends (linearity in the input channels).
 // out A-fragments: [pz][half][pyx 4][tap 8][lane 64][8]:  cout = half*16 + (lane & 15), cin = 8*(lane >> 4) + j, tap = (dz*2 + dy)*2 + dx
 // corr: [p 8][mask 8][cout 32] = - sum over the taps d that leave the window under `mask` (bit 2: z, 1: y, 0: x; the tap that
 // leaves is index 0 on an even, index 1 on an odd coordinate)  of  sum_{t -> d} sum_c' Wc[co][Cs+c'][t] bd[c']
 template <class P>
 __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int cs, const float* __restrict__ wd, const float* __restrict__ bd,
-                                   uint16_t* __restrict__ wpk, float* __restrict__ corr) {
+                                   uint16_t* __restrict__ wpk, float* __restrict__ corr, int ci0, int with_corr) {
     const int cup = 32, cin = 32;
     // taps of one axis that map (parity p) to coarse index i: t in {-1,0,1} with floor((p + t) / 2) + 1 - p == i
     auto maps = [](int p, int t, int i) { return ((p + t + 2) >> 1) - 1 + 1 - p == i; };
@@ -57,7 +59,7 @@ __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int c
                     const int t = ((tz + 1) * 3 + (ty + 1)) * 3 + (tx + 1);
                     const int par = (((p[0] + tz) & 1) * 2 + ((p[1] + ty) & 1)) * 2 + ((p[2] + tx) & 1);
                     for (int c = 0; c < cup; ++c)
-                        s = __fmaf_rn(wc[((long long)co * ctot + cs + c) * 27 + t], wd[((long long)ci * cup + c) * 8 + par], s);
+                        s = __fmaf_rn(wc[((long long)co * ctot + cs + c) * 27 + t], wd[((long long)(ci0 + ci) * cup + c) * 8 + par], s);
                 }
         wpk[e] = (uint16_t)(P::pack2(s, 0.f) & 0xffffu);
     }
@@ -78,13 +80,13 @@ __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int c
                     const int t = ((tz + 1) * 3 + (ty + 1)) * 3 + (tx + 1);
                     for (int c = 0; c < cup; ++c) s = __fmaf_rn(wc[((long long)co * ctot + cs + c) * 27 + t], bd[c], s);
                 }
-        corr[e] = -s;
+        corr[e] = with_corr ? -s : 0.f;  // (a later K-slice of the same transposed conv: the bias terms are in the first slice's table)
     }
 }
 
 template <class P>
 __global__ void __launch_bounds__(256) upconv2_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ corr,
-                                                      uint4* __restrict__ out, int Dc, int Hc, int Wc, int tilesY, int tilesX) {
+                                                      uint4* __restrict__ out, int Dc, int Hc, int Wc, int tilesY, int tilesX, int cstride, int c0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char uc_smem[];
     uint4* tile = reinterpret_cast<uint4*>(uc_smem);  // [4 chunks][UC_CS]: halo tile of the activated coarse tensor
     // the face corrections come from LDS: a global load inside the loop would wait (vmcnt counts stores too) for every store the
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(256) upconv2_kernel(const uint4* __restrict__ 
             v[it] = make_uint4(0u, 0u, 0u, 0u);
             dst[it] = i < NEL ? c * UC_CS + (zh * UC_HY + yh) * UC_HX + xh : -1;
             if (i < NEL && (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc)
-                v[it] = in[((long long)n * 4 + c) * voxc + ((long long)gz * Hc + gy) * Wc + gx];
+                v[it] = in[((long long)n * cstride + c0 + c) * voxc + ((long long)gz * Hc + gy) * Wc + gx];
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
@@ -246,7 +248,7 @@ __device__ __forceinline__ void um_mfma(f32x4& acc, const u32x4& w, const u32x4&
 template <class P>
 __global__ void __launch_bounds__(256, 1)
 upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ corr, uint4* __restrict__ out,
-                int Dc, int Hc, int Wc, int tilesY, int tilesX, int tilesWin, int total, int dbg) {
+                int Dc, int Hc, int Wc, int tilesY, int tilesX, int tilesWin, int total, int dbg, int cstride, int c0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char uc_smem[];
     u32x4* const lds = reinterpret_cast<u32x4*>(uc_smem);                 // two halo tiles [4 chunks][UC_CS]
     float* const corr_l = reinterpret_cast<float*>(lds + 8 * UC_CS);      // [p 8][mask 8][32]
@@ -298,7 +300,7 @@ upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, con
     // staging of tile `a` (this wave's chunk): resource over the chunk, offset of the tile's first halo voxel (may be "negative":
     // 32-bit wrap-around, the lanes it would send below the chunk are exactly the ones the face mask turns into zeros)
     auto stage_rsrc = [&](const TileAt& a) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(in + ((long long)a.n * 4 + wave) * voxc)), 0,
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(in + ((long long)a.n * cstride + c0 + wave) * voxc)), 0,
                                                  (dbg & 2) ? 0 : voxc * 16, 0x00020000);  // (dbg: timing-only builds of profiles/upconv_ab.py - a resource of zero records drops every access)
     };
     auto stage_base = [&](const TileAt& a) __attribute__((always_inline)) {
@@ -445,11 +447,12 @@ upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, con
 
 }  // namespace
 
-int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr) {
+int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr, int ci0,
+                    int with_corr) {
     if (f16)
-        hipLaunchKernelGGL(pack_upconv_kernel<PF16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr);
+        hipLaunchKernelGGL(pack_upconv_kernel<PF16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr);
     else
-        hipLaunchKernelGGL(pack_upconv_kernel<PBf16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr);
+        hipLaunchKernelGGL(pack_upconv_kernel<PBf16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr);
     DLV_LAUNCH_CHECK(ctx, "pack_upconv_kernel");
     return DLV_OK;
 }
@@ -461,8 +464,10 @@ bool dlv_upconv2_persistent(const dlv_ctx* ctx, int Dc, int Hc, int Wc) {
            ((long long)(UC_HZ - 1) * Hc + UC_HY) * Wc * 16 < (1 << 24) && voxc * 8 * 16 * 2 < (1LL << 31);
 }
 
-// in: activated coarse tensor (B, 32 ch, Dc, Hc, Wc) chunk-planar; out: P (B, 32 ch, 2Dc, 2Hc, 2Wc)
-int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, const float* corr, void* out, int B, int Dc, int Hc, int Wc) {
+// in: activated coarse tensor (B, 8 * cstride ch, Dc, Hc, Wc) chunk-planar, of which the four chunks from c0 are this launch's 32
+// input channels; out: P (B, 32 ch, 2Dc, 2Hc, 2Wc)
+int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, const float* corr, void* out, int B, int Dc, int Hc, int Wc,
+                       int cstride, int c0) {
     if (Wc % 2 || Dc <= 0 || Hc <= 0 || Wc <= 0) return dlv_fail(ctx, DLV_EUNSUP, "upconv: even coarse width expected");
     const int tilesX = dlv_cdiv(Wc, UC_TX), tilesY = dlv_cdiv(Hc, UC_TY), tilesZ = dlv_cdiv(Dc, UC_TZ);
     if (dlv_upconv2_persistent(ctx, Dc, Hc, Wc)) {
@@ -481,14 +486,14 @@ int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, 
                 dlv_attr_mark(mattr_f16, ctx->device);
             }
             hipLaunchKernelGGL(upconv2m_kernel<PF16>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4*)in, (const uint4*)wpk, corr, (uint4*)out,
-                               Dc, Hc, Wc, tilesY, tilesX, tilesWin, total, ctx->upconv_dbg);
+                               Dc, Hc, Wc, tilesY, tilesX, tilesWin, total, ctx->upconv_dbg, cstride, c0);
         } else {
             if (!dlv_attr_is_set(mattr_bf16, ctx->device)) {
                 DLV_HIP(ctx, hipFuncSetAttribute((const void*)upconv2m_kernel<PBf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 dlv_attr_mark(mattr_bf16, ctx->device);
             }
             hipLaunchKernelGGL(upconv2m_kernel<PBf16>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4*)in, (const uint4*)wpk, corr, (uint4*)out,
-                               Dc, Hc, Wc, tilesY, tilesX, tilesWin, total, ctx->upconv_dbg);
+                               Dc, Hc, Wc, tilesY, tilesX, tilesWin, total, ctx->upconv_dbg, cstride, c0);
         }
         DLV_LAUNCH_CHECK(ctx, "upconv2m_kernel");
         return DLV_OK;
@@ -501,14 +506,14 @@ int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, 
             dlv_attr_mark(attr_f16, ctx->device);
         }
         hipLaunchKernelGGL(upconv2_kernel<PF16>, dim3(tilesX * tilesY * tilesZ, 1, B), dim3(256), lds, ctx->stream, (const uint4*)in,
-                           (const uint4*)wpk, corr, (uint4*)out, Dc, Hc, Wc, tilesY, tilesX);
+                           (const uint4*)wpk, corr, (uint4*)out, Dc, Hc, Wc, tilesY, tilesX, cstride, c0);
     } else {
         if (!dlv_attr_is_set(attr_bf16, ctx->device)) {
             DLV_HIP(ctx, hipFuncSetAttribute((const void*)upconv2_kernel<PBf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             dlv_attr_mark(attr_bf16, ctx->device);
         }
         hipLaunchKernelGGL(upconv2_kernel<PBf16>, dim3(tilesX * tilesY * tilesZ, 1, B), dim3(256), lds, ctx->stream, (const uint4*)in,
-                           (const uint4*)wpk, corr, (uint4*)out, Dc, Hc, Wc, tilesY, tilesX);
+                           (const uint4*)wpk, corr, (uint4*)out, Dc, Hc, Wc, tilesY, tilesX, cstride, c0);
     }
     DLV_LAUNCH_CHECK(ctx, "upconv2_kernel");
     return DLV_OK;

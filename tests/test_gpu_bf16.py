@@ -437,20 +437,20 @@ def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, sh
 
     engs = {}
     try:
-        for tag, env in (("folded", {}), ("simple", {"DLV_UPCONV_SIMPLE": "1"}), ("unfolded", {"DLV_NO_UPCONV": "1"})):
-            for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
+        for tag, env in (("folded", {}), ("simple", {"DLV_UPCONV_SIMPLE": "1"}), ("unfolded", {"DLV_NO_UPCONV": "1"}), ("folded2", {"DLV_UPCONV2": "1"})):
+            for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV", "DLV_UPCONV2"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             e = HipEngine(0)
             e.load_state_dict({"state_dict": net.state_dict()})
             engs[tag] = e
     finally:
-        for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
+        for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV", "DLV_UPCONV2"):
             os.environ.pop(k, None)
     vol = synth_volume_np(shape, seed=13, dense=True)
     dvol = engs["folded"].to_device(vol)
     out, ran = {}, {}
-    for tag, p in (("fp32", "fp32"), ("folded", prec), ("simple", prec), ("unfolded", prec)):
+    for tag, p in (("fp32", "fp32"), ("folded", prec), ("simple", prec), ("unfolded", prec), ("folded2", prec)):
         e = engs["folded" if tag == "fp32" else tag]
         acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
         e.prof_reset()
@@ -466,9 +466,13 @@ def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, sh
     assert any(k.startswith("upconv2_") for k in ran["simple"]) and not any(k.startswith("upconv2m") for k in ran["simple"]), ran["simple"]
     assert not any(k.startswith("upconv") for k in ran["unfolded"]) and any(k.startswith("deconv2") for k in ran["unfolded"]), ran["unfolded"]
     assert not any(k.endswith("_add") for k in ran["unfolded"]) and any(k.endswith("_add") for k in ran["folded"])
+    # the opt-in fold of upcat_2 (DLV_UPCONV2=1: two K-slices of the 64-channel coarse tensor, two addends) wherever its level-1
+    # shapes take the persistent kernel
+    lvl1_persistent = all(v % m == 0 for v, m in zip(roi, (16, 32, 64))) and roi[0] * roi[1] * roi[2] // 8 > 32768  # (z-reg convs from 32^3 up)
+    assert any(k.endswith("_add2") for k in ran["folded2"]) == lvl1_persistent, ran["folded2"]
     std = float(out["fp32"].std())
-    rel = {t: float(np.sqrt(np.mean((out[t] - out["fp32"]) ** 2)) / std) for t in ("folded", "simple", "unfolded")}
-    between = {t: float(np.sqrt(np.mean((out[t] - out["unfolded"]) ** 2)) / std) for t in ("folded", "simple")}
+    rel = {t: float(np.sqrt(np.mean((out[t] - out["fp32"]) ** 2)) / std) for t in ("folded", "simple", "unfolded", "folded2")}
+    between = {t: float(np.sqrt(np.mean((out[t] - out["unfolded"]) ** 2)) / std) for t in ("folded", "simple", "folded2")}
     kernels = float(np.sqrt(np.mean((out["folded"] - out["simple"]) ** 2)) / std)
     print(prec, roi, "vs fp32:", rel, "vs unfolded:", between, "persistent vs one-tile kernel:", kernels)
     tol32, tol16 = (1e-2, 2e-3) if prec == "fp16" else (5e-2, 2e-2)

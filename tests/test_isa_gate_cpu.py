@@ -60,7 +60,7 @@ def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd()
     rep = hs.library_report(LIB)
     wino = {k: v for k, v in rep.items() if "zwino" in k}
     rep = {k: v for k, v in rep.items() if "zwino" not in k}
-    assert len(rep) == 14, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with addend; Cin 64: t8 a0/a1)
+    assert len(rep) == 18, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with one and with two addends; Cin 64: t8 a0/a1)
     assert len(wino) == 1, sorted(wino)  # the opt-in Winograd F(2,3)-x variant: 36 weight fragments = 144 AGPRs
     for name, r in wino.items():
         assert r["hazards"] == 0 and r["readback_hazards"] == 0, (name, r["first"], r["first_readback"])
