@@ -270,3 +270,35 @@ def test_bf16_meets_the_north_star_tolerance_on_margin_free_logits(eng, crop, tt
     rep = flip_report(mask, ref["mask"], ref["mean"])
     print(f"bf16 vs reference arithmetic ({'13 passes' if tta else '1 pass'}): IoU {rep['iou']:.5f}, {rep['flipped']} flipped voxels")
     assert rep["iou"] >= 0.999, rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_pass_is_bitwise_repeatable_on_three_lanes(prec):
+    """The same pass six times on the default three lanes (batches of several 128^3 windows; the persistent upconv kernel's
+    LDS-DMA staging, counted vmcnt and tile walk, the non-temporal streams, the lane joins): every repetition must give the
+    same bits - a race in any of them would show up as a difference between two runs."""
+    import numpy as np
+    import torch
+
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_torch
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    try:
+        eng.load_state_dict({"state_dict": random_state_dict(5)})
+        shape = (256, 256, 384)
+        vol = synth_volume_torch(shape, 4, eng.device, dense=True)
+        ref = None
+        for rep in range(6):
+            acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+            eng.sw_infer(eng.make_sw_params(shape, (128, 128, 128), 0.5, None, 0, prec, sw_batch=5), vol, acc)
+            eng.sync()
+            if ref is None:
+                ref = acc.clone()
+                assert torch.isfinite(ref).all() and float(ref.std()) > 0
+            else:
+                assert torch.equal(acc, ref), f"repetition {rep} differs in {int((acc != ref).sum())} voxels"
+    finally:
+        eng.close()
