@@ -338,7 +338,9 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
 #endif
     ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
     ctx->upconv_simple = getenv("DLV_UPCONV_SIMPLE") ? 1 : 0;
+#ifdef DLV_DIAG  // timing-only ablations (WRONG results): the diagnostic library only (make diag), never the product
     ctx->upconv_dbg = getenv("DLV_UPCONV_DBG") ? atoi(getenv("DLV_UPCONV_DBG")) : 0;
+#endif
     ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;
     ctx->fold_up2 = getenv("DLV_UPCONV2") ? 1 : 0;  // opt-in: measured break-even (profiles/README.md)        // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
     if (hipSetDevice(device_id) != hipSuccess) {

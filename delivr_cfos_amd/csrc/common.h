@@ -105,7 +105,7 @@ struct dlv_ctx {
     const float* blend_w = nullptr;
     float blend_min = 0.f;
     float* blend_wsum = nullptr;
-    int upconv_dbg = 0;         // DLV_UPCONV_DBG (diagnostic timing only, WRONG results): 1 = no stores, 2 = no halo loads
+    int upconv_dbg = 0;         // DLV_UPCONV_DBG, diagnostic library only (timing, WRONG results): 1 = no stores, 2 = no halo loads
     int upconv_simple = 0;      // DLV_UPCONV_SIMPLE=1: the one-tile-per-workgroup upconv kernel for every shape (A/B, tests)
     int fold_up2 = 0;           // ... and of upcat_2 (two K-slices, two launches, two addends): opt-in with DLV_UPCONV2=1 - measured
                                 // break-even (448 us unfolded, 239 + 2 x 88 us folded per 16 windows)

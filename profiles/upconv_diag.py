@@ -1,6 +1,7 @@
 """Where the time of the persistent upconv kernel goes: the same forward set with its stores and/or halo loads dropped
 (DLV_UPCONV_DBG: a buffer resource of zero records - the instruction stream stays), and the simple kernel beside it.
-Timing only: the results of the dbg engines are wrong by construction.
+Timing only: the results of the dbg engines are wrong by construction, and only the DIAGNOSTIC library reads the switch:
+    make -C delivr_cfos_amd/csrc diag && DLV_LIB=libdelivr_hip_diag.so python profiles/upconv_diag.py
 usage: python profiles/upconv_diag.py [Z,Y,X default 256,256,512]"""
 import os
 import sys
