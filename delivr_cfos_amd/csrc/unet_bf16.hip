@@ -1637,7 +1637,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         cur = o;
     }
     {
-        dim3 grid(std::min(net.grid1d(dm[0].vox()), 1024), B);  // (8 iterations per thread at 128^3: the software pipeline's depth)
+        dim3 grid(std::min(net.grid1d(dm[0].vox()), 512), B);  // (16 iterations per thread at 128^3 - the software pipeline wants a long loop: 1024 / 512 / 256 workgroups 515 / 487 / 484 us)
         DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
