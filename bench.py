@@ -4,10 +4,12 @@
     python bench.py --gpus 1 --steps 2 --warmup 1            # one MI355X
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W   # N ranks, RCCL over xGMI
+    python bench.py --gpus N ...                              # the same: spawns that launch line as a child process
 
 One "step" = ONE sliding-window pass (no TTA) over the whole volume, volume resident in HBM as
 uint16: tiler -> per-window background skip -> U-Net forward (16-bit MFMA operands, fp32 accumulate) -> fp32 overlap blend ->
-(N>1: seam exchange) -> threshold + L1-30 eroded re-mask -> uint8 mask (N>1: gathered on rank 0).
+(N>1: seam exchange) -> threshold + L1-30 eroded re-mask -> uint8 mask (N>1: it stays on the ranks as Z-slabs, the planes
+each rank owns; only the voxel count and checksum travel to rank 0).
 That is BASELINE.json's metric ("voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @
 1/2/4/8 GPU"); the volume and its window list are the same at every N, so scaling is "strong".
 
@@ -265,13 +267,33 @@ def main():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the contract's launch line as a CHILD process - before this
+        # process has imported torch or touched the GPU (a process that has initialised HIP must never exec or fork workers) -
+        # and relay its output and exit code
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU); see the docstring")
+    if args.gpus != world and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    # (device_count() does not initialise the GPU on this image)
+    ndev = torch.cuda.device_count()
+    if world > 1 and os.environ.get("DLV_BENCH_SAME_DEVICE") != "1" and ndev < world:
+        raise SystemExit(f"bench.py --gpus {world}: needs {world} devices, this box has {ndev} (one rank per GPU; "
+                         "DLV_BENCH_SAME_DEVICE=1 runs the ranks on cuda:0 over gloo as a functional check)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # functional check of the N>1 path on a single GPU: DLV_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
@@ -425,11 +447,14 @@ def main():
                           device=eng.device)
         if dist.get_backend() == "gloo":
             st, mask_sig = st.cpu(), mask_sig.cpu()
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, [int(st[0]), int(st[1])])  # (windows, of which skipped) of every rank's range
         dist.all_reduce(st)
         dist.all_reduce(mask_sig)
         n_windows, n_skipped = int(st[0]), int(st[1])
     else:
         n_windows, n_skipped = stats_last.get("n_windows", 0), stats_last.get("n_skipped", 0)
+        per_rank = None
     mask_voxels, mask_checksum = int(mask_sig[0]), int(mask_sig[1]) % CK_MOD
 
     if rank != 0:
@@ -466,14 +491,30 @@ def main():
         # (profiles/run_pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950
         # guide prescribes).  The passes ran the 512^3 workload (25k launches of C3 under PMC exceed the time limit): same
         # kernels, same batch of 16 windows per launch; a launch of another batch is scaled by algorithmic bytes.
+        # ... and only of THIS library: the JSON records the sha256 of the .so that ran under the counters and of its sources
+        # (profiles/make_traffic.py); when neither matches what is loaded now, `traffic` stays null and says why.
         try:
-            # (newest round first: the PMC passes are regenerated at the end of every round, profiles/run_r04.sh)
-            cands = [(f"traffic_{r}_{args.workload}.json", False) for r in ("r04", "r03")] + [(f"traffic_{r}_c2.json", True) for r in ("r04", "r03")]
+            from delivr_cfos_amd._lib import build_fingerprint
+
+            cands = [(f"traffic_r05_{args.workload}.json", False), ("traffic_r05_c2.json", True)]
             tfile, scaled = next(((os.path.join(ROOT, "profiles", n), sc) for n, sc in cands if os.path.isfile(os.path.join(ROOT, "profiles", n))),
-                                 (os.path.join(ROOT, "profiles", "traffic_r03_c2.json"), True))
-            if os.path.isfile(tfile) and args.sw_batch == 0:
+                                 (None, True))
+            if tfile is None:
+                r["traffic_note"] = "no PMC traffic file of this round under profiles/"
+            elif args.sw_batch != 0:
+                r["traffic_note"] = "non-default --sw-batch: the PMC passes ran the default batch"
+            else:
                 tj = json.load(open(tfile))
-                if name in tj["kernels"] and tj.get("precision") == args.precision:
+                fp_now, fp_then = build_fingerprint(), tj.get("fingerprint") or {}
+                same_lib = fp_then.get("lib_sha256") is not None and fp_then.get("lib_sha256") == fp_now["lib_sha256"]
+                same_src = fp_then.get("src_sha256") is not None and fp_then.get("src_sha256") == fp_now["src_sha256"]
+                if not (same_lib or same_src):
+                    r["traffic_note"] = (f"{os.path.relpath(tfile, ROOT)} was measured on another build (library sha256 "
+                                         f"{str(fp_then.get('lib_sha256'))[:12]}, sources {str(fp_then.get('src_sha256'))[:12]}; loaded: "
+                                         f"{str(fp_now['lib_sha256'])[:12]}, {str(fp_now['src_sha256'])[:12]}): regenerate with profiles/run_pmc_traffic.sh")
+                elif name not in tj["kernels"] or tj.get("precision") != args.precision:
+                    r["traffic_note"] = f"{os.path.relpath(tfile, ROOT)} holds no {args.precision} figure for {name}"
+                else:
                     k = tj["kernels"][name]
                     r["algorithmic_bytes"] = e["bytes"] / max(e["launches"], 1)
                     t = k["traffic_bytes"]
@@ -482,9 +523,11 @@ def main():
                     r["traffic"] = t
                     r["traffic_over_algorithmic"] = t / r["algorithmic_bytes"] if r["algorithmic_bytes"] else None
                     r["traffic_source"] = os.path.relpath(tfile, ROOT) + (
-                        " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "")
-        except Exception:
-            pass
+                        " (PMC run of the c2 workload, scaled by algorithmic bytes per launch)" if scaled else "") + (
+                        f"; same library sha256 {fp_now['lib_sha256'][:12]}" if same_lib else f"; same sources sha256 {fp_now['src_sha256'][:12]} (library rebuilt)") + (
+                        f"; git {tj.get('git_head')}" if tj.get("git_head") else "")
+        except Exception as ex:
+            r["traffic_note"] = f"traffic lookup failed: {ex}"
         r["lanes"] = lanes
         net_ms = sum(v["total_ms"] for v in prof.values())
         r["forward_tflops"] = (FLOP_PER_PATCH_VOXEL * tile_vox * n_active * steps_covered / (1e-3 * net_ms) / 1e12
@@ -602,7 +645,7 @@ def main():
                         f"1 pass (no TTA), {weights_name} BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
                         + (", dense (no background)" if args.dense else ", ellipsoid brain (background skipped)"),
             "volume_zyx": [Z, Y, X], "roi": list(roi), "overlap": 0.5,
-            "windows": n_windows, "windows_skipped": n_skipped,
+            "windows": n_windows, "windows_skipped": n_skipped, "per_rank_windows": per_rank,
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
             "patch_voxels_per_s": tile_vox * n_active / (elapsed / args.steps),
             "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),

@@ -59,7 +59,10 @@ def main(argv=None) -> int:
         brains = sorted(os.listdir(settings["raw_location"]))
         for i, brain in enumerate(brains):
             print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
-            if os.path.exists(os.path.join(settings["mask_detection"]["output_location"], brain)):
+            # (reference __main__.py:98: the step is done when masked_niftis exists - the brain's folder alone may hold only
+            # ilastik's output)
+            if os.path.exists(os.path.join(settings["mask_detection"]["output_location"], brain, "masked_niftis")):
+                print(f"{brain} exists, skipping...")
                 continue
             downsample_mask(settings, brain)
     if flags.get("BLOB_DETECTION"):

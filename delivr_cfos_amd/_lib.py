@@ -23,6 +23,36 @@ if os.environ.get("DLV_LIB"):
                           "to time it (profiles/tools/zreg_abl.sh does)")
     LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), _name)
 
+
+
+def build_fingerprint(lib_path: str | None = None) -> dict:
+    """What identifies the kernels a measurement ran on: sha256 of the shared library that is (or would be) loaded and of the
+    sources it is built from (csrc/*.hip, *.h, Makefile, include/*.h - a rebuild of the same sources may differ in bytes).
+    profiles/make_traffic.py stores it next to the PMC traffic figures, bench.py compares it with the loaded library."""
+    import glob
+    import hashlib
+
+    lib_path = lib_path or LIB_PATH
+    out = {"lib": os.path.basename(lib_path), "lib_sha256": None, "src_sha256": None}
+    if os.path.isfile(lib_path):
+        h = hashlib.sha256()
+        with open(lib_path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        out["lib_sha256"] = h.hexdigest()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")]
+                   + glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    h = hashlib.sha256()
+    for fn in files:
+        if os.path.isfile(fn):
+            h.update(os.path.basename(fn).encode() + b"\0")
+            with open(fn, "rb") as f:
+                h.update(f.read())
+    out["src_sha256"] = h.hexdigest()
+    return out
+
+
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP, DLV_ERANGE = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 N_CONV, N_DECONV = 18, 4

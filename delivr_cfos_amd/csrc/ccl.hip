@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(const uint8_t* __restrict
             L[c * 16 + k] = (u32)(c * 16 + k);
         }
         __syncthreads();
-        if (fill > CAP - 256) flush();  // (uniform: every thread reads the same value behind the barrier)
+        const u32 f = fill;  // every thread reads the value all adds of this iteration produced ...
+        __syncthreads();     // ... and nobody adds for the next iteration before everybody has read it: the decision is uniform
+        if (f > CAP - 256) flush();
     }
     flush();
 }

@@ -232,6 +232,10 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx);
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
                             const void* wpk, const float* bias, void* out, float* partials, int B, int D, int H, int W,
                             int* nparts);
+// deep-level conv (conv_deep.hip): LDS-shared weights, persistent workgroups; wpk16 = the 16-channel A-fragment pack
+bool dlv_conv3_deep_supports(int cin, int cout, int c1, int c2, int D, int H, int W);
+int dlv_conv3_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2, const void* wpk16,
+                          void* out, float* partials, int B, int D, int H, int W, int* nparts);
 // register-resident-weights z-march conv (conv_zreg.hip): Cout blocks of 32, Cin = 32, 32+32 or 64; ss1 / ss2 =
 // InstanceNorm scale/shift of the layer that produced in1 / in2 (applied with Mish while staging) or nullptr
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,

@@ -432,8 +432,11 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
             auto side = [&](int k) __attribute__((always_inline)) {
 #ifdef ZR_ABL  // timing-only ablation builds (WRONG results; `make abl`, never part of libdelivr_hip.so): bit 0 no barrier,
                // bit 1 no epilogue (statistics, pack, store), bit 2 no global loads of the plane after next, bit 3 no fragment
-               // reads, bit 4 no LDS writes of the next plane
+               // reads, bit 4 no LDS writes of the next plane, bit 5 / bit 6: 2 of 6 / 3 of 6 fragment reads dropped (the gate of a
+               // cout-complete wave layout, which would issue 0.6x the reads: profiles/README.md round 5)
                 if ((ZR_ABL & 8) && k < n_frag) return;
+                if ((ZR_ABL & 32) && k < n_frag && (k == 2 || k == 5)) return;
+                if ((ZR_ABL & 64) && k < n_frag && (k & 1)) return;
                 if ((ZR_ABL & 2) && k >= n_frag && k < n_frag + n_epi) return;
                 if ((ZR_ABL & 16) && k >= n_frag + n_epi && k <= n_frag + n_epi + n_act) return;
                 if ((ZR_ABL & 4) && k > n_frag + n_epi + n_act) return;

@@ -11,6 +11,7 @@
 // (tests on a one-GPU box) exchange with hipMemcpyAsync instead.  No all-reduce exists on this path: xGMI is
 // point-to-point, every seam crosses exactly one link.
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <cmath>
@@ -212,6 +213,36 @@ int dlv_shard_slab(const dlv_shard_plan* plan, int rank, int Z, int erode_iters,
     return DLV_OK;
 }
 
+// librccl.so for a host that is not a PyTorch process: (1) $DLV_RCCL_PATH, (2) a librccl that is already mapped into the
+// process (under torch it lives in torch/lib, which no loader path names), (3) $ROCM_PATH/lib (default /opt/rocm/lib), (4) the
+// soname through the loader's own search.  `tried` collects what was attempted for dlv_comm_last_error(NULL).
+static thread_local std::string g_comm_init_err;
+static int dlv_find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) {
+        *static_cast<std::string*>(out) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+static void* dlv_open_rccl(std::string& tried) {
+    tried.clear();
+    std::vector<std::string> cand;
+    if (const char* e = getenv("DLV_RCCL_PATH")) cand.push_back(e);
+    std::string mapped;
+    dl_iterate_phdr(dlv_find_mapped_rccl, &mapped);
+    if (!mapped.empty()) cand.push_back(mapped);
+    const char* rocm = getenv("ROCM_PATH");
+    cand.push_back(std::string(rocm && rocm[0] ? rocm : "/opt/rocm") + "/lib/librccl.so");
+    cand.push_back("librccl.so");
+    cand.push_back("librccl.so.1");
+    for (const std::string& p : cand) {
+        if (void* h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL)) return h;
+        const char* why = dlerror();
+        tried += (tried.empty() ? "librccl not loadable; tried: " : "; ") + p + " (" + (why ? why : "?") + ")";
+    }
+    return nullptr;
+}
+
 int dlv_comm_init_all(int n, const int* devs, dlv_comm** out) {
     if (!out || !devs || n < 1 || n > DLV_MAX_RANKS) return DLV_EINVAL;
     *out = nullptr;
@@ -238,11 +269,10 @@ int dlv_comm_init_all(int n, const int* devs, dlv_comm** out) {
     // entry point of this file - ncclCommInitAll, ncclBroadcast, grouped ncclSend/ncclRecv - then runs on a one-GPU box)
     const char* force = getenv("DLV_FORCE_RCCL");
     if (distinct && (n > 1 || (force && force[0] == '1'))) {
-        c->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!c->rccl) c->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        c->rccl = dlv_open_rccl(g_comm_init_err);
         if (!c->rccl) {
             dlv_comm_destroy(c);
-            return DLV_EUNSUP;  // several devices without RCCL
+            return DLV_EUNSUP;  // several devices without RCCL: dlv_comm_last_error(NULL) lists the paths that were tried
         }
 #define DLV_SYM(field, name) c->field = reinterpret_cast<decltype(c->field)>(dlsym(c->rccl, name))
         DLV_SYM(CommInitAll, "ncclCommInitAll");
@@ -378,7 +408,8 @@ int dlv_comm_selftest(dlv_comm* c, size_t bytes) {
     DLV_ABI_GUARD_END(c)
 }
 dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->ctx[rank] : nullptr; }
-const char* dlv_comm_last_error(dlv_comm* c) { return c ? c->err.c_str() : "null comm"; }
+// c == NULL: why the last dlv_comm_init_all of this thread failed (the RCCL paths that were tried)
+const char* dlv_comm_last_error(dlv_comm* c) { return c ? c->err.c_str() : (g_comm_init_err.empty() ? "null comm" : g_comm_init_err.c_str()); }
 
 int dlv_bcast_weights(dlv_comm* c, int root) {
     if (!c || root < 0 || root >= c->n) return DLV_EINVAL;

@@ -1354,7 +1354,23 @@ struct Net16 {
             zp.end();
             return stats(np, li, d);
         }
-        if ((L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32 && !ctx->no_zmarch) {  // LDS-weights z-march (conv_zmarch.hip)
+        // deep levels (conv_deep.hip): weights shared through LDS, persistent workgroups.  DLV_DEEP_MASK (A/B): bit 0 = the layers
+        // the LDS-weights z-march below would take, bit 1 = the others
+        static const int deep_mask = getenv("DLV_DEEP_MASK") ? atoi(getenv("DLV_DEEP_MASK")) : 3;
+        const bool zmarch_ok = (L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32;
+        if (!ctx->no_zmarch && ((zmarch_ok ? 1 : 2) & deep_mask) && dlv_conv3_deep_supports(L.cin, L.cout, c1, c2, d.D, d.H, d.W)) {
+            char zname[48];
+            snprintf(zname, sizeof(zname), "conv3_deep_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
+            int np = 0;
+            if ((size_t)B * dlv_cdiv(d.D, 4) * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 8) * L.cout * 2 > partials_floats)
+                return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (deep)");
+            DLV_TRY(dlv_conv3_deep_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, in2, c2, P::IS_F16 ? L.w16_f16 : L.w16_bf16, out, partials, B,
+                                          d.D, d.H, d.W, &np));
+            zp.end();
+            return stats(np, li, d);
+        }
+        if (zmarch_ok && !ctx->no_zmarch) {  // LDS-weights z-march (conv_zmarch.hip)
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_zmarch_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
             DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));

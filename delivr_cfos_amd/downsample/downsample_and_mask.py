@@ -6,9 +6,10 @@ Accelerated (device) pieces:
     upsample_mask      <- scipy.ndimage.zoom(order=2, prefilter=False) -> u8  (:285-299)
     mask_and_pad       <- img *= mask_us[i]; masked_nii[0,0,i,:Y,:X] = img    (:383-417)
     write_masked_nifti_npy: the (1,1,Zp,Yp,Xp) uint16 .npy with a 128-byte header the inference step memmaps
-Out of scope: ilastik / TeraConverter subprocesses and TIFF-LZW codecs.  Raw planes are
-read with a minimal baseline-TIFF reader (uncompressed strips, 8/16-bit grey); ``downsample_mask`` therefore
-supports the ``mask_with_Ilastik: false`` (simple threshold) branch end to end and raises for the ilastik one.
+    downsample_mask    <- the step itself, both branches: ilastik's mask (read where the reference reads it, binarised at
+                          125, :268-269) or the simple threshold
+Out of scope: the ilastik / TeraConverter subprocesses themselves.  Raw planes are read by the native
+TIFF reader (csrc/tiffio.hip).
 """
 from __future__ import annotations
 
@@ -125,33 +126,67 @@ def write_masked_nifti_npy(path: str, padded_dev) -> None:
     out.flush()
 
 
+def find_ilastik_mask_planes(results_folder: str):
+    """Where the reference picks up ilastik's output (ilastik_ventricles, :85-93): the probability planes
+    ``<results>/ventricles_zplanes/*.tif`` (sorted), which it also concatenates into ``<downsampled_name>_mask.tif``.
+    -> sorted plane paths, or [] when ilastik has not run."""
+    return sorted(glob.glob(os.path.join(results_folder, "ventricles_zplanes", "*.tif")))
+
+
+def load_ilastik_mask(results_folder: str) -> np.ndarray:
+    """ilastik's ventricle / outside-the-brain probabilities (0..255) on the down-sampled grid -> the binary uint8 mask the
+    reference makes of them: ``mask[mask < 125] = 0; mask[mask >= 125] = 1`` (:268-269)."""
+    planes = find_ilastik_mask_planes(results_folder)
+    if not planes:
+        multi = sorted(glob.glob(os.path.join(results_folder, "*_mask.tif")))
+        raise FileNotFoundError(
+            f"mask_with_Ilastik=true but no ilastik output under {os.path.join(results_folder, 'ventricles_zplanes')}: this package does "
+            "not shell out to the ilastik binary (reference :71-93) - run it on the down-sampled stack first (its headless "
+            "project writes one probability plane per z there), or set mask_with_Ilastik=false"
+            + (f" ({multi[0]} exists, but multi-page TIFFs are not read: keep the per-plane files)" if multi else ""))
+    prob = np.stack([read_tiff_plane(p) for p in planes])
+    return (prob >= 125).astype(np.uint8)
+
+
 def downsample_mask(settings: dict, brain: str, engine=None):
-    """Step 1 of the pipeline for one brain (reference :139-427), simple-threshold branch:
-    raw planes -> block-mean stack (saved as downsampled_stack.npy) -> threshold mask on the raw planes ->
-    padded masked_niftis/masked_nifti.npy."""
+    """Step 1 of the pipeline for one brain (reference :139-427):
+    raw planes -> block-mean stack (saved as downsampled_stack.npy) -> mask of the raw planes -> zero-padded
+    masked_niftis/masked_nifti.npy.  The mask is either (``mask_with_Ilastik: true``, the reference's default) ilastik's
+    output on the down-sampled grid, binarised at 125 (:268-269) and brought to the raw stack's shape with the spline-2 zoom
+    (:285-299), or (false) the simple threshold on the raw intensities (:404-408).  ilastik itself is an external binary:
+    its output is CONSUMED where the reference reads it, FileNotFoundError when it is absent."""
     from ..engine import HipEngine
 
     md = settings["mask_detection"]
-    if md.get("mask_with_Ilastik", True):
-        raise NotImplementedError("mask_with_Ilastik=true shells out to the ilastik binary (reference :71-93), which is "
-                                  "outside this package; run ilastik upstream and call upsample_mask/mask_and_pad, or set "
-                                  "mask_with_Ilastik=false")
     raw_location = os.path.join(settings["raw_location"], brain)
     planes = sorted(glob.glob(raw_location + "/*.tif"))
     if not planes:
         raise FileNotFoundError(f"no .tif planes under {raw_location}")
+    results = os.path.join(md["output_location"], brain)
+    use_ilastik = bool(md.get("mask_with_Ilastik", True))
+    mask_ds = load_ilastik_mask(results) if use_ilastik else None  # (before any device work: fails early when absent)
     own = engine is None
     eng = engine or HipEngine(0)
     try:
         raw_dev = load_stack_to_device(eng, planes)   # parallel decode -> pinned staging -> HBM
         ratios = downsample_ratios(md["downsample_steps"])
-        results = os.path.join(md["output_location"], brain)
         os.makedirs(os.path.join(results, "masked_niftis"), exist_ok=True)
         ds = downsample_volume(eng, raw_dev, ratios)
-        np.save(os.path.join(results, "downsampled_stack.npy"), ds.cpu().numpy())
+        ds_host = ds.cpu().numpy()
+        np.save(os.path.join(results, "downsampled_stack.npy"), ds_host)
         wd = settings["blob_detection"]["window_dimensions"]
         crop = (wd["window_dim_0"], wd["window_dim_1"], wd["window_dim_2"])
-        padded = mask_and_pad(eng, raw_dev, None, crop, int(md["simple_threshold_value"]))
+        if use_ilastik:
+            raw_shape = tuple(int(v) for v in raw_dev.shape)
+            print(f"Before upsampling: {mask_ds.shape}\nRaw shape {raw_shape}")
+            mask_us = upsample_mask(eng, eng.to_device(mask_ds), raw_shape)           # zoom(order=2, prefilter=False) -> uint8
+            padded = mask_and_pad(eng, raw_dev, mask_us, crop)                        # img *= mask_us[i]; zero padding
+            if mask_ds.shape == ds_host.shape:                                        # (reference :333: mask * stack)
+                np.save(os.path.join(results, "downsampled_masked_stack.npy"), mask_ds.astype(ds_host.dtype) * ds_host)
+        else:
+            padded = mask_and_pad(eng, raw_dev, None, crop, int(md["simple_threshold_value"]))
+            np.save(os.path.join(results, "downsampled_masked_stack.npy"),
+                    (ds_host > int(md["simple_threshold_value"])).astype(ds_host.dtype) * ds_host)  # (:316, :333)
         eng.sync()
         write_masked_nifti_npy(os.path.join(results, "masked_niftis", "masked_nifti.npy"), padded)
     finally:

@@ -59,7 +59,8 @@ class HipComm:
         h = C.c_void_p()
         rc = self.lib.dlv_comm_init_all(len(self.devices), arr, C.byref(h))
         if rc != 0:
-            raise DelivrHipError(rc, "dlv_comm_init_all failed (several devices need librccl.so)")
+            why = self.lib.dlv_comm_last_error(None)  # (NULL: the reason the last init of this thread failed)
+            raise DelivrHipError(rc, "dlv_comm_init_all failed: " + (why.decode() if why else "several devices need librccl.so"))
         self.handle = h
         self.engines = [HipEngine(d, _ctx=C.c_void_p(self.lib.dlv_comm_ctx(h, r))) for r, d in enumerate(self.devices)]
 
@@ -187,6 +188,8 @@ class HipEngine:
             t = arr
         else:
             a = np.ascontiguousarray(arr)
+            if not a.flags.writeable:  # (a read-only memmap: torch.from_numpy on it is undefined behaviour; big volumes
+                a = np.array(a)        # go through upload_volume, which never wraps the memmap)
             t = torch.from_numpy(a)
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)

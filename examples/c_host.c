@@ -4,7 +4,7 @@
  *   gcc -std=c99 -Iinclude examples/c_host.c -o c_host -Ldelivr_cfos_amd/lib -ldelivr_hip \
  *       -Wl,-rpath,$PWD/delivr_cfos_amd/lib -Wl,--allow-shlib-undefined -lm
  *   ./c_host            # needs an MI355X; prints the number of mask voxels and components
- *   ./c_host --gpus N [--same-device]   # the same pass sharded over N devices (dlv_comm_init_all, ONE weight broadcast,
+ *   ./c_host --gpus N [--same-device] [--comm]   # the same pass sharded over N devices (dlv_comm_init_all, ONE weight broadcast,
  *                       # per-rank Z-slabs, one seam exchange); --same-device puts every rank on device 0 (a one-GPU box)
  *   ./c_host --plan N   # prints the shard plan only (host logic, no GPU needed)
  *
@@ -66,7 +66,8 @@ static int run_sharded(int n, int same_device, const dlv_unet_weights* w, const 
     long long nw = 0, nsk = 0;
     for (r = 0; r < n; ++r) devs[r] = same_device ? 0 : r;
     if (dlv_comm_init_all(n, devs, &comm) != DLV_OK) {
-        fprintf(stderr, "dlv_comm_init_all(%d) failed: needs %d MI355X (or --same-device) and librccl.so\n", n, n);
+        fprintf(stderr, "dlv_comm_init_all(%d) failed: needs %d MI355X (or --same-device) and librccl.so: %s\n", n, n,
+                dlv_comm_last_error(NULL));
         return 2;
     }
 #define CCHECK(call)                                                                              \
@@ -138,12 +139,13 @@ int main(int argc, char** argv) {
     dlv_sw_stats st;
     uint64_t ncomp = 0;
     size_t fg = 0;
-    int gpus = 1, same_device = 0, plan_only = 0;
+    int gpus = 1, same_device = 0, plan_only = 0, use_comm = 0;
 
     for (i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--plan") && i + 1 < argc) { gpus = atoi(argv[++i]); plan_only = 1; }
         else if (!strcmp(argv[i], "--same-device")) same_device = 1;
+        else if (!strcmp(argv[i], "--comm")) use_comm = 1; /* the communicator path also for ONE rank (with DLV_FORCE_RCCL=1: real RCCL) */
     }
     if (gpus < 1 || gpus > DLV_MAX_RANKS) return 3;
     if (plan_only) { /* pure host logic: no device is touched */
@@ -158,7 +160,7 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    if (gpus == 1 && dlv_ctx_create(0, NULL, &ctx) != DLV_OK) {
+    if (gpus == 1 && !use_comm && dlv_ctx_create(0, NULL, &ctx) != DLV_OK) {
         fprintf(stderr, "dlv_ctx_create failed: this program needs an MI355X (there is no CPU fallback)\n");
         return 2;
     }
@@ -178,7 +180,7 @@ int main(int argc, char** argv) {
     w.final_b = filled(1, 0.1f, 0.f);
     /* a synthetic volume: tissue everywhere but a background margin in x (those windows are skipped) */
     for (i = 0; i < (int)nvox; ++i) vol[i] = (i % X) < 30 ? (uint16_t)(2000 + 1500 * lcg_uniform()) : 0;
-    if (gpus > 1) {
+    if (gpus > 1 || use_comm) {
         const int rc = run_sharded(gpus, same_device, &w, vol, Z, Y, X, roi, 3, mask);
         for (i = 0; i < (int)nvox; ++i) fg += mask[i] != 0;
         printf("mask voxels %zu of %zu\n", fg, nvox);

@@ -196,6 +196,8 @@ int dlv_comm_uses_rccl(dlv_comm* c);
  * on a mismatch.  Synchronous.  No reference counterpart (DataParallel has no such check). */
 int dlv_comm_selftest(dlv_comm* c, size_t bytes);
 dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank); /* owned by the communicator */
+/* c == NULL: why the calling thread's last dlv_comm_init_all failed - for DLV_EUNSUP the librccl paths that were tried
+ * ($DLV_RCCL_PATH, a librccl.so already mapped into the process, $ROCM_PATH/lib/librccl.so, then the soname). */
 const char* dlv_comm_last_error(dlv_comm* c);
 /* dlv_unet_load was called on rank `root`: every other rank allocates the blob and receives it with ONE ncclBroadcast */
 int dlv_bcast_weights(dlv_comm* c, int root);

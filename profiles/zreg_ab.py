@@ -33,7 +33,12 @@ for rnd in range(rounds + 1):  # round 0 = warm-up
         eng.sync()
         import time
         w0 = time.perf_counter()
-        eng.sw_infer(eng.make_sw_params(shape, roi, 0.0, None, 0, prec), vol, acc)
+        try:
+            eng.sw_infer(eng.make_sw_params(shape, roi, 0.0, None, 0, prec), vol, acc)
+        except Exception as e:  # timing-only ablation builds compute garbage: the range guard (DLV_ERANGE) fires at the end of the pass
+            if os.environ.get("DLV_ALLOW_WRONG_RESULTS") != "1":
+                raise
+            print("ignored:", str(e)[:80], file=sys.stderr)
         eng.sync()
         wall = time.perf_counter() - w0
         eng.prof_enable(False)

@@ -52,3 +52,45 @@ def test_two_ranks_through_torch_distributed_run_match_the_single_rank_line():
         assert c2["mask_checksum"] == c1["mask_checksum"]
     assert j2["value"] > 0 and j2["ms_per_step"] > 0
     assert j2["cpu_baseline"] is None  # the CPU leg is reported at N = 1 only
+
+
+def test_eight_ranks_launched_by_bench_itself_match_the_single_rank_line():
+    """`python bench.py --gpus 8` with no launcher in the environment: bench.py starts the contract's torch.distributed.run line
+    as a child process before it touches the GPU.  Eight ranks on cuda:0 (DLV_BENCH_SAME_DEVICE=1, gloo): the world size of the
+    driver's scaling run, on the tiny workload - thin slabs, ranks with few or no windows that run the network."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *COMMON], capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout + one.stderr
+    j1 = _json_line(one.stdout)
+    env["DLV_BENCH_SAME_DEVICE"] = "1"
+    env["DLV_LANES"] = "1"  # eight contexts share one device: keep their workspaces small
+    eight = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *COMMON], capture_output=True, text=True,
+                           timeout=1500, env=env, cwd=ROOT)
+    assert eight.returncode == 0, eight.stdout + eight.stderr
+    assert "torch.distributed.run" in eight.stderr  # the child launch line is announced
+    j8 = _json_line(eight.stdout)
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong"
+    c1, c8 = j1["config"], j8["config"]
+    assert c8["windows"] == c1["windows"] and c8["windows_skipped"] == c1["windows_skipped"]
+    per_rank = c8["per_rank_windows"]
+    assert len(per_rank) == 8 and sum(w for w, _ in per_rank) == c1["windows"] and sum(s for _, s in per_rank) == c1["windows_skipped"]
+    assert abs(c8["mask_voxels"] - c1["mask_voxels"]) <= 8, (c1["mask_voxels"], c8["mask_voxels"])
+
+
+def test_more_ranks_than_devices_fails_with_a_clear_message():
+    """`python bench.py --gpus 2` on a one-GPU box (no DLV_BENCH_SAME_DEVICE): the child ranks say what is missing."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DLV_BENCH_SAME_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *COMMON], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stdout + r.stderr, r.stdout + r.stderr

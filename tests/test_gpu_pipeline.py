@@ -124,6 +124,132 @@ def test_cli_steps_2_and_3(tmp_path, precision, tta):
     assert open(csv_path).read() == orc.cells_csv_text(ref_stats, n_ref)
 
 
+def _lzw_tiff(path, plane, bits):
+    """one grey plane through the library's own LZW writer (host code)"""
+    import ctypes as C
+
+    from delivr_cfos_amd import _lib
+
+    lib = _lib.load()
+    a = np.ascontiguousarray(plane.astype(np.uint16 if bits == 16 else np.uint8))
+    assert lib.dlv_tiff_write_plane(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], bits, 5) == 0, lib.dlv_tiff_last_error()
+
+
+@pytest.mark.parametrize("ilastik", [True, False])
+def test_cli_steps_1_2_3_from_tiff_planes(tmp_path, ilastik):
+    """MASK_DOWNSAMPLE + BLOB_DETECTION + POSTPROCESSING through the CLI from raw TIFF z-planes (reference __main__.py:87-140),
+    both mask branches of step 1: `mask_with_Ilastik: true` (the reference's default config; ilastik's probability planes are
+    read where the reference reads them, binarised at 125, zoomed with spline 2 - downsample_and_mask.py:85-93, :268-299) and
+    the simple threshold (:404-408).  masked_nifti.npy: header bytes = numpy's own open_memmap header (what the reference
+    calls), payload bit-exact vs scipy's zoom / the threshold; binaries.npy: header = the reference's own (ref_finalize.npz);
+    mask vs the oracle in the reference's arithmetic; labels, statistics and CSV bit-exact."""
+    import torch
+    from scipy.ndimage import zoom
+    from oracle.parity import LogitCache, flip_report, reference_arithmetic
+    from delivr_cfos_amd.__main__ import main
+    from delivr_cfos_amd.hostlogic import padded_shape
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    brain, crop, thr = "brainT", (32, 32, 32), 900
+    vol = synth_volume_np((40, 70, 66), seed=23, dense=True)  # (the stack shape of ref_finalize.npz: same binaries.npy header)
+    vol[:, :, :6] = 0
+    vol[5:20, 10:30, 20:40] //= 8  # a dim region: below the simple threshold
+    root = str(tmp_path)
+    raw_dir = os.path.join(root, "raw", brain)
+    os.makedirs(raw_dir)
+    for z in range(vol.shape[0]):  # raw planes: LZW and uncompressed mixed, as stitchers write them
+        (_lzw_tiff(os.path.join(raw_dir, f"Z{z:04d}.tif"), vol[z], 16) if z % 2 else _uncompressed_tiff(os.path.join(raw_dir, f"Z{z:04d}.tif"), vol[z]))
+    res_dir = os.path.join(root, "out", "01_mask", brain)
+    ds_shape = (19, 35, 33)  # block mean (2,2,2) of 40 x 70 x 66 with the reference's dropped last z-chunk
+    if ilastik:
+        # ilastik's output as the reference finds it: 8-bit probability planes on the down-sampled grid; values on both sides of 125
+        zz, yy, xx = np.meshgrid(np.arange(ds_shape[0]), np.arange(ds_shape[1]), np.arange(ds_shape[2]), indexing="ij")
+        r = np.sqrt(((zz - 9) / 8.0) ** 2 + ((yy - 17) / 15.0) ** 2 + ((xx - 16) / 14.0) ** 2)
+        prob = np.clip(np.round(255 * (1.25 - r)), 0, 255).astype(np.uint8)
+        prob[8:11, 15:19, 14:18] = 124  # a "ventricle": just below the cut
+        os.makedirs(os.path.join(res_dir, "ventricles_zplanes"))
+        for z in range(ds_shape[0]):
+            _lzw_tiff(os.path.join(res_dir, "ventricles_zplanes", f"mask_{z:04d}.tif"), prob[z], 8)
+        mask_ds = (prob >= 125).astype(np.uint8)
+        mask_us = np.zeros(vol.shape, dtype=np.uint8)
+        zoom(mask_ds, tuple(o / i for o, i in zip(vol.shape, mask_ds.shape)), output=mask_us, order=2, prefilter=False)  # (:299)
+        assert 0 < int(mask_us.sum()) < mask_us.size
+        masked = vol * mask_us
+    else:
+        masked = np.where(vol < thr, 0, vol).astype(np.uint16)
+    sd = random_state_dict(7)
+    wfile = os.path.join(root, "weights.tar")
+    torch.save({"state_dict": sd}, wfile)
+    cfg = {
+        "raw_location": os.path.join(root, "raw") + "/", "output_location": os.path.join(root, "out") + "/",
+        "mask_detection": {"output_location": os.path.join(root, "out", "01_mask") + "/", "mask_with_Ilastik": ilastik,
+                           "simple_threshold_value": thr, "ilastik_location": "/nonexistent", "ilastik_model": "none.ilp",
+                           "downsample_steps": {"original_um_x": 1.0, "original_um_y": 1.0, "original_um_z": 1.0,
+                                                "downsample_um_x": 2.0, "downsample_um_y": 2.0, "downsample_um_z": 2.0}},
+        "blob_detection": {"input_location": os.path.join(root, "out", "01_mask") + "/", "model_location": wfile,
+                           "output_location": os.path.join(root, "out", "02_blob") + "/",
+                           "window_dimensions": {"window_dim_0": crop[0], "window_dim_1": crop[1], "window_dim_2": crop[2]}},
+        "postprocessing": {"input_location": os.path.join(root, "out", "02_blob") + "/",
+                           "output_location": os.path.join(root, "out", "03_post") + "/", "min_size": -1, "max_size": -1},
+        "mi355x": {"precision": "fp32"},
+        "FLAGS": {"ABSPATHS": True, "LOAD_ALL_RAM": True, "TEST_TIME_AUGMENTATION": False, "MASK_DOWNSAMPLE": True,
+                  "BLOB_DETECTION": True, "POSTPROCESSING": True, "ATLAS_ALIGNMENT": False, "REGION_ASSIGNMENT": False,
+                  "VISUALIZATION": False, "SAVE_ACTIVATED_OUTPUT": False},
+    }
+    cfg_path = os.path.join(root, "config.json")
+    json.dump(cfg, open(cfg_path, "w"))
+    assert main([cfg_path]) == 0
+
+    # ---- step 1: the padded network input ------------------------------------------------------------------------------------
+    pad = padded_shape(vol.shape, crop)
+    nii_path = os.path.join(res_dir, "masked_niftis", "masked_nifti.npy")
+    probe = os.path.join(root, "probe.npy")
+    np.lib.format.open_memmap(probe, mode="w+", dtype=np.uint16, shape=(1, 1) + pad).flush()  # (the reference's call, :393)
+    assert open(nii_path, "rb").read(128) == open(probe, "rb").read(128)
+    nii = np.memmap(nii_path, dtype=np.uint16, mode="r", shape=(1, 1) + pad, offset=128)  # (as inference.py:234 reads it)
+    expect = np.zeros(pad, dtype=np.uint16)
+    expect[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = masked
+    assert np.array_equal(nii[0, 0], expect)
+    ds = np.load(os.path.join(res_dir, "downsampled_stack.npy"))
+    assert ds.shape == ds_shape and np.array_equal(ds, orc.block_mean_u16(vol[:38], (2, 2, 2)))
+    assert main([cfg_path]) == 0  # a second run finds masked_niftis and skips step 1 (reference __main__.py:98)
+
+    # ---- steps 2 + 3 against the oracle on the same masked stack ------------------------------------------------------------
+    bin_path = os.path.join(root, "out", "02_blob", brain, "binary_segmentations", "binaries.npy")
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_finalize.npz"))
+    assert open(bin_path, "rb").read(128) == gold["oneblock_header"].tobytes()  # the header the reference's create_nifti_seg wrote
+    binaries = np.load(bin_path)
+    net = orc.build_unet(seed=None)
+    net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+    ref = reference_arithmetic(orc, expect, crop, LogitCache(lambda x: orc.unet_forward(net, x)), False, stack_shape=vol.shape)
+    mean = ref["mean"][: vol.shape[0], : vol.shape[1], : vol.shape[2]]
+    rep = flip_report(binaries, ref["mask"], mean)
+    print(f"CLI steps 1-3 [ilastik={ilastik}] mask vs reference arithmetic: {rep}")
+    margin = np.abs(mean) < 2e-3
+    assert np.array_equal(binaries[~margin], ref["mask"][~margin]) and rep["iou"] >= 0.999
+    post = os.path.join(root, "out", "03_post")
+    labels_file = [f for f in sorted(os.listdir(post)) if f.endswith("-cc3d.npy")][0]
+    lab_ref, n_ref = orc.ccl26(binaries)
+    assert int(labels_file.split("-")[1]) == n_ref and np.array_equal(np.load(os.path.join(post, labels_file)).astype(np.uint32), lab_ref)
+    ref_stats = orc.cc_stats(lab_ref, n_ref)
+    assert open(os.path.join(post, f"{vol.shape}_{brain}.csv")).read() == orc.cells_csv_text(ref_stats, n_ref)
+
+
+def test_downsample_mask_without_ilastik_output_raises(tmp_path):
+    """mask_with_Ilastik=true and no ilastik output: a FileNotFoundError that says where the planes are expected"""
+    from delivr_cfos_amd.downsample.downsample_and_mask import downsample_mask
+
+    raw_dir = os.path.join(str(tmp_path), "raw", "b")
+    os.makedirs(raw_dir)
+    _uncompressed_tiff(os.path.join(raw_dir, "Z0000.tif"), np.zeros((8, 8), dtype=np.uint16))
+    settings = {"raw_location": os.path.join(str(tmp_path), "raw"), "mask_detection": {"output_location": os.path.join(str(tmp_path), "out"),
+                                                                                      "mask_with_Ilastik": True}}
+    with pytest.raises(FileNotFoundError, match="ventricles_zplanes"):
+        downsample_mask(settings, "b")
+
+
 def test_default_config_window_96_96_64():
     """config.json's default window (96,96,64): level sizes 96/48/24/12/6 x 64/32/16/8/4 exercise every tile
     shape (z-march with 6x2 tiles, generic TX 16 and TX 8 with masked x)."""
@@ -584,7 +710,7 @@ def test_uint8_count_map_refuses_a_multiplicity_it_cannot_hold():
     eng.close()
 
 
-@pytest.mark.parametrize("world,weighted", [(2, False), (3, True), (5, True)])
+@pytest.mark.parametrize("world,weighted", [(2, False), (3, True), (5, True), (8, False)])
 def test_c_abi_sharded_pass_on_slabs_equals_the_single_device_pass(world, weighted):
     """dlv_comm_init_all / dlv_bcast_weights / dlv_sw_infer_sharded / dlv_finalize_slab_dev with every rank on device 0 (the
     seam exchange then uses device copies; RCCL needs distinct devices): each rank holds only ITS slab of the volume and of
@@ -629,6 +755,8 @@ def test_c_abi_sharded_pass_on_slabs_equals_the_single_device_pass(world, weight
         assert hi - lo < shape[0] or world == 1  # a slab, not the volume
     stats = comm.sw_infer_sharded(p, plan, slabs, vols, accs, cnts)
     assert sum(s["n_windows"] for s in stats) == st1["n_windows"] and sum(s["n_skipped"] for s in stats) == st1["n_skipped"]
+    if world == 8:  # the equal plan over a volume whose upper part is background: ranks whose windows ALL skip the network
+        assert any(s["n_windows"] > 0 and s["n_windows"] == s["n_skipped"] for s in stats), stats
     torch.cuda.synchronize()
     covered = 0
     for r in range(world):
@@ -676,3 +804,16 @@ def test_plain_c_host_runs_the_pass_single_and_sharded(tmp_path):
         fg = int(re.search(r"mask voxels (\d+)", r.stdout).group(1))
         # sums associate differently across the seam (fp32): a voxel whose mean logit is within rounding of 0 may flip
         assert abs(fg - fg1) <= 2, (fg, fg1)
+    # the real RCCL from a host that is NOT a PyTorch process: one rank through a 1-rank communicator (DLV_FORCE_RCCL=1) with
+    # an empty loader path - librccl is found under $ROCM_PATH/lib (multi.hip: dlv_open_rccl)
+    env = {k: v for k, v in os.environ.items() if k != "LD_LIBRARY_PATH"}
+    env["DLV_FORCE_RCCL"] = "1"
+    r = subprocess.run([exe, "--gpus", "1", "--comm"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert abs(int(re.search(r"mask voxels (\d+)", r.stdout).group(1)) - fg1) <= 2
+    # ... and when it cannot be found the message lists what was tried
+    env["ROCM_PATH"] = "/nonexistent"
+    env["DLV_RCCL_PATH"] = "/nonexistent/librccl.so"
+    r = subprocess.run([exe, "--gpus", "1", "--comm"], capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode != 0:  # (a loader that finds the soname on its default path still succeeds)
+        assert "tried: /nonexistent/librccl.so" in r.stderr, r.stderr
