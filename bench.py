@@ -649,7 +649,7 @@ def main():
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
             "patch_voxels_per_s": tile_vox * n_active / (elapsed / args.steps),
             "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),
-            "lanes": int(os.environ.get("DLV_LANES", "3")), "cu_split_mem_cus_per_xcd": int(os.environ.get("DLV_CU_SPLIT", "0")),
+            "lanes": int(os.environ.get("DLV_LANES", "3")),
             "mask_voxels": mask_voxels, "mask_checksum": mask_checksum,
             "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
             "dist_backend": (dist.get_backend() + (" (forced at world size 1: DLV_BENCH_FORCE_DIST)" if world == 1 else "")) if dist_mode else None,

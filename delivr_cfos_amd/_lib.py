@@ -182,9 +182,10 @@ SIGNATURES = {
     "dlv_debug_set_format": (C.c_int, [_P, C.c_int]),
     "dlv_debug_layer_bf16": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int]),
+    "dlv_unet_set_conv_shift": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dlv_unet_get_conv_shift": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "dlv_range_report": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
-    "dlv_set_cu_split": (C.c_int, [_P, C.c_int]),
-    "dlv_set_conv_algo": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
     "dlv_prof_reset": (C.c_int, [_P]),
     "dlv_prof_report": (C.c_int, [_P, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),

@@ -197,10 +197,15 @@ def _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start):
             made = {}
 
             def create_output(n):
+                # written under a name load_cached_brain does NOT match (no '.npy' suffix) and renamed when pass 2 has finished:
+                # a run killed while it renumbers the slabs must not leave a complete-looking label file behind as a cache
                 made["path"] = os.path.join(path_out, f"{brain}-{n}-cc3d.npy")
-                return np.lib.format.open_memmap(made["path"], mode="w+", dtype=_label_dtype(n), shape=tuple(bin_img.shape))
+                made["tmp"] = os.path.join(path_out, f".{brain}-{n}-cc3d.partial")
+                return np.lib.format.open_memmap(made["tmp"], mode="w+", dtype=_label_dtype(n), shape=tuple(bin_img.shape))
 
             N, stats = ccl_streamed(eng, bin_img, int(n_slabs), os.path.join(path_out, f".{brain}-provisional-u32.tmp"), create_output)
+            if made:
+                os.replace(made["tmp"], made["path"])
             with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
                 pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
             return N, stats
@@ -209,20 +214,29 @@ def _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start):
             mask_dev = eng.to_device(np.ascontiguousarray(bin_img))
             labels_dev, N = eng.ccl26(mask_dev)
             labels = labels_dev.cpu().numpy().view(np.uint32).astype(_label_dtype(N), copy=False)
-            np.save(os.path.join(path_out, f"{brain}-{N}-cc3d.npy"), labels)
+            final = os.path.join(path_out, f"{brain}-{N}-cc3d.npy")
+            with open(final + ".partial", "wb") as fh:  # (same reason: never a partly written file under the cache's name)
+                np.save(fh, labels)
+            os.replace(final + ".partial", final)
         else:
             N = int(cached.split("/")[-1].split("-")[1])
             print(f"Cached brain found at {cached} with {N} components, loading...")
-            labels = np.load(cached)
+            labels = np.load(cached, mmap_mode="r")
         mid = datetime.datetime.now()
         print(f"{mid} labelling+writing/loading took {mid - start} : {N}")
         cached_stats = load_cached_stats(settings, brain)
         if not cached_stats:
-            if labels_dev is None:
-                import torch
+            if labels_dev is None and int(labels.size) * 4 > budget:
+                # cached labels that do not fit the HBM budget: statistics slab by slab (raw sums add up; streaming.py)
+                from .streaming import stats_streamed
 
-                labels_dev = torch.from_numpy(labels.astype(np.uint32).view(np.int32)).to(eng.device)
-            stats = eng.cc_stats(labels_dev, N)
+                stats = stats_streamed(eng, labels, N, budget)
+            else:
+                if labels_dev is None:
+                    import torch
+
+                    labels_dev = torch.from_numpy(np.ascontiguousarray(labels).astype(np.uint32).view(np.int32)).to(eng.device)
+                stats = eng.cc_stats(labels_dev, N)
             with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
                 pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
         else:

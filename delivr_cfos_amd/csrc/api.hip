@@ -43,87 +43,6 @@ int dlv_sync_all(dlv_ctx* ctx) {
     DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
     for (int k = 0; k < DLV_MAX_LANES - 1; ++k)
         if (ctx->aux[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->aux[k]));
-    for (int k = 0; k < DLV_MAX_LANES; ++k) {
-        if (ctx->split_mfma[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->split_mfma[k]));
-        if (ctx->split_mem[k]) DLV_HIP(ctx, hipStreamSynchronize(ctx->split_mem[k]));
-    }
-    return DLV_OK;
-}
-
-// ---- CU split ------------------------------------------------------------------------------------
-// hipExtStreamCreateWithCUMask: mask bit b stands for CU b / 8 of XCD b % 8 on this part (checked with
-// profiles/microbench/cu_partition.hip), so "CUs [lo, hi) of every XCD" are the bits 8*lo .. 8*hi-1: both partitions
-// keep all eight XCDs (L2s, fabric links) and differ only in how many CUs of each they may occupy.
-static void split_destroy(dlv_ctx* ctx) {
-    for (int l = 0; l < DLV_MAX_LANES; ++l) {
-        for (hipStream_t* s : {&ctx->split_mfma[l], &ctx->split_mem[l]})
-            if (*s) {
-                (void)hipStreamSynchronize(*s);
-                (void)hipStreamDestroy(*s);
-                *s = nullptr;
-            }
-        for (auto& e : ctx->split_ev[l])
-            if (e) {
-                (void)hipEventDestroy(e);
-                e = nullptr;
-            }
-    }
-    ctx->split_built = 0;
-}
-
-int dlv_split_prepare(dlv_ctx* ctx, int nlanes) {
-    const int m = ctx->split_mem_cus;
-    if (m == 0) return DLV_OK;
-    if (m >= 32) return dlv_fail(ctx, DLV_EINVAL, "CU split: %d of 32 CUs per XCD for the memory partition", m);
-    if (ctx->split_built != m) split_destroy(ctx);
-    if (m < 0) {
-        // priority mode (no CU masks): the convs of every lane on a high-priority stream, the HBM-class kernels on a
-        // low-priority one - a conv that is ready is dispatched before a pending memory-class workgroup, which then fills
-        // what the conv leaves free (a conv wave owns 440 of a SIMD's 512 registers: one 64-register wave fits beside it)
-        int lo = 0, hi = 0;
-        DLV_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest priority (numerically lower)
-        for (int l = 0; l < nlanes && l < DLV_MAX_LANES; ++l) {
-            if (!ctx->split_mfma[l]) DLV_HIP(ctx, hipStreamCreateWithPriority(&ctx->split_mfma[l], hipStreamNonBlocking, hi));
-            if (!ctx->split_mem[l]) DLV_HIP(ctx, hipStreamCreateWithPriority(&ctx->split_mem[l], hipStreamNonBlocking, lo));
-            for (auto& e : ctx->split_ev[l])
-                if (!e) DLV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        ctx->split_built = m;
-        return DLV_OK;
-    }
-    // the masks below address 8 XCDs x 32 CUs ("bit b = CU b/8 of XCD b%8"): refuse any other part / partition mode
-    // instead of silently selecting the wrong CUs
-    hipDeviceProp_t prop;
-    DLV_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    if (prop.multiProcessorCount != 256 || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return dlv_fail(ctx, DLV_EUNSUP, "CU split: written for gfx950 with 256 CUs in 8 XCDs; this device is %s with %d CUs", prop.gcnArchName,
-                        prop.multiProcessorCount);
-    auto masked = [&](int cu_lo, int cu_hi, hipStream_t* out) -> int {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = 8 * cu_lo; b < 8 * cu_hi; ++b) mask[b / 32] |= 1u << (b % 32);
-        DLV_HIP(ctx, hipExtStreamCreateWithCUMask(out, 8, mask));
-        return DLV_OK;
-    };
-    for (int l = 0; l < nlanes && l < DLV_MAX_LANES; ++l) {
-        if (!ctx->split_mfma[l]) DLV_TRY(masked(0, 32 - m, &ctx->split_mfma[l]));
-        if (!ctx->split_mem[l]) DLV_TRY(masked(32 - m, 32, &ctx->split_mem[l]));
-        for (auto& e : ctx->split_ev[l])
-            if (!e) DLV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    ctx->split_built = m;
-    return DLV_OK;
-}
-
-int dlv_use_class(dlv_ctx* ctx, int cls) {
-    if (!ctx->split_active) return DLV_OK;
-    const int l = ctx->lane;
-    hipStream_t want = cls == DLV_K_MEM ? ctx->split_mem[l] : ctx->split_mfma[l];
-    if (want == ctx->stream) return DLV_OK;
-    hipEvent_t e = ctx->split_ev[l][ctx->split_ev_next[l]];
-    ctx->split_ev_next[l] = (ctx->split_ev_next[l] + 1) % 16;
-    DLV_HIP(ctx, hipEventRecord(e, ctx->stream));
-    DLV_HIP(ctx, hipStreamWaitEvent(want, e, 0));
-    ctx->stream = want;
     return DLV_OK;
 }
 
@@ -230,6 +149,7 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         size_t nw = (size_t)cout[i] * cin[i] * 27;
         float* w = (float*)take(nw * 4);
         float* b = (float*)take((size_t)cout[i] * 4);
+        float* b16 = (float*)take((size_t)cout[i] * 4);
         float* g = (float*)take((size_t)cout[i] * 4);
         float* be = (float*)take((size_t)cout[i] * 4);
         // the stem (i == 0) keeps a 4-k-step hi/lo A-fragment pack for the MFMA stem (4 KiB)
@@ -237,13 +157,8 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         uint16_t* wh = (uint16_t*)take(i == 0 ? (size_t)4096 : nw * 2);
         uint16_t* wb16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
         uint16_t* wh16 = i == 0 ? nullptr : (uint16_t*)take(nw * 2);
-        uint16_t* ww = (i > 0 && cin[i] == 32 && cout[i] % 32 == 0) ? (uint16_t*)take((size_t)cout[i] * cin[i] * 36 * 2) : nullptr;
         // conv 16 = upcat_1.conv_0 when its inputs are a 32-channel skip + the 32 channels of a 32->32 transposed conv
-        // ... and conv 14 = upcat_2.conv_0 (32-channel skip + the 32 channels of a 64->32 transposed conv): the same fold with the
-        // coarse tensor's 64 input channels as two 32-channel K-slices (two packs, two correction tables, two addends)
-        const int slices = (i == 16 && cin[i] == 64 && cout[i] == 32 && dcin[3] == 32 && dcout[3] == 32)   ? 1
-                           : (i == 14 && cin[i] == 64 && cout[i] == 32 && dcin[2] == 64 && dcout[2] == 32) ? 2
-                                                                                                           : 0;
+        const int slices = (i == 16 && cin[i] == 64 && cout[i] == 32 && dcin[3] == 32 && dcout[3] == 32) ? 1 : 0;
         const bool fold = slices > 0;
         uint16_t* wsb = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
         uint16_t* wsh = fold ? (uint16_t*)take((size_t)32 * 32 * 27 * 2) : nullptr;
@@ -257,7 +172,6 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
             ctx->conv[i].wup_bf16 = wub;
             ctx->conv[i].wup_f16 = wuh;
             ctx->conv[i].up_corr = ucr;
-            ctx->conv[i].wwino_f16 = ww;
             ctx->conv[i].w16_bf16 = wb16;
             ctx->conv[i].w16_f16 = wh16;
             ctx->conv[i].w_f16 = wh;
@@ -265,6 +179,7 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
             ctx->conv[i].cout = cout[i];
             ctx->conv[i].w_f32 = w;
             ctx->conv[i].bias = b;
+            ctx->conv[i].bias16 = b16;
             ctx->conv[i].gamma = g;
             ctx->conv[i].beta = be;
             ctx->conv[i].w_bf16 = wb;
@@ -318,6 +233,7 @@ static int alloc_blob(dlv_ctx* ctx, const int f[6]) {
     ctx->blob_bytes = bytes;
     memcpy(ctx->features, f, sizeof(int) * 6);
     layout_blob(ctx, f, (char*)ctx->blob);
+    for (int i = 0; i < DLV_N_CONV; ++i) ctx->conv[i].shift = 0;  // a new checkpoint starts unshifted
     return DLV_OK;
 }
 
@@ -341,8 +257,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
 #ifdef DLV_DIAG  // timing-only ablations (WRONG results): the diagnostic library only (make diag), never the product
     ctx->upconv_dbg = getenv("DLV_UPCONV_DBG") ? atoi(getenv("DLV_UPCONV_DBG")) : 0;
 #endif
-    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;
-    ctx->fold_up2 = getenv("DLV_UPCONV2") ? 1 : 0;  // opt-in: measured break-even (profiles/README.md)        // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
+    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;  // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return DLV_EHIP;
@@ -376,7 +291,6 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         ctx->aux_stream = ctx->aux[0];
     }
     if (const char* e = getenv("DLV_LANES")) ctx->lanes_wanted = std::max(1, std::min(DLV_MAX_LANES, atoi(e)));
-    if (const char* e = getenv("DLV_CU_SPLIT")) ctx->split_mem_cus = std::max(-1, std::min(31, atoi(e)));
     *out = ctx;
     return DLV_OK;
 }
@@ -385,7 +299,6 @@ int dlv_ctx_destroy(dlv_ctx* ctx) {
     if (!ctx) return DLV_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)dlv_sync_all(ctx);
-    split_destroy(ctx);
     for (auto& p : ctx->prof_pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -490,6 +403,30 @@ int dlv_unet_load(dlv_ctx* ctx, const dlv_unet_weights* w) {
     return DLV_OK;
 }
 
+int dlv_unet_set_conv_shift(dlv_ctx* ctx, int layer, int shift) {
+    if (!ctx) return DLV_EINVAL;
+    if (layer < 0 || layer >= DLV_N_CONV || shift < 0 || shift > 40) return dlv_fail(ctx, DLV_EINVAL, "conv shift: layer 0..17, shift 0..40");
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_unet_set_conv_shift before dlv_unet_load");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    DLV_TRY(dlv_sync_all(ctx));
+    ctx->conv[layer].shift = shift;
+    DLV_TRY(dlv_pack_weights_bf16(ctx));  // (both 16-bit formats, every pack of every layer: milliseconds)
+    DLV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DLV_OK;
+}
+int dlv_unet_get_conv_shift(dlv_ctx* ctx, int layer, int* shift) {
+    if (!ctx || !shift || layer < 0 || layer >= DLV_N_CONV) return DLV_EINVAL;
+    *shift = ctx->conv[layer].shift;
+    return DLV_OK;
+}
+int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks) {
+    if (!ctx) return DLV_EINVAL;
+    if (layer) *layer = ctx->range_last;
+    if (peaks)
+        for (int i = 0; i < DLV_N_CONV; ++i) peaks[i] = ctx->range_peak[i];
+    return DLV_OK;
+}
+
 int dlv_unet_blob_size(dlv_ctx* ctx, size_t* bytes) {
     if (!ctx || !bytes) return DLV_EINVAL;
     if (!ctx->blob) return dlv_fail(ctx, DLV_ESTATE, "no weights loaded/allocated");
@@ -544,18 +481,6 @@ int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
 int dlv_set_lanes(dlv_ctx* ctx, int lanes) {
     if (!ctx || lanes < 1 || lanes > DLV_MAX_LANES) return DLV_EINVAL;
     ctx->lanes_wanted = lanes;
-    return DLV_OK;
-}
-
-int dlv_set_conv_algo(dlv_ctx* ctx, int algo) {
-    if (!ctx || (algo != DLV_CONV_DIRECT && algo != DLV_CONV_WINOGRAD)) return DLV_EINVAL;
-    ctx->conv_algo = algo;
-    return DLV_OK;
-}
-
-int dlv_set_cu_split(dlv_ctx* ctx, int mem_cus_per_xcd) {
-    if (!ctx || mem_cus_per_xcd < -1 || mem_cus_per_xcd > 31) return DLV_EINVAL;
-    ctx->split_mem_cus = mem_cus_per_xcd;
     return DLV_OK;
 }
 

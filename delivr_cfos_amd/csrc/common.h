@@ -31,6 +31,9 @@ struct DlvConvLayer {
     int cin = 0, cout = 0;
     float* w_f32 = nullptr;     // (Cout,Cin,27) fp32, as in the checkpoint
     float* bias = nullptr;      // (Cout)
+    float* bias16 = nullptr;    // (Cout) bias * 2^-shift: what the 16-bit kernels add (dlv_unet_set_conv_shift)
+    int shift = 0;              // the 16-bit packs hold W * 2^-shift: the raw output is stored 2^-shift times smaller, InstanceNorm
+                                // (eps * 4^-shift) gives the same normalised value - the fp16 range guard's remedy
     float* gamma = nullptr;     // (Cout)
     float* beta = nullptr;      // (Cout)
     uint16_t* w_bf16 = nullptr; // MFMA A-operand fragment order (see unet_bf16.hip)
@@ -44,8 +47,7 @@ struct DlvConvLayer {
     uint16_t* wup_bf16 = nullptr;
     uint16_t* wup_f16 = nullptr;
     float* up_corr = nullptr;
-    int up_slices = 0;          // 32-channel K-slices of the folded transposed conv (1: upcat_1, 2: upcat_2): packs / corr tables are consecutive
-    uint16_t* wwino_f16 = nullptr; // Winograd F(2,3)-x transformed weights, 36 fragments per 16 couts (conv_zwino.hip); Cin 32 only
+    int up_slices = 0;          // 1: this conv's up half is folded with its transposed conv (upcat_1)
 };
 struct DlvDeconvLayer {
     int cin = 0, cout = 0;
@@ -71,11 +73,6 @@ enum DlvWsSlot {
     WS_N_SLOTS = WS_LANE_STATS0 + DLV_MAX_LANES - 1
 };
 
-// Which part of the chip a kernel of the forward belongs on when the CU split is on (dlv_set_cu_split): the 3x3x3 convs
-// (MFMA-bound, one wave per SIMD, the whole register file) on the large partition, the HBM-class kernels that carry the
-// Mish (stem, InstanceNorm+Mish(+pool) passes, transposed convs, final conv + blend) on the small one.
-enum DlvKernelClass { DLV_K_MFMA = 0, DLV_K_MEM = 1 };
-
 struct dlv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream the NEXT launch goes to (main or aux lane)
@@ -83,18 +80,8 @@ struct dlv_ctx {
     hipStream_t aux_stream = nullptr;   // lane 1 (kept as a named alias of aux[0])
     hipStream_t aux[DLV_MAX_LANES - 1] = {nullptr};  // extra lanes: batches rotate over the lanes so that the
                                         // HBM-bound kernels of one batch overlap the MFMA kernels of another
-    hipEvent_t ev_lane[DLV_MAX_LANES + 1] = {nullptr};  // one per lane + one for the main stream (split mode)
+    hipEvent_t ev_lane[DLV_MAX_LANES + 1] = {nullptr};  // one per lane + one for the main stream
     int lane = 0;
-    // CU split (spatial partition of the chip, dlv_set_cu_split / DLV_CU_SPLIT): per lane one stream whose CU mask holds
-    // the first 32 - split_mem_cus CUs of every XCD (convs) and one with the remaining split_mem_cus (HBM-class kernels);
-    // a forward hops between its lane's two streams with an event per hop (dlv_use_class)
-    int split_mem_cus = 0;     // wanted: 0 = off
-    int split_built = 0;       // the value the masked streams were created for
-    bool split_active = false; // set by dlv_sw_infer_dev for the duration of a pass
-    hipStream_t split_mfma[DLV_MAX_LANES] = {nullptr};
-    hipStream_t split_mem[DLV_MAX_LANES] = {nullptr};
-    hipEvent_t split_ev[DLV_MAX_LANES][16] = {{nullptr}};
-    int split_ev_next[DLV_MAX_LANES] = {0};
     int lanes_wanted = 3;  // C3: 1 lane 6.86 s, 2: 6.58, 3: 6.56, 4: 6.63 per pass (profiles/lanes_sweep.sh, r02)
     bool own_stream = false;
     std::string err;
@@ -107,13 +94,13 @@ struct dlv_ctx {
     float* blend_wsum = nullptr;
     int upconv_dbg = 0;         // DLV_UPCONV_DBG, diagnostic library only (timing, WRONG results): 1 = no stores, 2 = no halo loads
     int upconv_simple = 0;      // DLV_UPCONV_SIMPLE=1: the one-tile-per-workgroup upconv kernel for every shape (A/B, tests)
-    int fold_up2 = 0;           // ... and of upcat_2 (two K-slices, two launches, two addends): opt-in with DLV_UPCONV2=1 - measured
-                                // break-even (448 us unfolded, 239 + 2 x 88 us folded per 16 windows)
     int fold_up = 1;            // fold the transposed conv into the first conv of upcat_1 (upconv.hip); DLV_NO_UPCONV=1: A/B, the unfolded path
-    int conv_algo = 0;          // dlv_set_conv_algo: 0 direct (default), 1 Winograd F(2,3) along x for the fp16 Cin-32 convs of levels 0/1
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
     void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
-    int* range_flag = nullptr;  // device word: 0, or 100 - (first layer whose InstanceNorm sums were not finite; 18 = logits)
+    int* range_flag = nullptr;  // device words: [0] 0, or 100 - (first layer whose InstanceNorm sums were not finite; 18 = logits);
+                                // [1 + layer] float bits of the largest |mean| + 8 sigma of the layer's raw output that exceeded 4096
+    int range_last = -1;        // layer of the last DLV_ERANGE (-1: none)
+    float range_peak[DLV_N_CONV] = {0};  // ... and the peaks read back with it
     void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads
     void* blob = nullptr;  // one allocation holding every packed parameter
     size_t blob_bytes = 0;
@@ -158,13 +145,8 @@ int dlv_fail(dlv_ctx* ctx, int code, const char* fmt, ...);
 
 // grow-only scratch slot
 int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out);
-// waits for every stream the context launches on (main, lanes, CU-split streams)
+// waits for every stream the context launches on (main, lanes)
 int dlv_sync_all(dlv_ctx* ctx);
-// CU split: creates the masked streams of `nlanes` lanes for ctx->split_mem_cus (no-op when they exist)
-int dlv_split_prepare(dlv_ctx* ctx, int nlanes);
-// CU split: the next launch of the forward running on lane ctx->lane is of class `cls` (DlvKernelClass); when that means
-// another stream, the new stream waits for everything the lane queued so far.  No-op unless ctx->split_active.
-int dlv_use_class(dlv_ctx* ctx, int cls);
 
 // kernel timer: DlvProf p(ctx, "name", flops, bytes); <launch>; p.end();
 struct DlvProf {
@@ -240,12 +222,12 @@ int dlv_conv3_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
 // InstanceNorm scale/shift of the layer that produced in1 / in2 (applied with Mish while staging) or nullptr
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,
                           int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
-                          int* nparts, const void* addend = nullptr, const void* addend2 = nullptr);
-int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin, int ctot = 0, int c0 = 0);
+                          int* nparts, const void* addend = nullptr);
+int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin, int ctot = 0, int c0 = 0, float wscale = 1.f);
 // folded up half of an UpCat block's first conv (upconv.hip): Weff / corr from the conv's and the transposed conv's fp32
 // tensors; P = conv3(up-sampled tensor) - const, computed from the ACTIVATED coarse tensor
 int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr,
-                    int ci0 = 0, int with_corr = 1);
+                    int ci0 = 0, int with_corr = 1, float wscale = 1.f);
 bool dlv_upconv2_persistent(const dlv_ctx* ctx, int Dc, int Hc, int Wc);
 int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, const float* corr, void* out, int B, int Dc, int Hc, int Wc,
                        int cstride = 4, int c0 = 0);
@@ -253,11 +235,6 @@ bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
 // range guard of the 16-bit formats (unet_bf16.hip): reset before a pass / forward, check after it (synchronises the stream)
 int dlv_range_reset(dlv_ctx* ctx);
 int dlv_range_check(dlv_ctx* ctx, bool f16);
-// Winograd F(2,3)-along-x variant of the same conv (conv_zwino.hip): fp16, Cin = 32, one final (activated) input
-int dlv_conv3_zwino_launch(dlv_ctx* ctx, int cin, int cout, const void* in1, const void* wwino, void* out, float* partials, int B, int D,
-                           int H, int W, int* nparts);
-int dlv_pack_conv_wino(dlv_ctx* ctx, const float* w_f32, uint16_t* out, int cout, int cin);
-bool dlv_conv3_zwino_supports(int cin, int cout, int c1, int c2, int W);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

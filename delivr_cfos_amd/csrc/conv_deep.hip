@@ -13,7 +13,8 @@
 //   wave       = 64 voxels (4 blocks of 16) x all 16*NCB channels: NCB x 4 accumulators of v_mfma_f32_16x16x32
 //   K loop     = 32 input channels at a time ("slab"): the slab's halo tile (6 x 10 x 18 voxels x 4 chunks, 68 KiB) in LDS,
 //                x 3 kz groups of 9 taps whose A fragments (9 x NCB KiB) sit in a double-buffered LDS stage: fetched from
-//                L2 ONCE per workgroup and group - a whole group (144 MFMAs per wave) ahead - and read by all 8 waves
+//                L2 ONCE per workgroup and group by LDS-DMA (no registers) - two thirds of a group (96 MFMAs per wave)
+//                ahead - and read by all 8 waves
 //   LDS reads  : per (kz, kx) a wave reads the 6 input rows its 4 output rows see through ky = 0..2 ONCE (9 row pairs at
 //                the 8-wide level) and 3 x NCB A fragments: 18 ds_read_b128 per 48 MFMAs (0.375 per MFMA; 1.0 before)
 //   staging    : the next slab's halo tile (of the next ITEM after the last slab: the walk is one software pipeline) is
@@ -21,6 +22,10 @@
 //   epilogue   : 16-bit pack + 8-byte stores into the chunk-planar output, InstanceNorm partial sums per (item, channel)
 //                in a fixed order (DPP row sums, the 8 waves through LDS).  No bias: every 3x3x3 conv of the network is
 //                followed by InstanceNorm, which removes a per-channel constant exactly (as conv_zreg_kernel.h).
+// Measured and dropped (profiles/README.md round 5): the same walk with ONE wave per SIMD (4 waves x 128 voxels, 22 reads per 96
+// MFMAs, every read issued a phase ahead in the source): 1.3x SLOWER - hipcc's schedule of an intrinsic-MFMA loop needs the
+// second wave to fill its waits; the weight stage filled through registers (global_load + ds_write in pieces) instead of
+// LDS-DMA: 1.35x slower (the in-order vmcnt ties the pieces to the halo prefetch, 3 spilled registers).
 // Weights: the 16-channel A-fragment pack of conv_zreg.hip ([cout/16][tap][cin/32][lane][8]).
 // Reference: the Conv3d -> InstanceNorm3d -> Mish blocks down_2..down_4 / upcat_4..upcat_2 of MONAI's BasicUNet
 // (inference/inference.py:190-197; call site inference/sliding_window_inferer.py:222).
@@ -75,7 +80,7 @@ template <class P, int TX, int NCB>
 __global__ void __launch_bounds__(512, 2)
 conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restrict__ in2, int c2_8, const uint4* __restrict__ wpk,
                   uint4* __restrict__ out, float* __restrict__ partials, int cout, int D, int H, int W, int tilesY, int tilesX,
-                  int ntiles, int B, int dbg) {
+                  int ntiles, int B) {
     using C = CdCfg<TX, NCB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* tile = reinterpret_cast<uint4*>(smem_raw);            // [4 chunks][CS]
@@ -195,7 +200,7 @@ conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restri
 
     cd_f32x4 acc[NCB][4];
     const int lbase = q * C::CS + (zl * C::HY + yb + (l16 / TX)) * C::HX + (l16 % TX);
-    auto compute_group = [&](int kz, int buf) __attribute__((always_inline)) {
+    auto compute_group = [&](int kz, int buf, bool wnext, int ct2, int sl2, int kz2) __attribute__((always_inline)) {
         const uint4* wb = wbuf + buf * C::WG_ELEMS + lane;
         const uint4* tb = tile + lbase + kz * C::HY * C::HX;
 #pragma unroll
@@ -217,6 +222,11 @@ conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restri
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) acc[cb][blk] = cd_mfma<P>(af[cb], bf[blk * C::RPB + ky], acc[cb][blk]);
             }
+            // the next group's LDS-DMA pieces are issued HERE, a third into the group: right behind the barrier all 8 waves would
+            // issue them at once (an LDS-DMA instruction holds its wave's issue for ~100 cycles) in front of their first MFMAs -
+            // measured 4-6 % slower on the 32^3 / 16^3 layers (profiles/README.md round 5); two thirds of a group (96 MFMAs per
+            // wave) still cover the L2 round trip
+            if (kx == 0 && wnext) dma_w(ct2, sl2, kz2, buf ^ 1);
         }
     };
 
@@ -237,15 +247,13 @@ conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restri
             for (int blk = 0; blk < 4; ++blk) acc[cb][blk] = cd_f32x4{0.f, 0.f, 0.f, 0.f};
         for (int sl = 0; sl < nslab; ++sl) {
             // (the barrier that ended the previous group: everybody is done with the tile)
-            if (!(dbg & 1)) write_in();
+            write_in();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the very first group's fragments)
-            if (!(dbg & 2)) __syncthreads();  // tile visible
-            if (!(dbg & 4)) {
+            __syncthreads();  // tile visible
             if (sl + 1 < nslab) fetch_in(cur, sl + 1);
             else if (has_next) {
                 map_item(nxt);
                 fetch_in(nxt, 0);
-            }
             }
 #pragma unroll 1
             for (int kz = 0; kz < 3; ++kz) {
@@ -261,12 +269,11 @@ conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restri
                             any = has_next;
                         }
                     }
-                    if (any && !(dbg & 8)) dma_w(ct2, sl2, kz2, (g + 1) & 1);
+                    compute_group(kz, g & 1, any, ct2, sl2, kz2);
                 }
-                compute_group(kz, g & 1);
                 ++g;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
-                if (!(dbg & 16)) __syncthreads();
+                __syncthreads();
             }
         }
         // ---- epilogue of the item: stores + InstanceNorm partial sums ---------------------------------------------------
@@ -344,9 +351,8 @@ int cd_launch(dlv_ctx* ctx, const void* in1, int c1, const void* in2, int c2, co
     }();
     const unsigned grid = (unsigned)std::min<long long>(nitems, ncu);
     *nparts = ntiles;
-    static const int dbg = getenv("DLV_DEEP_DBG") ? atoi(getenv("DLV_DEEP_DBG")) : 0;  // TEMPORARY timing-only switches
     hipLaunchKernelGGL((conv3_deep_kernel<P, TX, NCB>), dim3(grid), dim3(512), C::LDS_BYTES, ctx->stream, (const uint4*)in1, c1 / 8,
-                       (const uint4*)in2, c2 / 8, (const uint4*)wpk16, (uint4*)out, partials, cout, D, H, W, tilesY, tilesX, ntiles, B, dbg);
+                       (const uint4*)in2, c2 / 8, (const uint4*)wpk16, (uint4*)out, partials, cout, D, H, W, tilesY, tilesX, ntiles, B);
     DLV_LAUNCH_CHECK(ctx, "conv3_deep_kernel");
     return DLV_OK;
 }

@@ -6,7 +6,6 @@ struct dlv_ctx;
 struct ZrArgs {
     const void *in1, *ss1, *in2, *ss2, *wpk16;
     const void* addend = nullptr;  // ADD instantiations: 16-bit tensor in the layout of `out`, added before statistics and pack
-    const void* addend2 = nullptr; // ADD == 2: a second one
     void* out;
     float* partials;
     char* trash;
@@ -32,8 +31,3 @@ ZR_DECLARE(dlv_zr_f16_c32_t8_add);
 ZR_DECLARE(dlv_zr_f16_c32_t16_add);
 ZR_DECLARE(dlv_zr_bf16_c32_t8_add);
 ZR_DECLARE(dlv_zr_bf16_c32_t16_add);
-// ... with two addends (the two K-slices of a 64-channel folded transposed conv)
-ZR_DECLARE(dlv_zr_f16_c32_t8_add2);
-ZR_DECLARE(dlv_zr_f16_c32_t16_add2);
-ZR_DECLARE(dlv_zr_bf16_c32_t8_add2);
-ZR_DECLARE(dlv_zr_bf16_c32_t16_add2);

@@ -14,7 +14,7 @@ namespace {
 // (ctot, c0): the weight tensor has ctot input channels and the pack takes channels [c0, c0 + cin) of it - the skip half of an
 // UpCat conv whose up half is folded into upconv.hip
 template <class P>
-__global__ void pack_conv_w16_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin, int ctot, int c0) {
+__global__ void pack_conv_w16_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin, int ctot, int c0, float wscale) {
     const int KS = cin / 32;
     const long long n = (long long)cout * cin * 27;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -27,19 +27,19 @@ __global__ void pack_conv_w16_kernel(const float* __restrict__ w, uint16_t* __re
         const int cb = (int)(r / 27);
         const int co = cb * 16 + (lane & 15);
         const int ci = ks * 32 + 8 * (lane >> 4) + j;
-        const float v = w[((long long)co * ctot + c0 + ci) * 27 + t];
+        const float v = w[((long long)co * ctot + c0 + ci) * 27 + t] * wscale;  // (a power of two: exact)
         out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
     }
 }
 
 }  // namespace
 
-int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin, int ctot, int c0) {
+int dlv_pack_conv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cout, int cin, int ctot, int c0, float wscale) {
     if (ctot <= 0) ctot = cin;
     if (f16)
-        hipLaunchKernelGGL(pack_conv_w16_kernel<PF16>, dim3(256), dim3(256), 0, ctx->stream, w_f32, out, cout, cin, ctot, c0);
+        hipLaunchKernelGGL(pack_conv_w16_kernel<PF16>, dim3(256), dim3(256), 0, ctx->stream, w_f32, out, cout, cin, ctot, c0, wscale);
     else
-        hipLaunchKernelGGL(pack_conv_w16_kernel<PBf16>, dim3(256), dim3(256), 0, ctx->stream, w_f32, out, cout, cin, ctot, c0);
+        hipLaunchKernelGGL(pack_conv_w16_kernel<PBf16>, dim3(256), dim3(256), 0, ctx->stream, w_f32, out, cout, cin, ctot, c0, wscale);
     DLV_LAUNCH_CHECK(ctx, "pack_conv_w16_kernel");
     return DLV_OK;
 }
@@ -54,7 +54,7 @@ bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W) {
 // output).  Returns the number of partial-sum rows per sample in *nparts.
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,
                           int c2, const void* ss2, const void* wpk16, void* out, float* partials, int B, int D, int H, int W,
-                          int* nparts, const void* addend, const void* addend2) {
+                          int* nparts, const void* addend) {
     if (!dlv_conv3_zreg_supports(cin, cout, c1, c2, W))
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: needs Cout %% 32 == 0, W >= 32 and inputs of 32, 32+32 or 64 channels");
     if (addend && (cin != 32 || ss1 != nullptr)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: an addend needs Cin 32 and a final input");
@@ -86,15 +86,11 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     DLV_TRY(dlv_ws_get(ctx, WS_MISC, 65536, (void**)&trash));
     static const int dbg = getenv("DLV_ZREG_DBG") ? atoi(getenv("DLV_ZREG_DBG")) : 0;  // development: 1 = no interior steps
     ZrArgs a;
-    a.in1 = in1; a.ss1 = ss1; a.in2 = in2; a.ss2 = ss2; a.wpk16 = wpk16; a.addend = addend; a.addend2 = addend2;
+    a.in1 = in1; a.ss1 = ss1; a.in2 = in2; a.ss2 = ss2; a.wpk16 = wpk16; a.addend = addend;
     a.out = out; a.partials = partials; a.trash = trash;
     a.c1_8 = c1 / 8; a.c2_8 = c2 / 8; a.D = D; a.H = H; a.W = W; a.tilesX = tilesX; a.zseg = zseg; a.nseg = nseg; a.cout8 = cout / 8;
     a.dbg = dbg;
     a.gx = (unsigned)(tilesY * tilesX); a.gy = (unsigned)(nseg * ncb); a.gz = (unsigned)B;
-    if (addend && addend2) {
-        if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_add2(ctx, a) : dlv_zr_f16_c32_t8_add2(ctx, a);
-        return tyt == 16 ? dlv_zr_bf16_c32_t16_add2(ctx, a) : dlv_zr_bf16_c32_t8_add2(ctx, a);
-    }
     if (addend) {
         if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_add(ctx, a) : dlv_zr_f16_c32_t8_add(ctx, a);
         return tyt == 16 ? dlv_zr_bf16_c32_t16_add(ctx, a) : dlv_zr_bf16_c32_t8_add(ctx, a);

@@ -1,5 +1,5 @@
 // conv_zreg_inst.hip - one instantiation of conv3_zreg_kernel per object file: compiled with
-//   -DZR_INST_NAME=<entry point> -DZR_INST_P=<PF16|PBf16> -DZR_INST_CIN=<32|64> -DZR_INST_TYT=<8|16> -DZR_INST_ACT=<0|1> [-DZR_INST_ADD=<1|2>]
+//   -DZR_INST_NAME=<entry point> -DZR_INST_P=<PF16|PBf16> -DZR_INST_CIN=<32|64> -DZR_INST_TYT=<8|16> -DZR_INST_ACT=<0|1> [-DZR_INST_ADD=1]
 // (see the Makefile)
 #include "conv_zreg_kernel.h"
 

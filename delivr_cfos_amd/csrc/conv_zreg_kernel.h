@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256, 1)
 conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restrict__ ss1, const uint4* __restrict__ in2,
                   int c2_8, const float2* __restrict__ ss2, const uint4* __restrict__ wpk, uint4* __restrict__ out,
                   float* __restrict__ partials, int D, int H, int W, int tilesX, int zseg, int nseg, int cout8, int dbg,
-                  char* __restrict__ trash, const uint4* __restrict__ addend, const uint4* __restrict__ addend2) {
+                  char* __restrict__ trash, const uint4* __restrict__ addend) {
     using C = ZrCfg<CIN, TYT>;
     constexpr int RW = C::RW, RA = C::RA, RV = RW - RA, KS = C::KS, NG = C::NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -281,18 +281,11 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
     constexpr int AHEAD = ZR_ADD_AHEAD;  // rows between an addend's fetch and its use (RW % AHEAD == 0: a row's slot is r % AHEAD)
     static_assert(RW % AHEAD == 0, "addend slots");
     u32x2 pbuf[AHEAD][2] = {};
-    // ADD == 2: a second addend (the other 32-channel K-slice of a folded transposed conv with 64 input channels: upcat_2)
-    const __amdgpu_buffer_rsrc_t ars2 = __builtin_amdgcn_make_buffer_rsrc(
-        ADD == 2 ? const_cast<char*>(reinterpret_cast<const char*>(addend2 + ((long long)n * cout8 + cb * 4 + half * 2) * vox)) : obase, 0,
-        (int)(2u * (unsigned)vox * 16u), 0x00020000);
-    u32x2 pbuf2[ADD == 2 ? AHEAD : 1][2] = {};
     auto add_fetch = [&](bool valid, int r, int b, int oz) __attribute__((always_inline)) {  // row r (0..RW-1) of plane oz
         // (the scalar offset is not part of the buffer's range check: a row / plane that does not exist reads row 0 of plane 0
         // instead - its value is never used)
         if constexpr (ADD != 0)
             pbuf[r % AHEAD][b] = __builtin_amdgcn_raw_buffer_load_b64(ars, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, ZR_ADD_AUX);
-        if constexpr (ADD == 2)
-            pbuf2[r % AHEAD][b] = __builtin_amdgcn_raw_buffer_load_b64(ars2, (int)ooff_b[b], valid ? (int)((unsigned)(oz * plane + r * W) * 16u) : 0, ZR_ADD_AUX);
     };
     const unsigned toff = (unsigned)(threadIdx.x * 8u + (blockIdx.x & 31u) * 2048u);  // masked-out stores land here (64 KB)
 
@@ -355,13 +348,6 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
                 a[1] += P::hi(pv[0]);
                 a[2] += P::lo(pv[1]);
                 a[3] += P::hi(pv[1]);
-                if constexpr (ADD == 2) {
-                    const u32x2 qv = pbuf2[r % AHEAD][b];
-                    a[0] += P::lo(qv[0]);
-                    a[1] += P::hi(qv[0]);
-                    a[2] += P::lo(qv[1]);
-                    a[3] += P::hi(qv[1]);
-                }
                 epi_v[b] = a;
                 // the row AHEAD further on in the sequence (plane by plane, row by row): same slot, now free
                 const int r2 = (r + AHEAD) % RW, oz2 = oz + ((r + AHEAD) >= RW ? 1 : 0);
@@ -581,7 +567,7 @@ int zr_launch(dlv_ctx* ctx, const ZrArgs& a) {
     hipLaunchKernelGGL((conv3_zreg_kernel<P, CIN, TYT, ACT, ADD>), dim3(a.gx, a.gy, a.gz), dim3(256), (ZrCfg<CIN, TYT>::LDS_BYTES), ctx->stream,
                        (const uint4*)a.in1, a.c1_8, (const float2*)a.ss1, (const uint4*)a.in2, a.c2_8, (const float2*)a.ss2,
                        (const uint4*)a.wpk16, (uint4*)a.out, a.partials, a.D, a.H, a.W, a.tilesX, a.zseg, a.nseg, a.cout8, a.dbg,
-                       a.trash, (const uint4*)a.addend, (const uint4*)a.addend2);
+                       a.trash, (const uint4*)a.addend);
     DLV_LAUNCH_CHECK(ctx, "conv3_zreg_kernel");
     return DLV_OK;
 }

@@ -511,37 +511,11 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     // convolutions of the other.  Windows of one colour class are disjoint, so their blends may run
     // concurrently; the lanes are joined at every class boundary, which keeps the per-voxel summation
     // order (colour by colour) and therefore the bits of the result.
-    // CU split (dlv_set_cu_split): every lane owns TWO CU-masked streams - the convs on the large partition of the chip, the
-    // HBM-class kernels on the small one (dlv_use_class in unet_bf16.hip hops between them) - so that the two kinds of work
-    // of different batches run side by side on their own CUs instead of sharing every SIMD.  Same kernels, same order
-    // per window, same bits.
     const int nlanes = (p->precision != DLV_PREC_F32 && ctx->aux[0] != nullptr) ? std::max(1, std::min(ctx->lanes_wanted, DLV_MAX_LANES)) : 1;
-    const bool split = p->precision != DLV_PREC_F32 && ctx->split_mem_cus != 0 && ctx->aux[0] != nullptr &&
-                       tile_vox * (long long)sw_batch >= (1ll << 22);
-    if (split) {
-        DLV_TRY(dlv_split_prepare(ctx, nlanes));
-        if (p->sw_batch <= 0 && ctx->split_mem_cus > 0) {
-            // the convs of the top level launch B * (h/16) * (w/32) workgroups of one per CU onto the conv partition: pick the
-            // batch near the default whose launch fills whole rounds of that partition (128^3 windows, 192 CUs: 18, not 16)
-            const long long cus = 8LL * (32 - ctx->split_mem_cus), t = (long long)dlv_cdiv(h, 16) * dlv_cdiv(w, 32);
-            int best = sw_batch;
-            double best_cost = 1e30;
-            for (int b = std::max(1, sw_batch - sw_batch / 4); b <= sw_batch + sw_batch / 4 + 1; ++b) {
-                const double waste = (double)(((b * t + cus - 1) / cus) * cus) / (double)(b * t);
-                const double cost = waste + 1e-3 * std::abs(b - sw_batch);
-                if (cost < best_cost - 1e-12) {
-                    best_cost = cost;
-                    best = b;
-                }
-            }
-            sw_batch = best;
-        }
-    }
-    const bool two_lanes = nlanes > 1 || split;
-    auto lane_stream = [&](int l) { return split ? ctx->split_mfma[l] : (l == 0 ? ctx->main_stream : ctx->aux[l - 1]); };
-    // the streams that take part in a join: the lanes' home streams (+ the main stream when it is not lane 0)
+    const bool two_lanes = nlanes > 1;
+    auto lane_stream = [&](int l) { return l == 0 ? ctx->main_stream : ctx->aux[l - 1]; };
+    // the streams that take part in a join: the lanes' streams
     std::vector<hipStream_t> parts;
-    if (split) parts.push_back(ctx->main_stream);
     for (int l = 0; l < nlanes; ++l) parts.push_back(lane_stream(l));
     auto join_lanes = [&]() -> int {
         if (!two_lanes) return DLV_OK;
@@ -562,15 +536,12 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
             if (p->precision != DLV_PREC_F32) {
                 ctx->lane = two_lanes ? lane : 0;
                 ctx->stream = lane_stream(ctx->lane);
-                ctx->split_active = split;
                 rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, p->precision == DLV_PREC_F16 ? 1 : 0);
                 if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
                                        Xp, 0.0f, rep, acc_dev, cnt_dev, nullptr, 0.f, nullptr);
                     if (hipGetLastError() != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "launch of fill_add_kernel(count) failed");
                 }
-                if (rc == DLV_OK) rc = dlv_use_class(ctx, DLV_K_MFMA);  // split: the lane's home stream waits for the forward's tail
-                ctx->split_active = false;
                 lane = (lane + 1) % nlanes;
             } else {
                 float *tin, *tout;
@@ -589,7 +560,6 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
         }
         ctx->stream = ctx->main_stream;
         ctx->lane = 0;
-        ctx->split_active = false;
         if (rc == DLV_OK && s.n_skipped > 0) {
             const int* st_dev = list_dev + (s.off + s.n_active) * 3;
             DlvProf pr(ctx, "skip_fill_f32", 0.0, 8.0 * tile_vox * s.n_skipped);
@@ -602,7 +572,6 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     }
     ctx->stream = ctx->main_stream;
     ctx->lane = 0;
-    ctx->split_active = false;
     if (rc != DLV_OK) return rc;
     if (stats) {
         stats->n_skipped = n_skipped;

@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { retur
 // ---------------------------------------------------------------------------------------------------
 // conv:   out[((cb*27 + t)*KP + kp)*64 + lane][j] = W[cout = cb*32 + (lane&31)][cin = kp*16 + 8*(lane>>5) + j][t]
 template <class P>
-__global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin) {
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin, float wscale) {
     const int KP = cin / 16;
     const long long n = (long long)cout * cin * 27;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -67,7 +67,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __rest
         const int cb = (int)(r / 27);
         const int co = cb * 32 + (lane & 31);
         const int ci = kp * 16 + 8 * (lane >> 5) + j;
-        const float v = w[((long long)co * cin + ci) * 27 + t];
+        const float v = w[((long long)co * cin + ci) * 27 + t] * wscale;  // (2^-shift: exact)
         out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
     }
 }
@@ -75,7 +75,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, uint16_t* __rest
 // exactly into x = 256*hi + lo (both exact in bf16), the weights carry the factor 256 for the hi half:
 //   out[(s*64 + lane)*8 + j]: tap = 8 s + 4 (lane>>5) + (j>>1), part = j&1 (0: lo byte, 1: hi byte), cout = lane&31
 template <class P>
-__global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
+__global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, float wscale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 64 * 8) return;
     const int j = i & 7, lane = (i >> 3) & 63, s = i >> 9;
@@ -84,8 +84,12 @@ __global__ void pack_stem_w_kernel(const float* __restrict__ w, uint16_t* __rest
     // k-step s, lane half h: taps 8s + 4h + (j >> 1), low byte (j even) then high byte (j odd) of the same tap - the
     // (lo, hi) pair of one tap is one 32-bit word of the staged tile, i.e. one register of the MFMA operand
     const int tap = 8 * s + 4 * (lane >> 5) + (j >> 1);
-    if (tap < 27) v = w[co * 27 + tap] * ((j & 1) ? 256.f : 1.f) * P::STEM_SCALE;
+    if (tap < 27) v = w[co * 27 + tap] * ((j & 1) ? 256.f : 1.f) * P::STEM_SCALE * wscale;
     out[i] = (uint16_t)(P::pack2(v, 0.f) & 0xffffu);
+}
+__global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * f;
 }
 // deconv: out[((par*CB + cb)*KP + kp)*64 + lane][j] = W[cin = kp*16 + 8*(lane>>5) + j][cout = cb*32 + (lane&31)][par]
 template <class P>
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
                                                         int Yp, int Xp, const int* __restrict__ starts, int flip_dim,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         uint4* __restrict__ out, float* __restrict__ partials, int D,
-                                                        int H, int W) {
+                                                        int H, int W, float oscale) {
     __shared__ float wl[27 * 32];
     __shared__ float red[4][64];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) {
@@ -176,9 +180,9 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const float* __restrict_
                         acc[4 * c4 + 3] = fmaf(v, ww.w, acc[4 * c4 + 3]);
                     }
                 }
-        if (P::STEM_SCALE != 1.0f) {
+        if (oscale != 1.0f) {  // (STEM_SCALE * 2^-shift of layer 0)
 #pragma unroll
-            for (int c = 0; c < 32; ++c) acc[c] *= P::STEM_SCALE;
+            for (int c = 0; c < 32; ++c) acc[c] *= oscale;
         }
         const long long vox = (long long)D * hw;
         const long long o = (long long)z * hw + p;
@@ -628,6 +632,11 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
         const double mean = s * inv_count;
         double var = q * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
+        // ... and which layer is the large one: the sums are those of the fp32 accumulators, so they stay finite when the STORED
+        // 16-bit value overflows.  |mean| + 8 sigma beyond 4096 (a rare path: one atomic) is recorded per layer; after a
+        // DLV_ERANGE the host reads it as the hint for dlv_unet_set_conv_shift (positive floats order like their bit patterns)
+        const float peak = (float)(fabs(mean) + 8.0 * sqrt(var));
+        if (peak > 4096.f && peak < 3.0e38f) atomicMax(range_flag + 1 + layer, __float_as_int(peak));
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = rstd * gamma[c];
         ss[n * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
@@ -1241,13 +1250,6 @@ struct Net16 {
 
     int grid1d(long long n) const { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
 
-    // CU split (dlv_set_cu_split): the next launch works on a tensor of `d` voxels per window and is of class `cls`.  Only
-    // the large levels hop to the memory partition; the kernels of the deep levels are small and stay with the convs.
-    int use(int cls, Dims d) {
-        if (!ctx->split_active) return DLV_OK;
-        return dlv_use_class(ctx, d.vox() * B >= (1ll << 22) ? cls : DLV_K_MFMA);
-    }
-
     // does the register-resident-weights conv run this layer (and with which inputs may it apply the activation itself)?
     bool zreg_runs(int li, int c1, int c2, Dims d) const {
         const DlvConvLayer& L = ctx->conv[li];
@@ -1275,7 +1277,8 @@ struct Net16 {
     int stats(int nparts, int li, Dims d) {
         const DlvConvLayer& L = ctx->conv[li];
         // the fp16 format stores the raw stem output scaled by 2^-8: eps scales with its square (same normalised value)
-        const float eps = li == 0 ? 1e-5f * P::STEM_SCALE * P::STEM_SCALE : 1e-5f;
+        // ... and a layer stored 2^-shift times smaller (dlv_unet_set_conv_shift) with 4^-shift
+        const float eps = (li == 0 ? 1e-5f * P::STEM_SCALE * P::STEM_SCALE : 1e-5f) * exp2f(-2.f * (float)L.shift);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(B * L.cout), dim3(64), 0, ctx->stream, partials, nparts, L.cout,
                            1.0 / (double)d.vox(), eps, L.gamma, L.beta, ss_of(li), ctx->range_flag, li);
         DLV_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
@@ -1288,31 +1291,28 @@ struct Net16 {
         if (!(ctx->fold_up && L.up_corr != nullptr && cskip == 32 && (ctx->zm_variant == 0 || ctx->zm_variant == 50) && !ctx->no_zmarch &&
               d.vox() > 32768 && dlv_conv3_zreg_supports(32, L.cout, 32, 0, d.W) && d.D % 2 == 0 && d.H % 2 == 0 && d.W % 2 == 0))
             return false;
-        // two K-slices (upcat_2): only the persistent kernel takes a chunk offset into a wider coarse tensor
-        return L.up_slices == 1 || (ctx->fold_up2 && dlv_upconv2_persistent(ctx, d.D / 2, d.H / 2, d.W / 2));
+        return true;
     }
-    int conv_folded(int li, Act& sk, Act& coarse, uint4* pbuf, uint4* pbuf2, uint4* out, Dims d, Dims dc) {
+    int conv_folded(int li, Act& sk, Act& coarse, uint4* pbuf, uint4* out, Dims d, Dims dc) {
         const DlvConvLayer& L = ctx->conv[li];
         DLV_TRY(materialise(coarse, dc));  // the folded weights multiply the ACTIVATED coarse tensor
         DLV_TRY(materialise(sk, d));
-        if (coarse.C != 32 * L.up_slices) return dlv_fail(ctx, DLV_ESTATE, "folded conv %d: %d coarse channels, %d slices", li, coarse.C, L.up_slices);
-        for (int sl = 0; sl < L.up_slices; ++sl) {
-            DLV_TRY(use(DLV_K_MFMA, d));
+        if (coarse.C != 32) return dlv_fail(ctx, DLV_ESTATE, "folded conv %d: %d coarse channels, expected 32", li, coarse.C);
+        {
             char nm[48];
             snprintf(nm, sizeof(nm), "upconv2%s_%s_c32x32_d%d", dlv_upconv2_persistent(ctx, dc.D, dc.H, dc.W) ? "m" : "", P::IS_F16 ? "f16" : "bf16", dc.D);
             DlvProf pr(ctx, nm, 2.0 * 8 * 32 * 32 * (double)d.vox() * B, 2.0 * 32 * ((double)dc.vox() + (double)d.vox()) * B);
-            DLV_TRY(dlv_upconv2_launch(ctx, P::IS_F16, coarse.p, (P::IS_F16 ? L.wup_f16 : L.wup_bf16) + (size_t)sl * (2 * 2 * 4 * 8 * 64 * 8),
-                                       L.up_corr + (size_t)sl * (8 * 8 * 32), sl == 0 ? pbuf : pbuf2, B, dc.D, dc.H, dc.W, coarse.C / 8, 4 * sl));
+            DLV_TRY(dlv_upconv2_launch(ctx, P::IS_F16, coarse.p, P::IS_F16 ? L.wup_f16 : L.wup_bf16, L.up_corr, pbuf, B, dc.D, dc.H, dc.W, coarse.C / 8, 0));
             pr.end();
         }
         char zname[48];
-        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add%s", P::IS_F16 ? "f16" : "bf16", L.cout, d.D, L.up_slices == 2 ? "2" : "");
-        DlvProf zp(ctx, zname, 2.0 * 27 * 32 * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (32 + (1 + L.up_slices) * L.cout));
+        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add", P::IS_F16 ? "f16" : "bf16", L.cout, d.D);
+        DlvProf zp(ctx, zname, 2.0 * 27 * 32 * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (32 + 2 * L.cout));
         int np = 0;
         if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
             return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zreg)");
         DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, 32, L.cout, sk.p, 32, nullptr, nullptr, 0, nullptr, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, out,
-                                      partials, B, d.D, d.H, d.W, &np, pbuf, L.up_slices == 2 ? pbuf2 : nullptr));
+                                      partials, B, d.D, d.H, d.W, &np, pbuf));
         zp.end();
         return stats(np, li, d);
     }
@@ -1326,22 +1326,8 @@ struct Net16 {
         if (c1 % 32 || c2 % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: concat parts must be multiples of 32 channels", li);
         if (a2) DLV_TRY(materialise(*a2, d));
         if (!fuses_first_input(li, c1, c2, d)) DLV_TRY(materialise(a1, d));
-        DLV_TRY(use(DLV_K_MFMA, d));
         const uint4* in1 = a1.p;
         const uint4* in2 = a2 ? a2->p : nullptr;
-        if (zreg_runs(li, c1, c2, d) && P::IS_F16 && ctx->conv_algo == DLV_CONV_WINOGRAD && !a1.ss && L.wwino_f16 &&
-            dlv_conv3_zwino_supports(L.cin, L.cout, c1, c2, d.W)) {  // Winograd F(2,3) along x (conv_zwino.hip)
-            char zname[48];
-            snprintf(zname, sizeof(zname), "conv3_zwino_f16_c%dx%d_d%d", L.cin, L.cout, d.D);
-            // (flops: the DIRECT convolution's 2*27*Cin*Cout per voxel - what the layer computes, not what the MFMAs issue)
-            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
-            int np = 0;
-            if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
-                return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zwino)");
-            DLV_TRY(dlv_conv3_zwino_launch(ctx, L.cin, L.cout, in1, L.wwino_f16, out, partials, B, d.D, d.H, d.W, &np));
-            zp.end();
-            return stats(np, li, d);
-        }
         if (zreg_runs(li, c1, c2, d)) {
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_zreg_%s_c%dx%d_d%d%s", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D, a1.ss ? "_act" : "");
@@ -1355,8 +1341,9 @@ struct Net16 {
             return stats(np, li, d);
         }
         // deep levels (conv_deep.hip): weights shared through LDS, persistent workgroups.  DLV_DEEP_MASK (A/B): bit 0 = the layers
-        // the LDS-weights z-march below would take, bit 1 = the others
-        static const int deep_mask = getenv("DLV_DEEP_MASK") ? atoi(getenv("DLV_DEEP_MASK")) : 3;
+        // the LDS-weights z-march below takes (Cin, Cout <= 64 at the 32^3 level: 64->64 equal, 32->64 69 vs 78 us - they
+        // stay with the z-march), bit 1 = the others (Cin or Cout >= 128: 1.4-1.5x the generic kernel's rate)
+        static const int deep_mask = getenv("DLV_DEEP_MASK") ? atoi(getenv("DLV_DEEP_MASK")) : 2;
         const bool zmarch_ok = (L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32;
         if (!ctx->no_zmarch && ((zmarch_ok ? 1 : 2) & deep_mask) && dlv_conv3_deep_supports(L.cin, L.cout, c1, c2, d.D, d.H, d.W)) {
             char zname[48];
@@ -1377,7 +1364,7 @@ struct Net16 {
             int np = 0;
             if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
                 return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
-            DLV_TRY(dlv_conv3_zmarch_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, in2, c2, wpack<P>(L), L.bias, out, partials, B,
+            DLV_TRY(dlv_conv3_zmarch_launch(ctx, P::IS_F16, L.cin, L.cout, in1, c1, in2, c2, wpack<P>(L), L.bias16, out, partials, B,
                                             d.D, d.H, d.W, &np));
             zp.end();
             if ((size_t)B * np * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zmarch)");
@@ -1415,7 +1402,7 @@ struct Net16 {
             dlv_attr_mark(attr_done, ctx->device);                                                                                            \
         }                                                                                                                \
         hipLaunchKernelGGL((conv3_mfma_kernel<P, NCB_, TX_, WLDS_>), grid, dim3(256), lds, ctx->stream, in1, c1 / 8, in2,   \
-                           c2 / 8, reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias, out, partials, L.cout, d.D, d.H,    \
+                           c2 / 8, reinterpret_cast<const uint4*>(wpack<P>(L)), L.bias16, out, partials, L.cout, d.D, d.H,    \
                            d.W, tY, tX);                                                                                 \
     } while (0)
         if (wlds) {
@@ -1444,7 +1431,6 @@ struct Net16 {
     // InstanceNorm apply + Mish (+ MaxPool into `pooled`); writeback = false (pool only): x stays raw for consumers that
     // activate while loading
     int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
-        DLV_TRY(use(DLV_K_MEM, d));
         const long long work = pooled ? d.vox() / 8 : d.vox();
         // a tensor far beyond L2 + MALL is streamed with the non-temporal policy and two grid-stride iterations per thread
         // (profiles/microbench/nt_probe.hip: 2.15 GB in place 743 us at 2048 x default, 642 us at 4096 x nt); the small levels
@@ -1488,7 +1474,6 @@ struct Net16 {
         // the per-parity kernel has no activation on load; the weight-stationary kernel of the deep levels (Cin >= 128) would
         // repeat it for every (parity, output block) it enumerates: there the (small) input is activated by one norm pass
         if (!rows || L.cin >= 128) DLV_TRY(materialise(a, din));
-        DLV_TRY(use(DLV_K_MEM, Dims{2 * din.D, 2 * din.H, 2 * din.W}));
         const uint4* in = a.p;
         const float2* ssin = a.ss;
         const int segs = dlv_cdiv(din.W, 16);
@@ -1575,7 +1560,6 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         bool two_pass_stem = false;
         if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
         const DlvConvLayer& L = ctx->conv[0];
-        DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, (vol && !ctx->no_zmarch) ? "stem_mfma_u16" : "stem_conv_f32", 2.0 * 27 * 32 * (double)dm[0].vox() * B, (double)dm[0].vox() * B * (2 + 64));
         if (vol && !ctx->no_zmarch) {
             const int tY = dlv_cdiv(h, SM_TY), tX = dlv_cdiv(w, SM_TX), tZ = dlv_cdiv(d, SM_TZ * SM_ZC);
@@ -1584,18 +1568,18 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
             if ((size_t)B * nblk * 64 > pfloats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (stem)");
             const uint4* wst = reinterpret_cast<const uint4*>(wpack<P>(L));
             hipLaunchKernelGGL((stem_mfma_kernel<P, 1>), grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim, wst,
-                               L.bias, buf(0, A), net.partials, (const float2*)nullptr, d, h, w, tY, tX);
+                               L.bias16, buf(0, A), net.partials, (const float2*)nullptr, d, h, w, tY, tX);
             DLV_LAUNCH_CHECK(ctx, "stem_mfma_kernel<1>");
             DLV_TRY(net.stats(nblk, 0, dm[0]));
             hipLaunchKernelGGL((stem_mfma_kernel<P, 2>), grid, dim3(256), 0, ctx->stream, vol, Yp, Xp, starts_dev, flip_dim, wst,
-                               L.bias, buf(0, A), net.partials, (const float2*)net.ss_of(0), d, h, w, tY, tX);
+                               L.bias16, buf(0, A), net.partials, (const float2*)net.ss_of(0), d, h, w, tY, tX);
             two_pass_stem = true;
         } else if (vol)
             hipLaunchKernelGGL((stem_conv_kernel<P, true>), grid, dim3(256), 0, ctx->stream, nullptr, vol, Yp, Xp, starts_dev,
-                               flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
+                               flip_dim, L.w_f32, L.bias, buf(0, A), net.partials, d, h, w, P::STEM_SCALE * exp2f(-(float)L.shift));
         else
             hipLaunchKernelGGL((stem_conv_kernel<P, false>), grid, dim3(256), 0, ctx->stream, xf, nullptr, 0, 0, nullptr, -1,
-                               L.w_f32, L.bias, buf(0, A), net.partials, d, h, w);
+                               L.w_f32, L.bias, buf(0, A), net.partials, d, h, w, P::STEM_SCALE * exp2f(-(float)L.shift));
         pr.end();
         DLV_LAUNCH_CHECK(ctx, "stem_conv_kernel");
         if (!two_pass_stem) {
@@ -1640,7 +1624,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         if (net.folds_up(li, skip[l].C, dm[l])) {
             // upcat_1: the transposed conv folded into the conv (upconv.hip): P from the activated coarse tensor, then the
             // 32-channel conv of the skip half with P as its addend - no up-sampled tensor, 8 coarse taps instead of 27 fine ones
-            DLV_TRY(net.conv_folded(li, skip[l], cur, buf(l, U), buf(l, A), b.p, dm[l], dm[l + 1]));  // (A: the next conv's output, free until then)
+            DLV_TRY(net.conv_folded(li, skip[l], cur, buf(l, U), b.p, dm[l], dm[l + 1]));
         } else {
             DLV_TRY(net.deconv(j, cur, buf(l, U), dm[l + 1]));
             Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
@@ -1654,7 +1638,6 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     }
     {
         dim3 grid(std::min(net.grid1d(dm[0].vox()), 512), B);  // (16 iterations per thread at 128^3 - the software pipeline wants a long loop: 1024 / 512 / 256 workgroups 515 / 487 / 484 us)
-        DLV_TRY(net.use(DLV_K_MEM, dm[0]));
         DlvProf pr(ctx, acc ? "final_conv_blend" : "final_conv_logits", 2.0 * 32 * (double)dm[0].vox() * B,
                    (double)dm[0].vox() * B * (64 + (acc ? 8 : 4)));
         if (acc)
@@ -1673,22 +1656,24 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
 template <class P>
 int pack_weights_16(dlv_ctx* ctx) {
     auto dst = [](auto& L) { return const_cast<uint16_t*>(wpack<P>(L)); };
-    hipLaunchKernelGGL(pack_stem_w_kernel<P>, dim3(8), dim3(256), 0, ctx->stream, ctx->conv[0].w_f32, dst(ctx->conv[0]));
+    hipLaunchKernelGGL(pack_stem_w_kernel<P>, dim3(8), dim3(256), 0, ctx->stream, ctx->conv[0].w_f32, dst(ctx->conv[0]), exp2f(-(float)ctx->conv[0].shift));
     DLV_LAUNCH_CHECK(ctx, "pack_stem_w_kernel");
+    for (int i = 0; i < DLV_N_CONV; ++i) {  // the bias the 16-bit kernels add: scaled like the weights
+        const DlvConvLayer& L = ctx->conv[i];
+        hipLaunchKernelGGL(scale_copy_kernel, dim3(dlv_cdiv(L.cout, 256)), dim3(256), 0, ctx->stream, L.bias, L.bias16, L.cout, exp2f(-(float)L.shift));
+        DLV_LAUNCH_CHECK(ctx, "scale_copy_kernel");
+    }
     for (int i = 1; i < DLV_N_CONV; ++i) {
         const DlvConvLayer& L = ctx->conv[i];
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "conv %d: %d->%d not multiples of 32", i, L.cin, L.cout);
-        hipLaunchKernelGGL(pack_conv_w_kernel<P>, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->conv[i]), L.cout, L.cin);
+        const float ws = exp2f(-(float)L.shift);
+        hipLaunchKernelGGL(pack_conv_w_kernel<P>, dim3(256), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->conv[i]), L.cout, L.cin, ws);
         DLV_LAUNCH_CHECK(ctx, "pack_conv_w_kernel");
-        DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cout, L.cin));
-        if (P::IS_F16 && L.wwino_f16) DLV_TRY(dlv_pack_conv_wino(ctx, L.w_f32, L.wwino_f16, L.cout, L.cin));
-        if (L.up_corr) {  // upcat_1 / upcat_2 .conv_0: skip half as a 32-channel pack, up half folded with the transposed conv (upconv.hip)
-            const DlvDeconvLayer& Dl = ctx->deconv[i == 16 ? 3 : 2];
-            DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, L.cout, 32, L.cin, 0));
-            for (int sl = 0; sl < L.up_slices; ++sl)  // 32 input channels of the transposed conv per pack; the bias terms in the first table
-                DLV_TRY(dlv_pack_upconv(ctx, P::IS_F16, L.w_f32, L.cin, 32, Dl.w_f32, Dl.bias,
-                                        (P::IS_F16 ? L.wup_f16 : L.wup_bf16) + (size_t)sl * (2 * 2 * 4 * 8 * 64 * 8), L.up_corr + (size_t)sl * (8 * 8 * 32),
-                                        32 * sl, sl == 0 ? 1 : 0));
+        DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cout, L.cin, 0, 0, ws));
+        if (L.up_corr) {  // upcat_1.conv_0: skip half as a 32-channel pack, up half folded with the transposed conv (upconv.hip)
+            const DlvDeconvLayer& Dl = ctx->deconv[3];
+            DLV_TRY(dlv_pack_conv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, L.cout, 32, L.cin, 0, ws));
+            DLV_TRY(dlv_pack_upconv(ctx, P::IS_F16, L.w_f32, L.cin, 32, Dl.w_f32, Dl.bias, P::IS_F16 ? L.wup_f16 : L.wup_bf16, L.up_corr, 0, 1, ws));
         }
     }
     for (int j = 0; j < DLV_N_DECONV; ++j) {
@@ -1760,15 +1745,18 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx) {
 }
 
 int dlv_range_reset(dlv_ctx* ctx) {
-    DLV_HIP(ctx, hipMemsetAsync(ctx->range_flag, 0, sizeof(int), ctx->main_stream));
+    DLV_HIP(ctx, hipMemsetAsync(ctx->range_flag, 0, sizeof(int) * (1 + DLV_N_CONV), ctx->main_stream));
     return DLV_OK;
 }
 
 // after everything of the pass / forward has been ordered behind the main stream: read the guard word back
 int dlv_range_check(dlv_ctx* ctx, bool f16) {
-    int flag = 0;
-    DLV_HIP(ctx, hipMemcpyAsync(&flag, ctx->range_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->main_stream));
+    int words[1 + DLV_N_CONV] = {0};
+    DLV_HIP(ctx, hipMemcpyAsync(words, ctx->range_flag, sizeof(words), hipMemcpyDeviceToHost, ctx->main_stream));
     DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    const int flag = words[0];
+    for (int i = 0; i < DLV_N_CONV; ++i) memcpy(&ctx->range_peak[i], &words[1 + i], sizeof(float));
+    ctx->range_last = flag == 0 ? -1 : 100 - flag;
     if (flag == 0) return DLV_OK;
     const int layer = 100 - flag;
     static const char* const names[DLV_N_CONV] = {"conv_0.conv_0", "conv_0.conv_1", "down_1.conv_0", "down_1.conv_1", "down_2.conv_0",
@@ -1778,9 +1766,9 @@ int dlv_range_check(dlv_ctx* ctx, bool f16) {
     if (layer >= 0 && layer < DLV_N_CONV)
         return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: the InstanceNorm sums of conv block %d (%s) are not finite - a value of its input "
                         "(the block before it or the transposed conv feeding it) left the format%s", f16 ? "fp16" : "bf16", layer, names[layer],
-                        f16 ? "; use precision bf16 (8 exponent bits) for this checkpoint" : "");
+                        f16 ? "; use dlv_unet_set_conv_shift on the producing block (dlv_range_report) or precision bf16 (8 exponent bits) for this checkpoint" : "");
     return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: non-finite logits (raw output of the last conv block, upcat_1.conv_1)%s",
-                    f16 ? "fp16" : "bf16", f16 ? "; use precision bf16 (8 exponent bits) for this checkpoint" : "");
+                    f16 ? "fp16" : "bf16", f16 ? "; use dlv_unet_set_conv_shift on upcat_1.conv_1 (dlv_range_report) or precision bf16 (8 exponent bits) for this checkpoint" : "");
 }
 
 int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16) {

@@ -42,7 +42,7 @@ constexpr int UC_CS = ((UC_HZ * UC_HY * UC_HX + 15) / 16) * 16;  // chunk stride
 // leaves is index 0 on an even, index 1 on an odd coordinate)  of  sum_{t -> d} sum_c' Wc[co][Cs+c'][t] bd[c']
 template <class P>
 __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int cs, const float* __restrict__ wd, const float* __restrict__ bd,
-                                   uint16_t* __restrict__ wpk, float* __restrict__ corr, int ci0, int with_corr) {
+                                   uint16_t* __restrict__ wpk, float* __restrict__ corr, int ci0, int with_corr, float wscale) {
     const int cup = 32, cin = 32;
     // taps of one axis that map (parity p) to coarse index i: t in {-1,0,1} with floor((p + t) / 2) + 1 - p == i
     auto maps = [](int p, int t, int i) { return ((p + t + 2) >> 1) - 1 + 1 - p == i; };
@@ -61,7 +61,7 @@ __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int c
                     for (int c = 0; c < cup; ++c)
                         s = __fmaf_rn(wc[((long long)co * ctot + cs + c) * 27 + t], wd[((long long)(ci0 + ci) * cup + c) * 8 + par], s);
                 }
-        wpk[e] = (uint16_t)(P::pack2(s, 0.f) & 0xffffu);
+        wpk[e] = (uint16_t)(P::pack2(s * wscale, 0.f) & 0xffffu);  // (wscale: the conv's 2^-shift, a linear factor of the whole product)
     }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 8 * 8 * 32; e += gridDim.x * blockDim.x) {
         const int co = e & 31, mask = (e >> 5) & 7, pi = e >> 8;
@@ -80,7 +80,7 @@ __global__ void pack_upconv_kernel(const float* __restrict__ wc, int ctot, int c
                     const int t = ((tz + 1) * 3 + (ty + 1)) * 3 + (tx + 1);
                     for (int c = 0; c < cup; ++c) s = __fmaf_rn(wc[((long long)co * ctot + cs + c) * 27 + t], bd[c], s);
                 }
-        corr[e] = with_corr ? -s : 0.f;  // (a later K-slice of the same transposed conv: the bias terms are in the first slice's table)
+        corr[e] = with_corr ? -s * wscale : 0.f;  // (a later K-slice of the same transposed conv: the bias terms are in the first slice's table)
     }
 }
 
@@ -448,11 +448,11 @@ upconv2m_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, con
 }  // namespace
 
 int dlv_pack_upconv(dlv_ctx* ctx, bool f16, const float* wc, int ctot, int cs, const float* wd, const float* bd, uint16_t* wpk, float* corr, int ci0,
-                    int with_corr) {
+                    int with_corr, float wscale) {
     if (f16)
-        hipLaunchKernelGGL(pack_upconv_kernel<PF16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr);
+        hipLaunchKernelGGL(pack_upconv_kernel<PF16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr, wscale);
     else
-        hipLaunchKernelGGL(pack_upconv_kernel<PBf16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr);
+        hipLaunchKernelGGL(pack_upconv_kernel<PBf16>, dim3(64), dim3(256), 0, ctx->stream, wc, ctot, cs, wd, bd, wpk, corr, ci0, with_corr, wscale);
     DLV_LAUNCH_CHECK(ctx, "pack_upconv_kernel");
     return DLV_OK;
 }
@@ -474,7 +474,6 @@ int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, 
         static int ncu = 0;
         if (!ncu) DLV_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
         int cus = ncu;
-        if (ctx->split_active && ctx->split_mem_cus > 0) cus = std::max(8, ncu - 8 * ctx->split_mem_cus);
         const int tilesWin = tilesX * tilesY * tilesZ, total = tilesWin * B;
         int grid = dlv_cdiv(total, dlv_cdiv(total, cus));  // every workgroup walks over the same number of tiles (+-1)
         if (total % 8 == 0) grid = std::min(cus / 8 * 8, dlv_cdiv(grid, 8) * 8);  // the same number of workgroups on every XCD

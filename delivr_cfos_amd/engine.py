@@ -633,17 +633,31 @@ class HipEngine:
         return out
 
     # ---- kernel timer ------------------------------------------------------------------------------
+    # ---- fp16 range guard: per-block output shift (dlv_unet_set_conv_shift) ----------------------------------------
+    def set_conv_shift(self, layer: int, shift: int) -> None:
+        """conv block `layer` (0..17) stores its raw output 2^-shift times smaller (16-bit paths only; InstanceNorm removes the
+        factor exactly)"""
+        self._enter()
+        self._check(self.lib.dlv_unet_set_conv_shift(self.ctx, int(layer), int(shift)))
+        self._leave()
+
+    def conv_shifts(self):
+        out = []
+        for i in range(_lib.N_CONV):
+            v = C.c_int()
+            self._check(self.lib.dlv_unet_get_conv_shift(self.ctx, i, C.byref(v)))
+            out.append(v.value)
+        return out
+
+    def range_report(self):
+        """(layer the last DLV_ERANGE named or -1, [|mean| + 8 sigma of every conv block's raw output where it exceeded 4096])"""
+        layer = C.c_int()
+        peaks = (C.c_float * _lib.N_CONV)()
+        self._check(self.lib.dlv_range_report(self.ctx, C.byref(layer), peaks))
+        return layer.value, [float(v) for v in peaks]
+
     def set_lanes(self, lanes: int):
         self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))
-
-    def set_conv_algo(self, algo) -> None:
-        """"direct" (default) or "winograd" (opt-in: F(2,3) along x for the fp16 Cin-32 convs of levels 0/1; dlv_set_conv_algo)."""
-        code = {"direct": 0, "winograd": 1}.get(algo, algo)
-        self._check(self.lib.dlv_set_conv_algo(self.ctx, int(code)))
-
-    def set_cu_split(self, mem_cus_per_xcd: int):
-        """0 = off; m = the HBM-class kernels of the 16-bit forward run on m CUs of every XCD, the convs on the other 32 - m."""
-        self._check(self.lib.dlv_set_cu_split(self.ctx, int(mem_cus_per_xcd)))
 
     def prof_enable(self, on: bool = True):
         self._check(self.lib.dlv_prof_enable(self.ctx, 1 if on else 0))

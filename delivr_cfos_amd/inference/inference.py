@@ -15,6 +15,7 @@ import numpy as np
 
 from ..hostlogic import arrayterator_zblock, padded_shape, pass_schedule
 from .._lib import DLV_ERANGE, DelivrHipError
+from ..range_guard import next_shifts, run_with_range_recovery
 from ..model import HipBasicUNet
 from .sliding_window_inferer import SlidingWindowInferer
 
@@ -189,21 +190,23 @@ def run_inference(
         args = (eng, dataset_host[0, 0], tuple(pad[2:]), (Z, Y, X), crop_size, overlap, bool(tta))
         kw = dict(threshold=threshold, need_count=need_count, gaussian=gaussian, plan=stream_plan, out_mask=out_mask, out_prob=out_prob,
                   verbose=bool(verbosity))
-        try:
-            run_inference_streamed(*args, precision=precision, **kw)
-        except DelivrHipError as e:
-            if e.code != DLV_ERANGE or precision != "fp16":
-                raise
-            print(f"WARNING: {e}\nWARNING: repeating the inference passes with bf16 operands")
-            precision = "bf16"
-            run_inference_streamed(*args, precision=precision, **kw)
+        # range guard (DLV_ERANGE): the failed run's slabs are released before the repeat starts (the retry runs outside the
+        # except block, whose traceback would keep the streamed slabs of the failed run alive in HBM)
+        def reset_streamed():
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+
+        precision = run_with_range_recovery(eng, precision, lambda prec: run_inference_streamed(*args, precision=prec, **kw), reset_streamed)
         print(f"{datetime.datetime.now()} : Creating binarized blob output")
         out_mask.flush()
         if out_prob is not None:
             out_prob.flush()
         del out_mask, out_prob
     elif not sharded:
-        def run_passes():
+        def run_passes(prec):
+            model.precision = prec
             for flip_dim, repeat in pass_schedule(bool(tta)):
                 kw = dict(output_image=output_image, count_map=count_map, repeat=repeat)
                 if flip_dim is not None:
@@ -211,19 +214,14 @@ def run_inference(
                 inferer(dataset, model, **kw)
             eng.sync()
 
-        try:
-            run_passes()
-        except DelivrHipError as e:
-            # range guard (DLV_ERANGE): this checkpoint drives a raw activation beyond fp16's 65504 - the library reports it
-            # instead of painting a garbage mask; bf16 has fp32's exponent range and is the documented alternative
-            if e.code != DLV_ERANGE or model.precision != "fp16":
-                raise
-            print(f"WARNING: {e}\nWARNING: repeating the inference passes with bf16 operands")
-            model.precision = precision = "bf16"
+        def reset_sums():
             output_image.zero_()
             if count_map is not None:
                 count_map.zero_()
-            run_passes()
+
+        # range guard (DLV_ERANGE): this checkpoint drives a raw activation beyond fp16's 65504 - the library reports it instead
+        # of painting a garbage mask; the block is rescaled (range_guard.py: fp16 keeps its 11 bits), bf16 is the last resort
+        precision = run_with_range_recovery(eng, model.precision, run_passes, reset_sums)
         # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
         print(f"{datetime.datetime.now()} : Creating binarized blob output")
         os.makedirs(binaries_path, exist_ok=True)
@@ -265,17 +263,31 @@ def run_inference(
                 return 1
             return 0
 
-        bad = torch.tensor([run_passes(precision)], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else eng.device)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()):  # some rank left fp16's range: every rank repeats its passes in bf16 (one mask, one format)
-            if rank == 0:
-                print("WARNING: repeating the inference passes with bf16 operands on every rank")
-            precision = "bf16"
+        # Every rank must end in the same format with the same block shifts (one mask): after each attempt the ranks exchange
+        # what their guards saw - the named layer (max) and the per-block peaks (max) - and derive the SAME remedy from it
+        gdev = "cpu" if dist.get_backend() == "gloo" else eng.device
+        for attempt in range(6):
+            bad = run_passes(precision)
+            layer, peaks = eng.range_report() if bad else (-1, [0.0] * 18)
+            rep = torch.tensor([float(bad), float(layer)] + list(peaks), dtype=torch.float32, device=gdev)
+            dist.all_reduce(rep, op=dist.ReduceOp.MAX)
+            if not rep[0].item():
+                break
+            plan = next_shifts(int(rep[1].item()), [float(v) for v in rep[2:].tolist()], eng.conv_shifts()) if attempt < 4 else None
+            if plan is None or precision != "fp16":
+                if precision != "fp16":
+                    raise RuntimeError("unreachable: bf16 range errors are raised")
+                if rank == 0:
+                    print("WARNING: repeating the inference passes with bf16 operands on every rank")
+                precision = "bf16"
+            else:
+                for p, k in sorted(plan.items()):
+                    if rank == 0:
+                        print(f"WARNING: conv block {p}: storing its raw output scaled by 2^-{k} on every rank and repeating the passes in fp16")
+                    eng.set_conv_shift(p, k)
             output_image.zero_()
             if count_map is not None:
                 count_map.zero_()
-            if run_passes(precision):
-                raise RuntimeError("unreachable: bf16 range errors are raised")
         exchange_seams(output_image, plan, rank, dist, z0=slo)
         if count_map is not None:
             exchange_seams(count_map, plan, rank, dist, z0=slo)

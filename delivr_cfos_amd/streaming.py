@@ -208,3 +208,24 @@ def ccl_streamed(engine, bin_img, n_slabs: int, scratch_path: str, create_output
         except OSError:
             pass
     return n_total, stats
+
+
+def stats_streamed(engine, labels, n_total: int, budget_bytes: int) -> dict:
+    """cc3d.statistics layout (count_blobs.py:85) of a FINAL label volume (host array / memmap, (Z, Y, X), any unsigned dtype)
+    that does not fit the HBM budget: raw accumulators slab by slab (dlv_cc_stats_raw_dev), merged exactly like the sharded
+    run's (parallel.merge_stats with identity renumbering) - counts, boxes and integer coordinate sums add up across slabs."""
+    from .parallel import merge_stats
+
+    torch = engine.torch
+    Z, Y, X = (int(v) for v in labels.shape)
+    planes = max(1, int(budget_bytes // max(1, Y * X * 4 * 2)))  # uint32 slab + headroom
+    ident = np.arange(n_total + 1, dtype=np.uint32)
+    luts, raws, offs = [], [], []
+    for lo in range(0, Z, planes):
+        hi = min(Z, lo + planes)
+        lab = torch.from_numpy(np.ascontiguousarray(labels[lo:hi]).astype(np.uint32).view(np.int32)).to(engine.device)
+        raws.append(engine.cc_stats_raw(lab, n_total))
+        luts.append(ident)
+        offs.append(lo)
+        del lab
+    return merge_stats(luts, raws, offs, (Z, Y, X), n_total)

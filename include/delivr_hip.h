@@ -349,29 +349,23 @@ typedef struct dlv_prof_entry {
     double flops;        /* algorithmic FLOPs summed over those launches */
     double bytes;        /* algorithmic HBM bytes summed over those launches */
 } dlv_prof_entry;
+/* fp16 range guard, the remedy.  fp16 ends at 65504; a checkpoint whose RAW (pre-normalisation) output of conv block `layer`
+ * exceeds it makes dlv_sw_infer_dev / dlv_unet_forward_dev return DLV_ERANGE.  Every 3x3x3 conv of the network is followed by
+ * InstanceNorm, which is invariant to a scale of its input: dlv_unet_set_conv_shift(ctx, layer, k) packs that block's 16-bit
+ * weights (and bias) multiplied by 2^-k (exact) and normalises with eps * 4^-k - the stored raw tensor is 2^k times smaller, the
+ * normalised value the same, the format stays fp16 (11 significant bits; bf16, the other way out, has 8).  The fp32 path is
+ * not affected.  Shifts are reset by dlv_unet_load / dlv_unet_alloc_blob; a rank that received its weights by broadcast sets
+ * the same shifts itself.  dlv_range_report: the layer the last DLV_ERANGE named (-1: none; 18: the logits) - its INPUT
+ * overflowed, i.e. the block(s) feeding it - and per conv block the largest |mean| + 8 sigma of its raw output (in stored
+ * units, 0 where it stayed below 4096) seen since the last pass started: the hint for k.  inference/inference.py's
+ * run_inference applies both before it falls back to bf16.  No reference counterpart (the reference network is fp32:
+ * inference/sliding_window_inferer.py:205-229). */
+int dlv_unet_set_conv_shift(dlv_ctx* ctx, int layer, int shift);
+int dlv_unet_get_conv_shift(dlv_ctx* ctx, int layer, int* shift);
+int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks /* [DLV_N_CONV] or NULL */);
 /* 1 = run batches back to back on the ctx stream; 2 .. 6 (default 3) = rotate consecutive batches over that many HIP
  * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
 int dlv_set_lanes(dlv_ctx* ctx, int lanes);
-/* EXPERIMENTAL / diagnostic: slower than the default pipeline in every measured configuration; gfx950 with
- * 256 CUs in 8 XCDs only (DLV_EUNSUP on anything else).
- * CU split: spatial partition of the chip for dlv_sw_infer_dev's 16-bit path.  mem_cus_per_xcd = 0 (off): every kernel may
- * use all 256 CUs.  1..31: the 3x3x3 convs of a forward run on the first 32 - m CUs of every XCD, its HBM-class kernels
- * (stem, InstanceNorm+Mish passes, transposed convs, final conv + blend) on the remaining m, on CU-masked streams
- * (hipExtStreamCreateWithCUMask) - the two kinds of work of neighbouring batches then run side by side instead of
- * competing for the same SIMDs; lanes (dlv_set_lanes) = batches in flight, 1..6.  -1: no CU masks, but the two kinds of
- * kernels on a high- and a low-priority stream per lane.  Results are identical to the unsplit pass in every mode.  The DLV_CU_SPLIT environment variable sets the value a new context starts with.  No reference counterpart. */
-int dlv_set_cu_split(dlv_ctx* ctx, int mem_cus_per_xcd);
-/* Algorithm of the fp16 3x3x3 convolutions with 32 input channels at the two top levels (5 of the 7 convs that hold 91 % of
- * the FLOPs).  DLV_CONV_DIRECT (default): the 27-tap implicit GEMM for every layer.  DLV_CONV_WINOGRAD (opt-in, fp16 only):
- * Winograd F(2,3) along x, direct in y and z - 36 instead of 54 MFMAs per 32 voxels; weights transformed in fp32 and
- * rounded to fp16 once, the input transform is one packed fp16 add per element, accumulation and the output transform
- * are fp32.  Measured (round 4, profiles/README.md): 3-4.5 % faster per layer only - the staging of the halo planes, not
- * the MFMAs, is what a z step pays for - at 706 instead of 529 flipped voxels of 16.8 M against the reference's arithmetic
- * (mask IoU 0.99969 instead of 0.99977; north_star tolerance 0.999): not the default.  Replaces the cuDNN algorithm
- * choice behind torch.nn.Conv3d (inference/inference.py:190-197); no reference counterpart for the switch. */
-#define DLV_CONV_DIRECT 0
-#define DLV_CONV_WINOGRAD 1
-int dlv_set_conv_algo(dlv_ctx* ctx, int algo);
 int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch with hipEvents */
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */

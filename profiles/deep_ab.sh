@@ -4,6 +4,6 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 for M in ${1:-0 3}; do
-  echo "=== DLV_DEEP_MASK=$M"
+  echo "=== DLV_DEEP_MASK=$M ${3:-}"
   DLV_DEEP_MASK=$M python3 profiles/zreg_ab.py 0 3 128,256,2048 ${2:-fp16} 2>&1 | grep -E "wall|conv3_(deep|mfma|zmarch)|deconv|norm|stats" | grep -v "^{"
 done

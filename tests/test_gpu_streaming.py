@@ -112,7 +112,19 @@ def test_streamed_pipeline_is_bit_identical_on_the_trained_like_checkpoint(tmp_p
         assert np.array_equal(a["stats"][k], b["stats"][k]), k
     assert np.array_equal(a["stats"]["centroids"], b["stats"]["centroids"], equal_nan=True)
     assert a["csv"] == b["csv"]
-    assert a["files"] == b["files"]  # (the scratch file of the streamed labelling is gone)
+    assert a["files"] == b["files"]  # (the scratch file of the streamed labelling is gone, the label file carries its final name)
+    # a second call finds the cached labelling; with the statistics removed they are recomputed from the CACHED labels - slab by
+    # slab under the small budget (stats_streamed) - and equal the first run's
+    st = _settings(tmp_path / "streamed", crop, hbm_budget_gb=0.012)
+    out_dir = st["postprocessing"]["output_location"]
+    os.remove(os.path.join(out_dir, "b-stats.pickle"))
+    N2 = count_blobs(st, str(tmp_path / "streamed" / "02"), 1, "b", (1, 1) + vol.shape)
+    txt = capsys.readouterr().out
+    assert N2 == b["N"] and "Cached brain found" in txt, txt
+    again = pickle.load(open(os.path.join(out_dir, "b-stats.pickle"), "rb"))
+    for k in ("voxel_counts", "bounding_boxes"):
+        assert np.array_equal(again[k], b["stats"][k]), k
+    assert np.array_equal(again["centroids"], b["stats"]["centroids"], equal_nan=True)
 
 
 def test_a_budget_nothing_fits_is_reported_with_sizes(tmp_path):

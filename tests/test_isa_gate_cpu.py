@@ -23,8 +23,11 @@ def _need_tools():
     llvm = "/opt/rocm/lib/llvm/bin"
     if not (os.path.isfile(os.path.join(llvm, "llvm-readelf")) and os.path.isfile(os.path.join(llvm, "llvm-objdump"))):
         pytest.skip("ROCm LLVM tools (llvm-readelf / llvm-objdump) are not installed on this host")
-    if not os.path.isfile(LIB):
-        pytest.skip("libdelivr_hip.so is not built (make -C delivr_cfos_amd/csrc)")
+    if not os.path.isfile(LIB):  # a missing library is built (as tests/test_abi_cpu.py does), never skipped: the gate stays on
+        import __graft_entry__ as g
+
+        g.build()
+    assert os.path.isfile(LIB), "libdelivr_hip.so is not built (make -C delivr_cfos_amd/csrc)"
 
 
 def test_scanner_finds_a_planted_readback_hazard():
@@ -58,15 +61,7 @@ def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd()
     _need_tools()
     hs = _tool()
     rep = hs.library_report(LIB)
-    wino = {k: v for k, v in rep.items() if "zwino" in k}
-    rep = {k: v for k, v in rep.items() if "zwino" not in k}
-    assert len(rep) == 18, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with one and with two addends; Cin 64: t8 a0/a1)
-    assert len(wino) == 1, sorted(wino)  # the opt-in Winograd F(2,3)-x variant: 36 weight fragments = 144 AGPRs
-    for name, r in wino.items():
-        assert r["hazards"] == 0 and r["readback_hazards"] == 0, (name, r["first"], r["first_readback"])
-        assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, name
-        assert 144 <= r["agpr_count"] < r["vgpr_count"] <= 512, (name, r["vgpr_count"], r["agpr_count"])
-        assert r["mfma"] == 864, (name, r["mfma"])  # 2 x 3 steps x 144
+    assert len(rep) == 14, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with an addend; Cin 64: t8 a0/a1)
     for name, r in rep.items():
         assert r["hazards"] == 0, (name, r["first"])
         assert r["readback_hazards"] == 0, (name, r["first_readback"])  # asm MFMA result read too early by non-MFMA code
