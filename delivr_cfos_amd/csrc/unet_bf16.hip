@@ -29,8 +29,10 @@ namespace {
 __device__ __forceinline__ float mish_fast(float y) {
     // y * tanh(softplus(y)) = y * t / (t + 2) = y - 2y / d,  d = t + 2 = n (n + 2) + 2,  n = e^y.
     // In this form nothing has to be clamped: for large y, n and d overflow to +inf, 1/d = 0 and the result is y exactly (torch's
-    // softplus threshold does the same from y = 20).  For very negative y the difference cancels to |y| * 1e-7 absolute - below
-    // half an ulp of the 16-bit store for every value the formats can hold.  One v_exp_f32 + one v_rcp_f32 (1 ulp) and four plain
+    // softplus threshold does the same from y = 20).  For very negative y the difference y - 2y/d cancels: its absolute error is
+    // |y| * 2^-23 (about 1e-6 at y = -10, where the exact value is -4.5e-4 and fp16's half ulp 2.4e-7: a relative 2e-3 of a value
+    // that is itself 5e-4 of the tensor's scale - inside the 1e-3 rel. RMS the 16-bit forward is held to, not below the store's
+    // rounding as an earlier comment claimed).  One v_exp_f32 + one v_rcp_f32 (1 ulp) and four plain
     // VALU ops; __fdividef would expand to the 10-instruction IEEE division sequence.
     const float n = __builtin_amdgcn_exp2f(y * 1.44269504f);
     const float d = fmaf(n, n + 2.f, 2.f);
@@ -1530,6 +1532,8 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     const int* f = ctx->features;
     if (f[0] != 32 || f[5] != 32)
         return dlv_fail(ctx, DLV_EUNSUP, "bf16 path: features[0] and features[5] must be 32 (got %d, %d)", f[0], f[5]);
+    // the stem, the final conv and the norm passes index a window's voxels with 32 bits (whatever conv kernel runs in between)
+    if ((long long)d * h * w >= (1ll << 31)) return dlv_fail(ctx, DLV_EUNSUP, "16-bit path: a window of %d x %d x %d voxels exceeds the 2^31 voxel index range", d, h, w);
     Dims dm[5];
     for (int l = 0; l < 5; ++l) dm[l] = Dims{d >> l, h >> l, w >> l};
     const int lvlC[5] = {32, f[1], f[2], f[3], f[4]};

@@ -126,8 +126,9 @@ def test_conv_shift_is_invisible_behind_instancenorm_and_cures_the_overflow():
             plan = next_shifts(named, peaks, eng.conv_shifts())
             if layer == 5:  # the fp32 statistics of the block itself stayed finite and say how large it is: one step
                 assert peaks[layer] > 1e6 and plan == {layer: plan[layer]} and 10 <= plan[layer] <= 30, (named, peaks, plan)
-            else:           # the folded up half of block 16 overflows before the block's statistics exist: 6 bits at a time
-                assert named == 16 and plan == {16: 6 * (attempt + 1)}, (named, plan)
+            else:           # the folded up half of block 16 (P, 16-bit) overflows before the block's statistics exist: 6 bits blind,
+                            # then the block's own statistics - finite once P is - give the rest
+                assert named in (16, 17) and list(plan) == [16], (named, plan)
             for p, k in plan.items():
                 eng.set_conv_shift(p, k)
             try:
@@ -137,6 +138,7 @@ def test_conv_shift_is_invisible_behind_instancenorm_and_cures_the_overflow():
                 assert e.code == DLV_ERANGE
         assert np.isfinite(got).all()
         plan = {i: k for i, k in enumerate(eng.conv_shifts()) if k}
+        assert list(plan) == [layer] and 8 <= plan[layer] <= 30, plan
         rel = float(np.sqrt(np.mean((got - base) ** 2)) / base.std())
         print(f"{key} x 1e6 with shifts {plan}: rel rms vs the unscaled fp16 pass {rel:.2e}")
         assert rel < 2e-3, rel
