@@ -191,7 +191,11 @@ static size_t layout_blob(dlv_ctx* ctx, const int f[6], char* base) {
         float* b = (float*)take((size_t)dcout[j] * 4);
         uint16_t* wb = (uint16_t*)take(nw * 2);
         uint16_t* wh = (uint16_t*)take(nw * 2);
+        uint16_t* wb16 = dcin[j] >= 128 ? (uint16_t*)take(nw * 2) : nullptr;
+        uint16_t* wh16 = dcin[j] >= 128 ? (uint16_t*)take(nw * 2) : nullptr;
         if (base) {
+            ctx->deconv[j].w16_bf16 = wb16;
+            ctx->deconv[j].w16_f16 = wh16;
             ctx->deconv[j].w_f16 = wh;
             ctx->deconv[j].cin = dcin[j];
             ctx->deconv[j].cout = dcout[j];

@@ -55,6 +55,8 @@ struct DlvDeconvLayer {
     float* bias = nullptr;      // (Cout)
     uint16_t* w_bf16 = nullptr; // fragment order, per output parity
     uint16_t* w_f16 = nullptr;
+    uint16_t* w16_bf16 = nullptr;  // Cin >= 128: v_mfma_f32_16x16x32 A-fragment order [parity][cout/16][cin/32][lane][8] (conv_deep.hip)
+    uint16_t* w16_f16 = nullptr;
 };
 
 enum DlvWsSlot {
@@ -218,6 +220,11 @@ int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const voi
 bool dlv_conv3_deep_supports(int cin, int cout, int c1, int c2, int D, int H, int W);
 int dlv_conv3_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2, const void* wpk16,
                           void* out, float* partials, int B, int D, int H, int W, int* nparts);
+// transposed conv of the deep levels (conv_deep.hip): Cin 128 / 256, LDS-shared weights; `in` holds final (activated) values
+bool dlv_deconv2_deep_supports(int cin, int cout, int D, int H, int W);
+int dlv_pack_deconv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cin, int cout);
+int dlv_deconv2_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in, const void* wpk16, const float* bias, void* out, int B,
+                            int D, int H, int W);
 // register-resident-weights z-march conv (conv_zreg.hip): Cout blocks of 32, Cin = 32, 32+32 or 64; ss1 / ss2 =
 // InstanceNorm scale/shift of the layer that produced in1 / in2 (applied with Mish while staging) or nullptr
 int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* ss1, const void* in2,

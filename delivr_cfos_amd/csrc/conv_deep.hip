@@ -357,6 +357,200 @@ int cd_launch(dlv_ctx* ctx, const void* in1, int c1, const void* in2, int c2, co
     return DLV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The transposed convs of the deep levels (ConvTranspose3d k2 s2, Cin 256 -> 128 at 8^3 and 128 -> 64 at 16^3 per 128^3 window):
+// eight 1x1x1 channel GEMMs (one per output parity) of few voxels and many weights.  The kernel they ran in before
+// (deconv2_wst_kernel: a wave keeps the fragments of ONE (parity pair, 32-channel block) and walks 4 row segments) re-reads its
+// 32 KiB of weights per 128 MFMAs and wave and wastes half of every 16-voxel segment at the 8-wide level: 53 + 45 us per 16
+// windows for 4 + 8 GFLOP.  Here
+//   workgroup = 8 waves (2 per SIMD) x TWO blocks of 16 consecutive voxels (linear order: a row, or two rows of 8): their
+//               input fragments (2 x Cin/32 x 1 KiB per wave) stay in registers for the whole walk;
+//   walk      = the (parity, 64-channel output group) pairs of this workgroup's share of the output channels: a pair's A
+//               fragments (4 x Cin/32 KiB) are staged in a ring of three LDS stages by LDS-DMA - once per workgroup, read by all
+//               8 waves - TWO pairs ahead behind a counted vmcnt (one pair ahead the L2 round trip was in front of every pair:
+//               28 instead of 57 us, not the 10 the arithmetic asks for); 8 x Cin/32 MFMAs (v_mfma_f32_16x16x32) per wave and
+//               pair, then 8 x 8-byte buffer stores per lane (lanes without a voxel: out-of-range offsets).
+// Weights: [parity 8][cout/16][cin/32][lane 64][8] (pack_deconv_w16_kernel).  Input: final (activated) values.
+// Reference: the ConvTranspose3d of MONAI's UpCat blocks upcat_4 / upcat_3 (inference/inference.py:190-197).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class P>
+__global__ void pack_deconv_w16_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cin, int cout) {
+    const int KS = cin / 32, CB = cout / 16;
+    const long long n = (long long)cin * cout * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        long long r = i >> 9;
+        const int ks = (int)(r % KS);
+        r /= KS;
+        const int cb = (int)(r % CB);
+        const int par = (int)(r / CB);
+        const int co = cb * 16 + (lane & 15);
+        const int ci = ks * 32 + 8 * (lane >> 4) + j;
+        out[i] = (uint16_t)(P::pack2(w[((long long)ci * cout + co) * 8 + par], 0.f) & 0xffffu);
+    }
+}
+
+template <class P, int KS>
+__global__ void __launch_bounds__(512, 2)
+deconv2_deep_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ bias, uint4* __restrict__ out,
+                    int cout, int D, int H, int W, int groups_per_wg) {
+    constexpr int STAGE = 4 * KS * 64;  // uint4 of one (parity, 64-channel group): 4 output blocks of 16 x KS fragments
+    constexpr int NST = 3, NBLK = 2;    // LDS stages (a pair is fetched TWO pairs ahead), voxel blocks per wave
+    constexpr int ND = 4 * KS / 8;      // LDS-DMA instructions per wave and pair
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* wst = reinterpret_cast<uint4*>(smem_raw);  // [NST][4 cb16][KS][64 lanes]
+    float* bias_l = reinterpret_cast<float*>(wst + NST * STAGE);  // [cout]: read with ds_read - a global load inside the walk would
+                                                                  // make hipcc drain vmcnt, i.e. wait for the LDS-DMA just issued
+    for (int i = threadIdx.x; i < cout; i += 512) bias_l[i] = bias[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l16 = lane & 15, q = lane >> 4;
+    const int n = blockIdx.z;
+    const int vox = D * H * W, ovox = vox * 8;
+    const int cin8 = KS * 4, cout8 = cout / 8, CB = cout / 16;
+    const int g0 = blockIdx.y * groups_per_wg;  // this workgroup's 64-channel groups [g0, g0 + groups_per_wg)
+    const int OH = 2 * H, OW = 2 * W;
+    // input fragments: lane (q, l16) holds channels ks*32 + 8q .. +7 of voxel l16 of block blk
+    uint4 bf[NBLK][KS];
+    unsigned obase[NBLK];  // byte offset of the voxel's parity-0 output inside this sample's first output chunk, or out of range
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const int v = ((blockIdx.x * 8 + wave) * NBLK + blk) * 16 + l16;
+        const bool vok = v < vox;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bf[blk][ks] = vok ? in[((long long)n * cin8 + ks * 4 + q) * vox + v] : make_uint4(0u, 0u, 0u, 0u);
+        const int x = v % W, y = (v / W) % H, z = v / (W * H);
+        obase[blk] = vok ? (unsigned)(((2 * z) * OH + 2 * y) * OW + 2 * x) * 16u : 0xf0000000u;  // (+ 16 for the x-parity-1 voxel: odd rows)
+    }
+    // (the fragments are in their registers BEFORE the first LDS-DMA is issued: hipcc's own wait for them - placed at their
+    // first use - would otherwise also wait for every DMA piece in flight at that point)
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(bf[blk][ks].x), "v"(bf[blk][ks].y), "v"(bf[blk][ks].z), "v"(bf[blk][ks].w) : "memory");
+    // stores through a buffer resource over this sample's output (a lane without a voxel carries an offset beyond it: the
+    // hardware drops its store) - every wave issues the same number of vector-memory instructions per pair, which is what the
+    // counted vmcnt below relies on
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out + (long long)n * cout8 * ovox), 0,
+                                                                         (int)((long long)cout8 * ovox * 16), 0x00020000);
+
+    typedef unsigned cd_u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned cd_u32x2 __attribute__((ext_vector_type(2)));
+    cd_u32x4 wrs;
+    {
+        const unsigned long long wa = (unsigned long long)reinterpret_cast<uintptr_t>(wpk);
+        wrs.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa);
+        wrs.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32)) & 0xffffu;
+        wrs.z = (unsigned)((long long)cout * KS * 32 * 8 * 2);
+        wrs.w = 0x00020000u;
+    }
+    const unsigned wst_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wst;
+    const unsigned dma_voff = (unsigned)lane * 16u;
+    // pair p of this workgroup: x parity p & 1, group g0 + (p >> 1) % groups_per_wg, (z, y) parity p / (2 groups_per_wg): the two x
+    // parities of one (z, y, group) follow each other, so that their results - neighbouring output voxels - leave in 16-byte
+    // stores (below); a pair's fragments are contiguous in the pack: [par][cb16 = 4 g .. 4 g + 3][ks] = 4 * KS KiB
+    const int npairs = 8 * groups_per_wg;
+    auto pair_of = [&](int p, int& par, int& g) __attribute__((always_inline)) {
+        par = (p / (2 * groups_per_wg)) * 2 + (p & 1);
+        g = g0 + (p >> 1) % groups_per_wg;
+    };
+    auto dma_pair = [&](int p, int st) __attribute__((always_inline)) {
+        int par, g;
+        pair_of(p, par, g);
+        const unsigned base = (unsigned)((par * CB + 4 * g) * KS) * 1024u;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int f = wave + 8 * i;
+            const unsigned src = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)f * 1024u));
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(wst_lds + (unsigned)(st * STAGE + f * 64) * 16u));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(dma_voff), "s"(wrs), "s"(src) : "memory");
+        }
+    };
+    dma_pair(0, 0);
+    if (npairs > 1) dma_pair(1, 1);
+    if (npairs > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // pair 0 has landed
+    cd_u32x2 keep[NBLK][4];  // the packed x-parity-0 result of the even iteration
+    int st = 0;
+    for (int p = 0; p < npairs; ++p) {
+        // (stage (p + 2) % 3 was read in iteration p - 1: everybody passed the barrier that ended it)
+        if (p + 2 < npairs) dma_pair(p + 2, st == 0 ? 2 : st - 1);
+        int par, g;
+        pair_of(p, par, g);
+        const uint4* wb = wst + st * STAGE + lane;
+        cd_f32x4 acc[NBLK][4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_l + (4 * g + cb) * 16 + 4 * q);
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) acc[blk][cb] = cd_f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const uint4 a = wb[(cb * KS + ks) * 64];
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) acc[blk][cb] = cd_mfma<P>(a, bf[blk][ks], acc[blk][cb]);
+            }
+        // Stores: a lane holds 8 bytes (channels 4q .. 4q+3) of its voxel's 16-byte chunk word, its row neighbour (q ^ 1) the other 8;
+        // the x-parity-1 result of the same voxel is the NEXT output voxel.  The even iteration keeps its packed result; the odd one
+        // swaps rows with v_permlane16_swap (odd rows of the first operand <-> even rows of the second): even-q lanes then hold
+        // the whole 16-byte word of the parity-0 voxel, odd-q lanes that of the parity-1 voxel - one 16-byte store per lane, a lane
+        // pair writes 32 contiguous bytes, a row pair 512 (8-byte stores at a 32-byte stride took 2/3 of the kernel's time)
+        if ((p & 1) == 0) {
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) keep[blk][cb] = cd_u32x2{P::pack2(acc[blk][cb][0], acc[blk][cb][1]), P::pack2(acc[blk][cb][2], acc[blk][cb][3])};
+            if (p + 2 < npairs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const unsigned poff = (unsigned)(((par >> 2) * OH + ((par >> 1) & 1)) * OW) * 16u + (unsigned)(q & 1) * 16u;
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const unsigned o0 = P::pack2(acc[blk][cb][0], acc[blk][cb][1]), o1 = P::pack2(acc[blk][cb][2], acc[blk][cb][3]);
+                    const auto sx = __builtin_amdgcn_permlane16_swap(keep[blk][cb][0], o0, false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(keep[blk][cb][1], o1, false, false);
+                    // (lane of an even row: sx[0], sy[0] = its own parity-0 half, sx[1], sy[1] = the odd row's parity-0 half; odd row:
+                    // sx[0], sy[0] = the even row's parity-1 half, sx[1], sy[1] = its own)
+                    __builtin_amdgcn_raw_buffer_store_b128(cd_u32x4{sx[0], sy[0], sx[1], sy[1]}, ors,
+                                                           (int)(obase[blk] + poff + (unsigned)(q >> 1) * (unsigned)ovox * 16u),
+                                                           (int)((unsigned)((4 * g + cb) * 2) * (unsigned)ovox * 16u), 0);
+                }
+            // this wave's vector-memory instructions in program order: DMA(p+1), DMA(p+2), stores(p): pair p + 1 has landed when all
+            // but the youngest ND + 4 NBLK are done
+            if (p + 2 < npairs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND + 4 * NBLK) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NBLK) : "memory");
+        }
+        __syncthreads();
+        st = st == 2 ? 0 : st + 1;
+    }
+}
+
+template <class P, int KS>
+int dd_launch(dlv_ctx* ctx, const void* in, const void* wpk16, const float* bias, void* out, int cout, int B, int D, int H, int W) {
+    const int vox = D * H * W, G = cout / 64;
+    // output channels are split over workgroups until a launch has a few hundred of them (a property of the layer and window
+    // shape, not of the batch: every output element is computed by exactly one workgroup either way)
+    int gpw = G;
+    while (gpw > 1 && (long long)dlv_cdiv(vox, 256) * (G / gpw) < 16) gpw >>= 1;
+    const size_t lds = (size_t)3 * 4 * KS * 64 * 16 + (size_t)cout * 4;
+    static dlv_attr_bits attr_set{0};
+    if (!dlv_attr_is_set(attr_set, ctx->device)) {
+        DLV_HIP(ctx, hipFuncSetAttribute((const void*)deconv2_deep_kernel<P, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dlv_attr_mark(attr_set, ctx->device);
+    }
+    hipLaunchKernelGGL((deconv2_deep_kernel<P, KS>), dim3(dlv_cdiv(vox, 256), G / gpw, B), dim3(512), lds, ctx->stream, (const uint4*)in,
+                       (const uint4*)wpk16, bias, (uint4*)out, cout, D, H, W, gpw);
+    DLV_LAUNCH_CHECK(ctx, "deconv2_deep_kernel");
+    return DLV_OK;
+}
+
 }  // namespace
 
 // which layers the kernel takes: the deep levels of a window (at most 32^3 voxels), channel counts in multiples of 32 / 64
@@ -391,4 +585,22 @@ int dlv_conv3_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     if (ncb4) CD_GO(PBf16, 8, 4);
     CD_GO(PBf16, 8, 2);
 #undef CD_GO
+}
+
+// ---- transposed conv of the deep levels -------------------------------------------------------------------------------------
+bool dlv_deconv2_deep_supports(int cin, int cout, int D, int H, int W) {
+    return (cin == 128 || cin == 256) && cout % 64 == 0 && cout > 0 && (long long)D * H * W <= 32768 && W >= 1;
+}
+int dlv_pack_deconv_w16(dlv_ctx* ctx, bool f16, const float* w_f32, uint16_t* out, int cin, int cout) {
+    if (f16) hipLaunchKernelGGL(pack_deconv_w16_kernel<PF16>, dim3(64), dim3(256), 0, ctx->stream, w_f32, out, cin, cout);
+    else hipLaunchKernelGGL(pack_deconv_w16_kernel<PBf16>, dim3(64), dim3(256), 0, ctx->stream, w_f32, out, cin, cout);
+    DLV_LAUNCH_CHECK(ctx, "pack_deconv_w16_kernel");
+    return DLV_OK;
+}
+// in: FINAL (activated) values; out: raw transposed-conv output (bias added), chunk-planar (B, cout, 2D, 2H, 2W)
+int dlv_deconv2_deep_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in, const void* wpk16, const float* bias, void* out, int B,
+                            int D, int H, int W) {
+    if (!dlv_deconv2_deep_supports(cin, cout, D, H, W)) return dlv_fail(ctx, DLV_EUNSUP, "deep deconv: unsupported layer shape");
+    if (f16) return cin == 256 ? dd_launch<PF16, 8>(ctx, in, wpk16, bias, out, cout, B, D, H, W) : dd_launch<PF16, 4>(ctx, in, wpk16, bias, out, cout, B, D, H, W);
+    return cin == 256 ? dd_launch<PBf16, 8>(ctx, in, wpk16, bias, out, cout, B, D, H, W) : dd_launch<PBf16, 4>(ctx, in, wpk16, bias, out, cout, B, D, H, W);
 }

@@ -1486,9 +1486,16 @@ struct Net16 {
                           din.vox() * 8 * 4 * 16 < (1ll << 32);  // (its stores address one sample's output with 32-bit offsets)
         if (regw) grid.x = dlv_cdiv((long long)din.D * din.H * segs, 4 * DC_IPW);
         char dname[48];
-        snprintf(dname, sizeof(dname), "deconv2_mfma_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
+        static const bool deep_off = getenv("DLV_DEEP_MASK") && atoi(getenv("DLV_DEEP_MASK")) == 0;  // (A/B: the round-4 kernels)
+        const bool deep = rows && !deep_off && L.w16_f16 && a.ss == nullptr && dlv_deconv2_deep_supports(L.cin, L.cout, din.D, din.H, din.W);
+        snprintf(dname, sizeof(dname), "deconv2_%s_%s_c%dx%d_d%d", deep ? "deep" : "mfma", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
         DlvProf pr(ctx, dname, 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,
                    2.0 * (double)din.vox() * B * (L.cin + 8.0 * L.cout));
+        if (deep) {  // Cin 128 / 256 at the deep levels: weights shared through LDS (conv_deep.hip)
+            DLV_TRY(dlv_deconv2_deep_launch(ctx, P::IS_F16, L.cin, L.cout, in, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.bias, out, B, din.D, din.H, din.W));
+            pr.end();
+            return DLV_OK;
+        }
 #define DLV_DECONV(KP_)                                                                                                  \
     do {                                                                                                                 \
         if (rows)                                                                                                        \
@@ -1685,6 +1692,7 @@ int pack_weights_16(dlv_ctx* ctx) {
         if (L.cin % 32 || L.cout % 32) return dlv_fail(ctx, DLV_EUNSUP, "deconv %d: %d->%d not multiples of 32", j, L.cin, L.cout);
         hipLaunchKernelGGL(pack_deconv_w_kernel<P>, dim3(64), dim3(256), 0, ctx->stream, L.w_f32, dst(ctx->deconv[j]), L.cin, L.cout);
         DLV_LAUNCH_CHECK(ctx, "pack_deconv_w_kernel");
+        if (L.w16_f16) DLV_TRY(dlv_pack_deconv_w16(ctx, P::IS_F16, L.w_f32, P::IS_F16 ? L.w16_f16 : L.w16_bf16, L.cin, L.cout));
     }
     return DLV_OK;
 }

@@ -90,3 +90,20 @@ def test_persistent_upconv_kernel_has_no_mfma_hazard_and_keeps_its_weights_in_ag
         assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, name
         assert r["agpr_count"] == 128 and r["vgpr_count"] <= 512, (name, r["vgpr_count"], r["agpr_count"])
         assert r["mfma"] == 32 * 32, (name, r["mfma"])
+
+
+def test_deep_level_kernels_fit_two_waves_per_simd_without_scratch():
+    """conv_deep.hip: 8-wave workgroups = two waves per SIMD, i.e. at most 256 registers per lane, and nothing may spill (a spill
+    in the K loop of an MFMA kernel costs more than the kernel gained); compiler-scheduled intrinsic MFMAs (no hand-placed asm
+    MFMA: the hazard recogniser sees them), 9 taps x NCB x 4 blocks of them per kz group."""
+    _need_tools()
+    hs = _tool()
+    rep = hs.library_report(LIB, name_filter=("conv3_deep_kernel", "deconv2_deep_kernel"))
+    conv = {k: v for k, v in rep.items() if "conv3_deep_kernel" in k}
+    dec = {k: v for k, v in rep.items() if "deconv2_deep_kernel" in k}
+    assert len(conv) == 8 and len(dec) == 4, sorted(rep)  # 2 formats x (tile 16 / 8 wide) x (64 / 32 channels); 2 formats x Cin 128 / 256
+    for name, r in rep.items():
+        assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, (name, "scratch / spills")
+        assert r["vgpr_count"] <= 256 and r["agpr_count"] == 0, (name, r["vgpr_count"], r["agpr_count"])
+    for name, r in conv.items():
+        assert r["mfma"] == (144 if "ELi4EEE" in name else 72), (name, r["mfma"])
