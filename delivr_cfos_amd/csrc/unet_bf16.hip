@@ -1350,7 +1350,8 @@ struct Net16 {
         if (!ctx->no_zmarch && ((zmarch_ok ? 1 : 2) & deep_mask) && dlv_conv3_deep_supports(L.cin, L.cout, c1, c2, d.D, d.H, d.W)) {
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_deep_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
-            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout));
+            // (algorithmic bytes: activations in and out + the weights once - at these levels they are 10-50 % of the activations)
+            DlvProf zp(ctx, zname, 2.0 * 27 * L.cin * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (L.cin + L.cout) + 2.0 * 27 * L.cin * L.cout);
             int np = 0;
             if ((size_t)B * dlv_cdiv(d.D, 4) * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 8) * L.cout * 2 > partials_floats)
                 return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (deep)");

@@ -21,7 +21,7 @@ import sys
 root, wl, precision = sys.argv[1], sys.argv[2], sys.argv[3]
 # label prefix -> the kernel(s) a bracketed launch of that label dispatches, in order (a|b: either template)
 # (the stem is two launches of one template under one bracket: statistics pass, then the pass that writes)
-FAMILY = [("conv3_zreg_", ["conv3_zreg_kernel"]), ("conv3_zmarch_", ["conv3_zmarch_kernel"]), ("conv3_mfma_", ["conv3_mfma_kernel"]),
+FAMILY = [("conv3_deep_", ["conv3_deep_kernel"]), ("deconv2_deep_", ["deconv2_deep_kernel"]), ("conv3_zreg_", ["conv3_zreg_kernel"]), ("conv3_zmarch_", ["conv3_zmarch_kernel"]), ("conv3_mfma_", ["conv3_mfma_kernel"]),
           ("norm_mish_", ["norm_mish_kernel|norm_mish_pool_rows_kernel"]), ("pool_act_", ["norm_mish_kernel|norm_mish_pool_rows_kernel"]),
           ("upconv2", ["upconv2m_kernel|upconv2_kernel"]), ("deconv2_mfma_", ["deconv2_rows_kernel|deconv2_regw_kernel|deconv2_wst_kernel"]),
           ("stem_mfma_", ["stem_mfma_kernel", "stem_mfma_kernel"]), ("final_conv_", ["final_conv_kernel"]), ("erode_x_", ["erode_x_kernel|erode_x_bits_kernel"]),
