@@ -399,6 +399,14 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
         u32x4 fb[2][6];
         auto load_frag = [&](int g, int i) __attribute__((always_inline)) {
             const int j = g / KS, ks = g % KS, kx = i / 2, b = i % 2;
+#ifdef ZR_ABL  // bit 7: every fragment read is issued, but into registers no MFMA reads (the MFMAs multiply stale ones): what is
+               // left is the reads' issue slots and LDS traffic without the dependency of an MFMA on a read
+            if (ZR_ABL & 128) {
+                u32x4 t = lds[lbase + rb + (ks * 4) * C::CS + j * ZR_HX + b * 16 + kx];
+                asm volatile("" ::"v"(t));
+                return;
+            }
+#endif
             fb[g & 1][i] = lds[lbase + rb + (ks * 4) * C::CS + j * ZR_HX + b * 16 + kx];
         };
 #pragma unroll

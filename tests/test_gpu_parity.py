@@ -93,6 +93,52 @@ def test_sw_pass_fp32_matches_oracle(eng_w, net, golden_dir, flip):
     assert (a <= -999).any()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_sharded_pass_fp32_matches_the_oracle(net, golden_dir, world):
+    """The DataParallel replacement against the ORACLE, not against the single-device HIP pass: dlv_comm_init_all /
+    dlv_bcast_weights / dlv_sw_infer_sharded with every rank on device 0 and its own Z-slab of volume and accumulator (fp32
+    network), every owned plane compared with the oracle's sliding-window pass (fp32 accumulate) - sums to 1e-3 absolute on up to
+    8 logits, count map bit-exact vs the REFERENCE golden (ref_blend.npz: p1_b1).  inference/inference.py:217-219."""
+    import torch
+    from oracle import delivr_oracle as orc
+    from delivr_cfos_amd.engine import HipComm
+
+    g = _g(golden_dir, "ref_blend.npz")
+    vol = g["volume"]
+    roi = (32, 32, 16)
+    acc_ref = np.zeros(vol.shape, dtype=np.float32)
+    cnt_ref = np.zeros(vol.shape, dtype=np.uint8)
+    info = orc.sliding_window_pass(vol, roi, lambda x: orc.unet_forward(net, x), acc_ref, cnt_ref, 0.5, None, sw_batch_size=1, fp16=False)
+    comm = HipComm([0] * world)
+    comm.engines[0].load_state_dict({"state_dict": {"module." + k: v for k, v in net.state_dict().items()}})
+    comm.bcast_weights(0)
+    p = comm.engines[0].make_sw_params(vol.shape, roi, 0.5, None, 0, "fp32")
+    plan = comm.make_plan(p, None)
+    v = comm.engines[0].to_device(vol)
+    slabs, vols, accs, cnts = [], [], [], []
+    for r in range(world):
+        lo, hi = plan.slab(r, vol.shape[0], 0, 0)
+        slabs.append((lo, hi - lo))
+        vols.append(v[lo:hi].clone())
+        accs.append(torch.zeros((hi - lo,) + vol.shape[1:], dtype=torch.float32, device="cuda"))
+        cnts.append(torch.zeros((hi - lo,) + vol.shape[1:], dtype=torch.uint8, device="cuda"))
+    stats = comm.sw_infer_sharded(p, plan, slabs, vols, accs, cnts)
+    torch.cuda.synchronize()
+    assert sum(s["n_windows"] for s in stats) == info["n_windows"] and sum(s["n_skipped"] for s in stats) == info["n_skipped"] > 0
+    covered = 0
+    for r in range(world):
+        olo, ohi = plan.z_owned[r]
+        if ohi <= olo:
+            continue
+        lo = slabs[r][0]
+        a = accs[r][olo - lo:ohi - lo].cpu().numpy()
+        assert np.abs(a - acc_ref[olo:ohi]).max() < 1e-3, r
+        np.testing.assert_array_equal(cnts[r][olo - lo:ohi - lo].cpu().numpy(), g["p1_b1_count"][olo:ohi])
+        covered += ohi - olo
+    assert covered == vol.shape[0]
+    comm.close()
+
+
 def test_window_enumeration_matches_reference(eng, golden_dir):
     g = _g(golden_dir, "ref_tiler.npz")
     for i in range(int(g["n_cases"])):
