@@ -273,21 +273,23 @@ def run_inference(
             dist.all_reduce(rep, op=dist.ReduceOp.MAX)
             if not rep[0].item():
                 break
-            plan = next_shifts(int(rep[1].item()), [float(v) for v in rep[2:].tolist()], eng.conv_shifts()) if attempt < 4 else None
-            if plan is None or precision != "fp16":
+            shifts = next_shifts(int(rep[1].item()), [float(v) for v in rep[2:].tolist()], eng.conv_shifts()) if attempt < 4 else None
+            if shifts is None or precision != "fp16":
                 if precision != "fp16":
                     raise RuntimeError("unreachable: bf16 range errors are raised")
                 if rank == 0:
                     print("WARNING: repeating the inference passes with bf16 operands on every rank")
                 precision = "bf16"
             else:
-                for p, k in sorted(plan.items()):
+                for p, k in sorted(shifts.items()):
                     if rank == 0:
                         print(f"WARNING: conv block {p}: storing its raw output scaled by 2^-{k} on every rank and repeating the passes in fp16")
                     eng.set_conv_shift(p, k)
             output_image.zero_()
             if count_map is not None:
                 count_map.zero_()
+        else:  # (not reachable: the bf16 attempt either succeeds or raises in run_passes)
+            raise RuntimeError("range guard: the passes did not come to an end in six attempts")
         exchange_seams(output_image, plan, rank, dist, z0=slo)
         if count_map is not None:
             exchange_seams(count_map, plan, rank, dist, z0=slo)

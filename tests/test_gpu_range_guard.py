@@ -180,3 +180,45 @@ def test_run_inference_recovers_in_fp16_within_the_north_star_tolerance(tmp_path
     rep = flip_report(mask, ref["mask"], ref["mean"][: vol.shape[0], : vol.shape[1], : vol.shape[2]])
     print(f"fp16 recovery (streamed={streamed}) vs the reference arithmetic: {rep}")
     assert mask.any() and rep["iou"] >= 0.999, rep
+
+
+def test_sharded_run_inference_recovers_in_fp16_on_every_rank(tmp_path):
+    """The range guard under torch.distributed (two ranks on cuda:0, gloo): the rank whose windows overflow reports it, every rank
+    learns the layer and the peaks through one all-reduce, applies the SAME block shift and repeats its passes in fp16; the
+    gathered mask equals the single-process recovery's."""
+    import socket
+    import subprocess
+    import sys
+
+    from delivr_cfos_amd.inference import run_inference
+    from delivr_cfos_amd.weights import random_state_dict
+
+    crop = (32, 32, 32)
+    from delivr_cfos_amd.synth import synth_volume_np
+
+    vol = synth_volume_np((72, 64, 64), seed=9, dense=True)
+    vol[:, :, :6] = 0
+    nifti = os.path.join(str(tmp_path), "masked_nifti.npy")
+    _write_padded_npy(nifti, vol, crop)
+    big = _scaled(random_state_dict(6), "down_1.convs.conv_0", 1.0e6)
+    settings = {"blob_detection": {"window_dimensions": {"window_dim_0": 32, "window_dim_1": 32, "window_dim_2": 32}},
+                "mi355x": {"precision": "fp16"}}
+    single = run_inference([nifti], str(tmp_path / "one"), (1, 1) + vol.shape, comment="b", tta=False, crop_size=crop,
+                           state_dict={"state_dict": big}, settings=settings)
+    m1 = np.load(os.path.join(single, "binary_segmentations", "binaries.npy"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "run_inference_ranks.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker, nifti, str(tmp_path / "two"), *[str(v) for v in vol.shape]],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "storing its raw output scaled by 2^-" in r.stdout and "on every rank" in r.stdout, r.stdout
+    assert "with bf16 operands" not in r.stdout, r.stdout
+    m2 = np.load(os.path.join(str(tmp_path / "two"), "b", "binary_segmentations", "binaries.npy"))
+    assert m1.any() and m2.shape == m1.shape
+    # (the seam sums associate differently in fp32: voxels whose mean logit is within rounding of 0 may flip)
+    assert int((m1 != m2).sum()) <= 4, int((m1 != m2).sum())
