@@ -576,3 +576,24 @@ def test_streaming_host_arithmetic():
     assert st.forward_workspace_bytes((128, 128, 128), "fp16") > 30 * 2**30  # 3 lanes x 2^25 patch voxels x 340 B
     assert st.forward_workspace_bytes((32, 32, 32), "fp16") < 4 * 2**30
     assert st.hbm_budget_bytes(None, {"mi355x": {"hbm_budget_gb": 1.5}}) == int(1.5 * 2**30)
+
+
+def test_range_guard_maps_the_named_layer_to_the_blocks_feeding_it():
+    """range_guard.producers: MONAI BasicUNet's wiring (inference/inference.py:190-197) - the block whose InstanceNorm sums were
+    not finite names its INPUT's producers; next_shifts turns the library's per-block |mean| + 8 sigma into a power of two."""
+    from delivr_cfos_amd.range_guard import MAX_SHIFT, next_shifts, producers
+
+    assert producers(1) == [0] and producers(2) == [1] and producers(9) == [8]
+    assert producers(10) == [7, 9] and producers(12) == [5, 11] and producers(14) == [3, 13] and producers(16) == [1, 15]
+    assert producers(11) == [10] and producers(17) == [16] and producers(18) == [17] and producers(0) == []
+    peaks = [0.0] * 18
+    shifts = [0] * 18
+    # a hint on one of two candidates: only that block moves, far enough to bring the peak to <= 1024
+    peaks[13] = 3.0e6
+    plan = next_shifts(14, peaks, shifts)
+    assert plan == {13: 12} and 3.0e6 / 2 ** 12 <= 1024 < 3.0e6 / 2 ** 11
+    # no hint: every candidate moves by 6 bits; block 16 itself when its folded up half overflowed before its statistics exist
+    assert next_shifts(14, [0.0] * 18, shifts) == {3: 6, 13: 6}
+    assert next_shifts(16, [0.0] * 18, shifts) == {16: 6}
+    assert next_shifts(18, [0.0] * 18, [0] * 17 + [MAX_SHIFT]) is None  # nothing left to try
+    assert next_shifts(0, [0.0] * 18, shifts) is None
