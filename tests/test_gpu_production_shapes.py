@@ -124,6 +124,34 @@ def test_default_window_96_96_64_vs_oracle(eng, net, prec):
     _check("96x96x64", prec, acc.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("roi,batch", [((80, 96, 112), 3), ((128, 64, 160), 2)])
+def test_uneven_windows_through_the_deep_level_kernels_vs_oracle(eng, net, prec, roi, batch):
+    """Windows whose deep levels do not fill the tiles of conv_deep.hip (4 x 8 x 16 / 8 x 8 x 8 voxels): (80,96,112) -> 20x24x28,
+    10x12x14 (the 8-wide tile, partial in y and x), 5x6x7 (too small: the generic kernel); (128,64,160) -> 32x16x40, 16x8x20,
+    8x4x10 - several windows per launch (the persistent walk crosses item and window boundaries), each against the oracle."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    shape = (roi[0], roi[1], roi[2] * batch)
+    vol = synth_volume_np(shape, seed=7, dense=True)
+    acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    eng.prof_reset()
+    eng.prof_enable(True)
+    st = eng.sw_infer(eng.make_sw_params(shape, roi, 0.0, None, 0, prec), eng.to_device(vol), acc)
+    eng.sync()
+    eng.prof_enable(False)
+    ran = [k for k, e in eng.prof_report().items() if e["launches"]]
+    assert st["n_windows"] == batch and st["n_skipped"] == 0
+    assert any(k.startswith("conv3_deep_") for k in ran) and any(k.startswith("deconv2_deep_") for k in ran), ran
+    out = acc.cpu().numpy()
+    for b in range(batch):
+        sl = slice(b * roi[2], (b + 1) * roi[2])
+        ref = orc.unet_forward(net, vol[:, :, sl].astype(np.float32)[None, None])[0, 0]
+        _check(f"{roi} window {b}", prec, out[:, :, sl], ref)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 def test_window_128cube_forward_vs_oracle(eng, crop, prec):
     """dlv_unet_forward_dev on the centre window of the crop (fp32 patch input) vs the oracle's logits of that window."""
