@@ -87,7 +87,7 @@ def run_inference_streamed(engine, dataset_host, pad, stack_zyx, crop_size, over
                            need_count: bool, gaussian: bool, plan, out_mask, out_prob=None, verbose: bool = True):
     """dataset_host: (Zp, Yp, Xp) uint16 host array (the memmap of masked_nifti.npy); out_mask: (Z, Y, X) uint8 host array
     (the memmap of binaries.npy), out_prob: fp32 (Z, Y, X) or None.  Runs every slab of `plan`; raises DelivrHipError
-    (DLV_ERANGE included: the caller repeats the run in bf16)."""
+    (DLV_ERANGE included: the caller rescales the offending conv block and repeats the run, range_guard.py)."""
     from .hostlogic import arrayterator_zblock, pass_schedule
     from .parallel import finalize_owned
 
