@@ -184,6 +184,7 @@ SIGNATURES = {
                                        C.c_int]),
     "dlv_unet_set_conv_shift": (C.c_int, [_P, C.c_int, C.c_int]),
     "dlv_unet_get_conv_shift": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "dlv_unet_note_conv_shifts": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "dlv_range_report": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),

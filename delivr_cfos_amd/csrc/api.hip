@@ -423,6 +423,15 @@ int dlv_unet_get_conv_shift(dlv_ctx* ctx, int layer, int* shift) {
     *shift = ctx->conv[layer].shift;
     return DLV_OK;
 }
+int dlv_unet_note_conv_shifts(dlv_ctx* ctx, const int* shifts) {
+    if (!ctx || !shifts) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_unet_note_conv_shifts before the blob was allocated");
+    for (int i = 0; i < DLV_N_CONV; ++i) {
+        if (shifts[i] < 0 || shifts[i] > 40) return dlv_fail(ctx, DLV_EINVAL, "conv shift %d of block %d", shifts[i], i);
+        ctx->conv[i].shift = shifts[i];
+    }
+    return DLV_OK;
+}
 int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks) {
     if (!ctx) return DLV_EINVAL;
     if (layer) *layer = ctx->range_last;

@@ -447,6 +447,15 @@ int dlv_bcast_weights(dlv_comm* c, int root) {
         DLV_CHIP(c, hipSetDevice(c->devs[r]));
         DLV_CHIP(c, hipStreamSynchronize(c->ctx[r]->main_stream));
     }
+    // the packs that travelled were made with the root's per-block shifts (dlv_unet_set_conv_shift): the receivers normalise with
+    // the matching eps
+    int shifts[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) DLV_TRY(dlv_unet_get_conv_shift(src, i, &shifts[i]));
+    for (int r = 0; r < c->n; ++r)
+        if (r != root) {
+            const int rc = dlv_unet_note_conv_shifts(c->ctx[r], shifts);
+            if (rc != DLV_OK) return comm_fail(c, rc, "rank %d: %s", r, dlv_last_error(c->ctx[r]));
+        }
     return DLV_OK;
     DLV_ABI_GUARD_END(c)
 }

@@ -649,6 +649,11 @@ class HipEngine:
             out.append(v.value)
         return out
 
+    def note_conv_shifts(self, shifts) -> None:
+        """the blob this engine received by broadcast was packed with these per-block shifts (no repack)"""
+        arr = (C.c_int * _lib.N_CONV)(*[int(v) for v in shifts])
+        self._check(self.lib.dlv_unet_note_conv_shifts(self.ctx, arr))
+
     def range_report(self):
         """(layer the last DLV_ERANGE named or -1, [|mean| + 8 sigma of every conv block's raw output where it exceeded 4096])"""
         layer = C.c_int()

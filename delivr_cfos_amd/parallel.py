@@ -255,16 +255,18 @@ def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]]
     (fp32 + MFMA-packed bf16 parameters, ~35 MB) with ONE broadcast."""
     import torch
 
-    meta = torch.zeros(6, dtype=torch.int64, device=engine.device)
+    meta = torch.zeros(6 + 18, dtype=torch.int64, device=engine.device)  # features + the per-block shifts the packs were made with
     if rank == src:
-        meta[:] = torch.tensor(engine.features, dtype=torch.int64)
+        meta[:] = torch.tensor(list(engine.features) + list(engine.conv_shifts()), dtype=torch.int64)
     dist.broadcast(meta, src, group=group)
     if rank != src:
-        engine.alloc_weight_blob([int(v) for v in meta.tolist()])
+        engine.alloc_weight_blob([int(v) for v in meta[:6].tolist()])
     blob = engine.weight_blob()
     engine.sync()
     dist.broadcast(blob, src, group=group)
     torch.cuda.synchronize(engine.device)
+    if rank != src:
+        engine.note_conv_shifts([int(v) for v in meta[6:].tolist()])
 
 
 def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0, group=None):

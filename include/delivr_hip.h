@@ -363,6 +363,10 @@ typedef struct dlv_prof_entry {
 int dlv_unet_set_conv_shift(dlv_ctx* ctx, int layer, int shift);
 int dlv_unet_get_conv_shift(dlv_ctx* ctx, int layer, int* shift);
 int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks /* [DLV_N_CONV] or NULL */);
+/* The blob this context RECEIVED (dlv_unet_alloc_blob + a broadcast into dlv_unet_blob_dev) holds 16-bit packs made with these
+ * shifts: record them - the InstanceNorm eps of a shifted block scales with 4^-shift - without packing again.  dlv_bcast_weights
+ * does it for the ranks of a dlv_comm; parallel.broadcast_weights for the ranks of a torch.distributed job. */
+int dlv_unet_note_conv_shifts(dlv_ctx* ctx, const int* shifts /* [DLV_N_CONV] */);
 /* 1 = run batches back to back on the ctx stream; 2 .. 6 (default 3) = rotate consecutive batches over that many HIP
  * streams so that HBM-bound and MFMA-bound kernels of neighbouring batches overlap (results are identical). */
 int dlv_set_lanes(dlv_ctx* ctx, int lanes);

@@ -222,3 +222,30 @@ def test_sharded_run_inference_recovers_in_fp16_on_every_rank(tmp_path):
     assert m1.any() and m2.shape == m1.shape
     # (the seam sums associate differently in fp32: voxels whose mean logit is within rounding of 0 may flip)
     assert int((m1 != m2).sum()) <= 4, int((m1 != m2).sum())
+
+
+def test_block_shifts_travel_with_the_broadcast_blob():
+    """dlv_bcast_weights sends packs made with rank 0's block shifts: the receiving context must normalise with the matching
+    eps (4^-shift), i.e. know the shifts - same pass, same bits on both ranks (C-ABI communicator, both ranks on device 0)."""
+    import torch
+    from delivr_cfos_amd.engine import HipComm
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    shape, roi = (64, 64, 64), (64, 64, 64)
+    vol = synth_volume_np(shape, seed=15, dense=True)
+    comm = HipComm([0, 0])
+    e0, e1 = comm.engines
+    e0.load_state_dict({"state_dict": _scaled(random_state_dict(4), "down_2.convs.conv_1", 1.0e6)})
+    e0.set_conv_shift(5, 13)
+    e0.set_conv_shift(2, 3)  # (an ordinary block too: with the default eps its normalisation would be visibly off)
+    comm.bcast_weights(0)
+    assert e1.conv_shifts() == e0.conv_shifts() and e1.conv_shifts()[5] == 13 and e1.conv_shifts()[2] == 3
+    outs = []
+    for e in (e0, e1):
+        acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        e.sw_infer(e.make_sw_params(shape, roi, 0.5, None, 0, "fp16"), e.to_device(vol), acc)
+        e.sync()
+        outs.append(acc.cpu().numpy())
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    comm.close()
