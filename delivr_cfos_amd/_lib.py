@@ -186,6 +186,9 @@ SIGNATURES = {
     "dlv_unet_get_conv_shift": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "dlv_unet_note_conv_shifts": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "dlv_range_report": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "dlv_range_next_shifts": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dlv_range_recover": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "dlv_comm_range_recover": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "dlv_set_lanes": (C.c_int, [_P, C.c_int]),
     "dlv_prof_enable": (C.c_int, [_P, C.c_int]),
     "dlv_prof_reset": (C.c_int, [_P]),

@@ -1,6 +1,7 @@
 // api.hip - context, memory helpers, weight loading and the in-library kernel timer of
 // libdelivr_hip.so (C ABI declared in include/delivr_hip.h).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -437,6 +438,61 @@ int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks) {
     if (layer) *layer = ctx->range_last;
     if (peaks)
         for (int i = 0; i < DLV_N_CONV; ++i) peaks[i] = ctx->range_peak[i];
+    return DLV_OK;
+}
+
+// The range guard's policy as host logic (what run_inference does about DLV_ERANGE: delivr_cfos_amd/range_guard.py holds the
+// same rules; a CPU test compares the two).  Conv block `layer` (18 = the logits) saw a non-finite input: the blocks whose
+// stored raw output reaches it - MONAI BasicUNet's wiring, inference/inference.py:190-197 - get a larger shift.
+static int range_producers(int layer, int* out) {
+    if (layer == 18) { out[0] = 17; return 1; }
+    if (layer == 10 || layer == 12 || layer == 14 || layer == 16) {  // upcat_l.conv_0: the skip tensor of its level + the block below
+        const int level = 3 - (layer - 10) / 2;
+        out[0] = 2 * level + 1;
+        out[1] = layer - 1;
+        return 2;
+    }
+    if (layer >= 1 && layer < DLV_N_CONV) { out[0] = layer - 1; return 1; }
+    return 0;
+}
+int dlv_range_next_shifts(int layer, const float* peaks, const int* shifts, int* out) {
+    if (!peaks || !shifts || !out) return -1;
+    for (int i = 0; i < DLV_N_CONV; ++i) out[i] = shifts[i];
+    int cand[2];
+    int nc = range_producers(layer, cand);
+    bool hinted = false;
+    for (int i = 0; i < nc; ++i) hinted |= peaks[cand[i]] > 4096.0f;
+    if (layer == 16 && !hinted) {  // the folded up half P of upcat_1.conv_0 is stored before the block's statistics exist
+        cand[0] = 16;
+        nc = 1;
+    }
+    int changed = 0;
+    for (int i = 0; i < nc; ++i) {
+        const int p = cand[i];
+        const bool hint = hinted && peaks[p] > 4096.0f;
+        if (hinted && !hint) continue;
+        // |mean| + 8 sigma of the stored tensor to <= 1024; without a hint 6 bits at a time
+        const int step = hint ? std::max(1, (int)std::ceil(std::log2((double)peaks[p] / 1024.0))) : 6;
+        const int k = std::min(40, shifts[p] + step);
+        if (k != shifts[p]) {
+            out[p] = k;
+            ++changed;
+        }
+    }
+    return changed;
+}
+int dlv_range_recover(dlv_ctx* ctx, int* n_changed) {
+    if (!ctx) return DLV_EINVAL;
+    if (n_changed) *n_changed = 0;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_range_recover before dlv_unet_load");
+    if (ctx->range_last < 0) return dlv_fail(ctx, DLV_ESTATE, "dlv_range_recover: the last 16-bit pass did not end with DLV_ERANGE");
+    int cur[DLV_N_CONV], nxt[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) cur[i] = ctx->conv[i].shift;
+    const int changed = dlv_range_next_shifts(ctx->range_last, ctx->range_peak, cur, nxt);
+    if (changed <= 0) return dlv_fail(ctx, DLV_ERANGE, "range guard: no block shift left to try for conv block %d (repeat the passes in bf16)", ctx->range_last);
+    for (int i = 0; i < DLV_N_CONV; ++i) ctx->conv[i].shift = nxt[i];
+    DLV_TRY(dlv_unet_set_conv_shift(ctx, 0, nxt[0]));  // (re-packs every block with the shifts noted above)
+    if (n_changed) *n_changed = changed;
     return DLV_OK;
 }
 

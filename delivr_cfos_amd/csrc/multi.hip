@@ -460,6 +460,37 @@ int dlv_bcast_weights(dlv_comm* c, int root) {
     DLV_ABI_GUARD_END(c)
 }
 
+// dlv_sw_infer_sharded ended with DLV_ERANGE on some rank: every rank gets the same next block shifts (the largest block index
+// named and the largest peaks seen by any rank - what the ranks of a torch.distributed job exchange with an all_reduce MAX,
+// inference/inference.py of this package), so the ranks' masks keep composing.
+int dlv_comm_range_recover(dlv_comm* c, int* n_changed) {
+    if (!c) return DLV_EINVAL;
+    DLV_ABI_GUARD_BEGIN
+    if (n_changed) *n_changed = 0;
+    int layer = -1;
+    float peaks[DLV_N_CONV] = {};
+    for (int r = 0; r < c->n; ++r) {
+        int l = -1;
+        float pk[DLV_N_CONV];
+        DLV_TRY(dlv_range_report(c->ctx[r], &l, pk));
+        layer = std::max(layer, l);
+        for (int i = 0; i < DLV_N_CONV; ++i) peaks[i] = std::max(peaks[i], pk[i]);
+    }
+    if (layer < 0) return comm_fail(c, DLV_ESTATE, "dlv_comm_range_recover: no rank's last 16-bit pass ended with DLV_ERANGE");
+    int cur[DLV_N_CONV], nxt[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) DLV_TRY(dlv_unet_get_conv_shift(c->ctx[0], i, &cur[i]));
+    const int changed = dlv_range_next_shifts(layer, peaks, cur, nxt);
+    if (changed <= 0) return comm_fail(c, DLV_ERANGE, "range guard: no block shift left to try for conv block %d (repeat the passes in bf16)", layer);
+    for (int r = 0; r < c->n; ++r) {
+        int rc = dlv_unet_note_conv_shifts(c->ctx[r], nxt);
+        if (rc == DLV_OK) rc = dlv_unet_set_conv_shift(c->ctx[r], 0, nxt[0]);  // (re-packs every block of this rank's blob)
+        if (rc != DLV_OK) return comm_fail(c, rc, "rank %d: %s", r, dlv_last_error(c->ctx[r]));
+    }
+    if (n_changed) *n_changed = changed;
+    return DLV_OK;
+    DLV_ABI_GUARD_END(c)
+}
+
 int dlv_sw_infer_sharded(dlv_comm* c, const dlv_sw_params* p, const dlv_shard_plan* plan, const int* slab_z0, const int* slab_nz,
                          const uint16_t* const* vol_slab_dev, float* const* acc_slab_dev, uint8_t* const* cnt_slab_dev,
                          dlv_sw_stats* stats) {

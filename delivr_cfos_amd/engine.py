@@ -88,6 +88,13 @@ class HipComm:
         for e in self.engines:
             e.features = self.engines[root].features
 
+    def range_recover(self) -> int:
+        """dlv_comm_range_recover after sw_infer_sharded raised DLV_ERANGE: the same next block shifts on every rank
+        -> number of blocks changed (raises DLV_ERANGE when nothing is left)"""
+        n = C.c_int()
+        self._check(self.lib.dlv_comm_range_recover(self.handle, C.byref(n)))
+        return n.value
+
     def make_plan(self, params, weights=None):
         from .parallel import plan_from_params
 
@@ -660,6 +667,17 @@ class HipEngine:
         peaks = (C.c_float * _lib.N_CONV)()
         self._check(self.lib.dlv_range_report(self.ctx, C.byref(layer), peaks))
         return layer.value, [float(v) for v in peaks]
+
+    def range_recover(self) -> int:
+        """dlv_range_recover: the library's own next step after DLV_ERANGE (what range_guard.next_shifts decides, applied);
+        -> number of conv blocks whose shift changed; raises DelivrHipError(DLV_ERANGE) when nothing is left to try"""
+        n = C.c_int()
+        self._enter()
+        try:
+            self._check(self.lib.dlv_range_recover(self.ctx, C.byref(n)))
+        finally:
+            self._leave()
+        return n.value
 
     def set_lanes(self, lanes: int):
         self._check(self.lib.dlv_set_lanes(self.ctx, int(lanes)))

@@ -7,6 +7,9 @@
  *   ./c_host --gpus N [--same-device] [--comm]   # the same pass sharded over N devices (dlv_comm_init_all, ONE weight broadcast,
  *                       # per-rank Z-slabs, one seam exchange); --same-device puts every rank on device 0 (a one-GPU box)
  *   ./c_host --plan N   # prints the shard plan only (host logic, no GPU needed)
+ *   ./c_host --hot-block B [...]  # conv block B's weights times 2^16: its raw output leaves fp16's range, the pass returns
+ *                       # DLV_ERANGE and the host repeats it after dlv_range_recover / dlv_comm_range_recover (the block's output
+ *                       # stored 2^-k times smaller - InstanceNorm removes the factor), bf16 only as the last resort
  *
  * Weights: a deterministic LCG stands in for a checkpoint (same topology as MONAI BasicUNet(3,1,1,
  * (32,32,64,128,256,32), act=mish, norm=instance-affine); a real host passes the arrays of its state_dict). */
@@ -64,6 +67,7 @@ static int run_sharded(int n, int same_device, const dlv_unet_weights* w, const 
     float* aslab[DLV_MAX_RANKS];
     const size_t plane = (size_t)Y * X;
     long long nw = 0, nsk = 0;
+    int attempt, recoveries = 0;
     for (r = 0; r < n; ++r) devs[r] = same_device ? 0 : r;
     if (dlv_comm_init_all(n, devs, &comm) != DLV_OK) {
         fprintf(stderr, "dlv_comm_init_all(%d) failed: needs %d MI355X (or --same-device) and librccl.so: %s\n", n, n,
@@ -99,7 +103,24 @@ static int run_sharded(int n, int same_device, const dlv_unet_weights* w, const 
         printf("rank %d: windows [%lld,%lld), holds planes [%d,%d), owns [%d,%d)\n", r, (long long)plan.win_begin[r],
                (long long)plan.win_end[r], z0[r], z0[r] + nz[r], plan.z_own_lo[r], plan.z_own_hi[r]);
     }
-    CCHECK(dlv_sw_infer_sharded(comm, &p, &plan, z0, nz, vslab, aslab, NULL, st));
+    for (attempt = 0;; ++attempt) { /* the fp16 range guard: DLV_ERANGE -> next block shifts on every rank -> repeat */
+        int changed = 0;
+        const int rc = dlv_sw_infer_sharded(comm, &p, &plan, z0, nz, vslab, aslab, NULL, st);
+        if (rc != DLV_ERANGE || p.precision != DLV_PREC_F16) {
+            CCHECK(rc);
+            break;
+        }
+        fprintf(stderr, "range guard: %s\n", dlv_comm_last_error(comm));
+        if (attempt == 4 || dlv_comm_range_recover(comm, &changed) != DLV_OK) p.precision = DLV_PREC_BF16;
+        else ++recoveries;
+        for (r = 0; r < n; ++r)
+            if (nz[r] > 0) {
+                ctx = dlv_comm_ctx(comm, r);
+                CHECK(dlv_memset_dev(ctx, aslab[r], 0, (size_t)nz[r] * plane * 4));
+                CHECK(dlv_sync(ctx));
+            }
+    }
+    printf("range recoveries %d, precision %s\n", recoveries, p.precision == DLV_PREC_F16 ? "fp16" : "bf16");
     for (r = 0; r < n; ++r) {
         const int olo = plan.z_own_lo[r], ohi = plan.z_own_hi[r] < Z ? plan.z_own_hi[r] : Z;
         void* m = NULL;
@@ -139,12 +160,13 @@ int main(int argc, char** argv) {
     dlv_sw_stats st;
     uint64_t ncomp = 0;
     size_t fg = 0;
-    int gpus = 1, same_device = 0, plan_only = 0, use_comm = 0;
+    int gpus = 1, same_device = 0, plan_only = 0, use_comm = 0, hot_block = -1, attempt, recoveries = 0;
 
     for (i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--plan") && i + 1 < argc) { gpus = atoi(argv[++i]); plan_only = 1; }
         else if (!strcmp(argv[i], "--same-device")) same_device = 1;
+        else if (!strcmp(argv[i], "--hot-block") && i + 1 < argc) hot_block = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--comm")) use_comm = 1; /* the communicator path also for ONE rank (with DLV_FORCE_RCCL=1: real RCCL) */
     }
     if (gpus < 1 || gpus > DLV_MAX_RANKS) return 3;
@@ -167,10 +189,17 @@ int main(int argc, char** argv) {
     for (k = 0; k < 6; ++k) w.features[k] = f[k];
     for (i = 0; i < DLV_N_CONV; ++i) {
         const size_t nw = (size_t)cout[i] * cin[i] * 27;
-        w.conv_w[i] = filled(nw, 1.0f / (float)(cin[i] * 27 > 27 ? 40 : 6), 0.f);
-        w.conv_b[i] = filled((size_t)cout[i], 0.05f, 0.f);
+        float* cw = filled(nw, 1.0f / (float)(cin[i] * 27 > 27 ? 40 : 6), 0.f);
+        float* cb = filled((size_t)cout[i], 0.05f, 0.f);
+        w.conv_w[i] = cw;
+        w.conv_b[i] = cb;
         w.norm_g[i] = filled((size_t)cout[i], 0.2f, 1.0f);
         w.norm_b[i] = filled((size_t)cout[i], 0.2f, 0.f);
+        if (i == hot_block) { /* the same block times 2^16 (exact): same network after InstanceNorm, raw output beyond 65504 */
+            size_t j;
+            for (j = 0; j < nw; ++j) cw[j] *= 65536.0f;
+            for (j = 0; j < (size_t)cout[i]; ++j) cb[j] *= 65536.0f;
+        }
     }
     for (i = 0; i < DLV_N_DECONV; ++i) {
         w.deconv_w[i] = filled((size_t)dcin[i] * dcout[i] * 8, 0.05f, 0.f);
@@ -196,7 +225,19 @@ int main(int argc, char** argv) {
     CHECK(dlv_memset_dev(ctx, acc_dev, 0, nvox * 4));
 
     set_params(&p, Z, Y, X, roi);
-    CHECK(dlv_sw_infer_dev(ctx, &p, (const uint16_t*)vol_dev, (float*)acc_dev, NULL, &st));
+    for (attempt = 0;; ++attempt) { /* the fp16 range guard: DLV_ERANGE -> next block shifts -> repeat */
+        int changed = 0;
+        const int rc = dlv_sw_infer_dev(ctx, &p, (const uint16_t*)vol_dev, (float*)acc_dev, NULL, &st);
+        if (rc != DLV_ERANGE || p.precision != DLV_PREC_F16) {
+            CHECK(rc);
+            break;
+        }
+        fprintf(stderr, "range guard: %s\n", dlv_last_error(ctx));
+        if (attempt == 4 || dlv_range_recover(ctx, &changed) != DLV_OK) p.precision = DLV_PREC_BF16;
+        else ++recoveries;
+        CHECK(dlv_memset_dev(ctx, acc_dev, 0, nvox * 4));
+    }
+    printf("range recoveries %d, precision %s\n", recoveries, p.precision == DLV_PREC_F16 ? "fp16" : "bf16");
     CHECK(dlv_finalize_dev(ctx, (const float*)acc_dev, NULL, (const uint16_t*)vol_dev, Y, X, Z, Y, X, 0.5f, 3, 0,
                            (uint8_t*)mask_dev, NULL));
     CHECK(dlv_ccl26_dev(ctx, (const uint8_t*)mask_dev, Z, Y, X, (uint32_t*)lab_dev, &ncomp));

@@ -201,6 +201,8 @@ dlv_ctx* dlv_comm_ctx(dlv_comm* c, int rank); /* owned by the communicator */
 const char* dlv_comm_last_error(dlv_comm* c);
 /* dlv_unet_load was called on rank `root`: every other rank allocates the blob and receives it with ONE ncclBroadcast */
 int dlv_bcast_weights(dlv_comm* c, int root);
+/* dlv_range_recover for every rank of the communicator (see the range guard below): one decision, the same shifts everywhere. */
+int dlv_comm_range_recover(dlv_comm* c, int* n_changed /* or NULL */);
 /* One sliding-window pass sharded over the communicator.  Rank r's buffers hold planes [slab_z0[r], slab_z0[r]+slab_nz[r])
  * of the padded volume (vol: uint16, acc: fp32 in/out, cnt: uint8 in/out or cnt_slab_dev == NULL), on device devs[r]; they
  * must cover the rank's z_comp and z_own ranges.  p->win_begin/win_end/z0/nz are ignored (taken from the plan).  After the
@@ -363,6 +365,16 @@ typedef struct dlv_prof_entry {
 int dlv_unet_set_conv_shift(dlv_ctx* ctx, int layer, int shift);
 int dlv_unet_get_conv_shift(dlv_ctx* ctx, int layer, int* shift);
 int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks /* [DLV_N_CONV] or NULL */);
+/* The policy between the two, for hosts that do not go through run_inference (same rules as delivr_cfos_amd/range_guard.py; a CPU
+ * test compares them).  dlv_range_next_shifts is pure host logic: given the layer and peaks of dlv_range_report and the current
+ * shifts it writes the next shifts to out[DLV_N_CONV] and returns how many blocks changed (0: nothing left to try; -1: null
+ * argument) - the blocks feeding `layer` (MONAI BasicUNet's wiring, inference/inference.py:190-197) move so that |mean| + 8 sigma
+ * of their stored output falls to <= 1024, or by 6 bits where no block reported a peak.  dlv_range_recover applies it to one
+ * context after a DLV_ERANGE: DLV_OK = shifts changed, repeat the passes (zero the accumulators first); DLV_ERANGE = nothing left
+ * (the caller's last resort is DLV_PREC_BF16); run_inference gives up after four such steps.  dlv_comm_range_recover does the
+ * same for every rank of a dlv_comm with the largest layer / peaks any rank saw, so all ranks keep the same shifts. */
+int dlv_range_next_shifts(int layer, const float* peaks, const int* shifts, int* out /* [DLV_N_CONV] each */);
+int dlv_range_recover(dlv_ctx* ctx, int* n_changed /* or NULL */);
 /* The blob this context RECEIVED (dlv_unet_alloc_blob + a broadcast into dlv_unet_blob_dev) holds 16-bit packs made with these
  * shifts: record them - the InstanceNorm eps of a shifted block scales with 4^-shift - without packing again.  dlv_bcast_weights
  * does it for the ranks of a dlv_comm; parallel.broadcast_weights for the ranks of a torch.distributed job. */

@@ -817,3 +817,35 @@ def test_plain_c_host_runs_the_pass_single_and_sharded(tmp_path):
     r = subprocess.run([exe, "--gpus", "1", "--comm"], capture_output=True, text=True, timeout=600, env=env)
     if r.returncode != 0:  # (a loader that finds the soname on its default path still succeeds)
         assert "tried: /nonexistent/librccl.so" in r.stderr, r.stderr
+
+
+def test_plain_c_host_recovers_from_the_fp16_range_guard(tmp_path):
+    """examples/c_host.c --hot-block B: conv block B's weights times 2^16 (the same network after InstanceNorm, a raw output beyond
+    65504).  The pass returns DLV_ERANGE; the host - no Python, no range_guard.py - calls dlv_range_recover (one device) /
+    dlv_comm_range_recover (sharded: one decision for every rank) and repeats IN FP16: same mask as the unscaled network up to
+    voxels within rounding of the decision."""
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "delivr_cfos_amd", "lib")
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_host.c"), "-o", exe, "-L" + lib_dir, "-ldelivr_hip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-lm"])
+    base = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert base.returncode == 0 and "range recoveries 0, precision fp16" in base.stdout, base.stdout + base.stderr
+    fg0 = int(re.search(r"mask voxels (\d+)", base.stdout).group(1))
+    for args in (["--hot-block", "3"], ["--hot-block", "9"], ["--gpus", "2", "--same-device", "--hot-block", "3"],
+                 ["--gpus", "3", "--same-device", "--hot-block", "12"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"range recoveries (\d+), precision (\w+)", r.stdout)
+        assert m and int(m.group(1)) >= 1 and m.group(2) == "fp16", r.stdout + r.stderr
+        assert "range guard:" in r.stderr and "DLV_ERANGE" not in r.stdout
+        fg = int(re.search(r"mask voxels (\d+)", r.stdout).group(1))
+        print(args, "recoveries", m.group(1), "mask voxels", fg, "unscaled", fg0)
+        assert abs(fg - fg0) <= max(4, fg0 // 500), (args, fg, fg0)

@@ -597,3 +597,36 @@ def test_range_guard_maps_the_named_layer_to_the_blocks_feeding_it():
     assert next_shifts(16, [0.0] * 18, shifts) == {16: 6}
     assert next_shifts(18, [0.0] * 18, [0] * 17 + [MAX_SHIFT]) is None  # nothing left to try
     assert next_shifts(0, [0.0] * 18, shifts) is None
+
+
+def test_c_abi_range_policy_equals_the_python_one():
+    """dlv_range_next_shifts (api.hip; what dlv_range_recover / dlv_comm_range_recover apply for hosts without run_inference) against
+    range_guard.next_shifts on every layer x a set of peak / shift patterns (pure host logic: no GPU)."""
+    import ctypes as C
+
+    from delivr_cfos_amd import _lib
+    from delivr_cfos_amd.range_guard import next_shifts
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n = _lib.N_CONV
+    cases = 0
+    for layer in range(-1, 20):
+        for trial in range(40):
+            peaks = np.where(rng.random(n) < 0.3, 2.0 ** rng.uniform(12.0, 40.0, n), 0.0).astype(np.float32)
+            if trial % 4 == 0:
+                peaks[:] = 0
+            if trial % 7 == 0:
+                peaks = np.where(peaks > 0, np.float32(4097.0), peaks)  # just above the reporting threshold: one bit... (ceil(log2(4.0009)) = 3)
+            shifts = rng.integers(0, 41, n).astype(np.int32) if trial % 3 else np.zeros(n, np.int32)
+            out = (C.c_int * n)()
+            changed = lib.dlv_range_next_shifts(layer, peaks.ctypes.data_as(C.POINTER(C.c_float)), shifts.ctypes.data_as(C.POINTER(C.c_int)), out)
+            want = next_shifts(layer, [float(v) for v in peaks], [int(v) for v in shifts]) if 0 <= layer <= 18 else None
+            exp = [int(v) for v in shifts]
+            for p, k in (want or {}).items():
+                exp[p] = k
+            assert list(out) == exp, (layer, peaks, shifts, list(out), want)
+            assert changed == len(want or {})
+            cases += 1
+    assert cases > 500
+    assert lib.dlv_range_next_shifts(3, None, None, None) == -1
