@@ -466,10 +466,13 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const u32x4 bf = fb[g & 1][kx * 2 + b];
+                    for (int kz = 0; kz < 3; ++kz) {
+                        // the two column blocks innermost: consecutive MFMAs share the WEIGHT fragment (A) and alternate between two
+                        // input fragments; with kz innermost (one input fragment for three MFMAs, a new weight fragment for each) the
+                        // step is 0.9-1.2 % slower, interleaved over 7 rounds (profiles/README.md r05z_mfma_order_ab*)
 #pragma unroll
-                        for (int kz = 0; kz < 3; ++kz) {
+                        for (int b = 0; b < 2; ++b) {
+                            const u32x4 bf = fb[g & 1][kx * 2 + b];
                             const u32x4 w = wf[((kz * 3 + ky) * 3 + kx) * KS + ks];
                             const int set = kz == 0 ? SC : (kz == 1 ? SB : SA);
                             const bool first = (kz == 0 && ky == 0 && ks == 0 && kx == 0);
@@ -481,7 +484,7 @@ conv3_zreg_kernel(const uint4* __restrict__ in1, int c1_8, const float2* __restr
                                 else zr_mfma<P, false, false, !INT>(accv[set][r >= RA ? r - RA : 0][b], w, bf);
                             }
                             // the side ops that belong behind MFMA m of this group
-                            const int m = ((vr * 3 + kx) * 2 + b) * 3 + kz;
+                            const int m = ((vr * 3 + kx) * 3 + kz) * 2 + b;
                             const int lo = m * n_side / n_mfma, hi = (m + 1) * n_side / n_mfma;
 #pragma unroll
                             for (int t = 0; t < 3; ++t)  // constant trip count (at most 30 side ops per >= 18 MFMAs)
