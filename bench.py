@@ -35,10 +35,16 @@ if ROOT not in sys.path:
 
 METRIC = "voxels/sec sliding-window 3D U-Net inference, 2048x2048x1024 vol @1/2/4/8 GPU"
 WORKLOADS = {
-    # name: (Z, Y, X), roi, seed
-    "c3": ((1024, 2048, 2048), (128, 128, 128), 2),  # BASELINE configs[2]: 2048x2048x1024 synthetic brain
-    "c2": ((512, 512, 512), (128, 128, 128), 1),     # BASELINE configs[1]: 512^3 volume
-    "tiny": ((128, 256, 256), (64, 64, 64), 5),      # plumbing check
+    # name: (stack (Z, Y, X), window (roi), seed, TTA).  The volume in HBM is the stack zero-padded to multiples of the window
+    # (what step 1 writes into masked_nifti.npy, downsample/downsample_and_mask.py:390-417); `value` counts the STACK's voxels.
+    "c3": ((1024, 2048, 2048), (128, 128, 128), 2, False),  # BASELINE configs[2]: 2048x2048x1024 synthetic brain
+    "c2": ((512, 512, 512), (128, 128, 128), 1, False),     # BASELINE configs[1]: 512^3 volume
+    "tiny": ((128, 256, 256), (64, 64, 64), 5, False),      # plumbing check
+    # what the reference SHIPS (config.json:24-28,63): windows 96 x 96 x 64 and test-time augmentation - the 13 passes of
+    # inference/inference.py:261-279 = 3 distinct passes weighted 5:4:4; one step = all of them
+    "default": ((1024, 2048, 2048), (96, 96, 64), 2, True),
+    # run_inference's own defaults (inference/inference.py:113-129): crop_size (64, 64, 32), tta False
+    "legacy": ((1024, 2048, 2048), (64, 64, 32), 2, False),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -244,6 +250,85 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
     }
 
 
+def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels):
+    """File -> file wall-clock of the two steps the reference's caller sees (__main__.py:133-140,166): `run_inference`
+    (masked_nifti.npy -> binaries.npy) and `count_blobs` (binaries.npy -> <brain>-<N>-cc3d.npy + statistics + CSV) on THIS
+    volume, files on tmpfs (/dev/shm; $DLV_BENCH_TMP overrides), so that what is timed is the step's own host work - reads,
+    PCIe, the passes, writes - and not a disk.  Returns the `step_walls` block of the bench line (H2D / D2H rates included)."""
+    import shutil
+    import tempfile
+
+    from delivr_cfos_amd import hostio
+    from delivr_cfos_amd.count_blobs import count_blobs
+    from delivr_cfos_amd.inference.inference import run_inference
+
+    Z, Y, X = stack
+    need = int(vol.numel()) * 2 + Z * Y * X * (1 + 4) + (1 << 30)
+    base = os.environ.get("DLV_BENCH_TMP") or "/dev/shm"
+    try:
+        free = shutil.disk_usage(base).free
+        avail = None
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+    except OSError as exc:
+        return {"skipped": f"{base}: {exc}"}
+    if free < 1.25 * need or (avail is not None and avail < 2.5 * need):
+        return {"skipped": f"{base} has {free / 2**30:.0f} GiB free, the host {0 if avail is None else avail / 2**30:.0f} GiB available: "
+                           f"{need / 2**30:.0f} GiB of files needed"}
+    d = tempfile.mkdtemp(prefix="dlv_bench_", dir=base)
+    try:
+        nifti_dir = os.path.join(d, "01_mask", "brain", "masked_niftis")
+        out_dir = os.path.join(d, "02_blob")
+        post_dir = os.path.join(d, "03_post") + "/"
+        os.makedirs(nifti_dir)
+        nifti = os.path.join(nifti_dir, "masked_nifti.npy")
+        t0 = time.perf_counter()
+        hostio.save_npy(eng, vol.reshape((1, 1) + tuple(shape)), nifti, np.uint16, what="d2h_volume")
+        write_volume_s = time.perf_counter() - t0
+        if os.path.getsize(nifti) != 128 + int(vol.numel()) * 2:
+            return {"skipped": "masked_nifti.npy: numpy's header is not the 128 bytes the reference assumes (inference.py:234)"}
+        import contextlib
+        import io
+
+        log = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(log):  # (the step's own progress lines: bench.py prints ONE line)
+            run_inference([nifti], out_dir, (1, 1, Z, Y, X), comment="brain", tta=bool(tta), crop_size=tuple(roi),
+                          state_dict={"state_dict": sd}, precision=precision)
+        step2 = time.perf_counter() - t0
+        t2 = dict(getattr(run_inference, "last_timings", {}))
+        xfer2 = {k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_volume", "d2h_mask")}
+        settings = {"postprocessing": {"output_location": post_dir}}
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(log):
+            n_comp = count_blobs(settings, out_dir, 0, "brain", (1, 1, Z, Y, X))
+        step3 = time.perf_counter() - t0
+        t3 = dict(getattr(count_blobs, "last_timings", {}))
+        xfer3 = {k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_mask", "d2h_labels")}
+        # the files the next step / the reference's consumers read
+        binaries = np.load(os.path.join(out_dir, "brain", "binary_segmentations", "binaries.npy"), mmap_mode="r")
+        lab_path = os.path.join(post_dir, f"brain-{n_comp}-cc3d.npy")
+        labels = np.load(lab_path, mmap_mode="r")
+        fg = int(np.count_nonzero(binaries))
+        n_lab = 0
+        for zc in range(0, Z, 64):  # (the labels number the components 1..N in raster order: the largest label is N)
+            n_lab = max(n_lab, int(labels[zc:zc + 64].max()))
+        files_ok = bool(binaries.shape == (Z, Y, X) and binaries.dtype == np.uint8 and fg == int(mask_voxels) and labels.shape == (Z, Y, X)
+                        and n_lab == int(n_comp) and os.path.isfile(os.path.join(post_dir, "brain-stats.pickle"))
+                        and os.path.isfile(post_dir + f"({Z}, {Y}, {X})_brain.csv"))
+        return {"step2_wall_s": step2, "step3_wall_s": step3, "step2_breakdown": t2, "step3_breakdown": t3,
+                "h2d_volume": xfer2.get("h2d_volume"), "d2h_mask": xfer2.get("d2h_mask"), "h2d_mask": xfer3.get("h2d_mask"),
+                "d2h_labels": xfer3.get("d2h_labels"), "write_input_volume_s": write_volume_s, "components": int(n_comp),
+                "label_dtype": str(labels.dtype), "mask_voxels_in_file": fg, "files_ok": files_ok, "files_on": base,
+                "io_threads": hostio.io_threads(),
+                "what": "run_inference(masked_nifti.npy -> binaries.npy) and count_blobs(binaries.npy -> labels .npy, stats pickle, CSV) "
+                        "called as python -m delivr_cfos_amd calls them, fresh engine per step, files on tmpfs; wall clock of each call"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +350,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the stages either side of the pass (finalize, CCL-26 + statistics, "
                     "resamplers, one Gaussian-blend pass: BASELINE configs 4/5), which run by default at N=1")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
+    ap.add_argument("--no-step-walls", action="store_true", help="skip the file -> file wall-clock of run_inference and count_blobs "
+                    "on this volume (N = 1; ~30 GiB of files on /dev/shm for c3)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -316,13 +403,26 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from delivr_cfos_amd.engine import HipEngine
-    from delivr_cfos_amd.hostlogic import arrayterator_zblock
+    from delivr_cfos_amd.hostlogic import arrayterator_zblock, padded_shape, pass_schedule
     from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, p2p_selftest, plan_from_params
     from delivr_cfos_amd.synth import synth_planes_torch, synth_volume_torch
     from delivr_cfos_amd.weights import TRAINED_LIKE_FIXTURE, random_state_dict, trained_like_state_dict
 
-    shape, roi, seed = WORKLOADS[args.workload]
-    Z, Y, X = shape
+    stack, roi, seed, tta = WORKLOADS[args.workload]
+    Z, Y, X = stack
+    shape = padded_shape(stack, roi)  # the volume the windows tile (Zp, Yp, Xp)
+    Zp, Yp, Xp = shape
+    schedule = pass_schedule(tta)     # [(flip_dim, repeat)]: the distinct passes of one inference
+
+    def planes(lo, hi):
+        """planes [lo, hi) of the padded volume: the synthetic brain fills the stack, the padding is background"""
+        if (Zp, Yp, Xp) == (Z, Y, X):
+            return synth_planes_torch(stack, seed, eng.device, lo, hi, dense=args.dense)
+        out = torch.zeros((hi - lo, Yp, Xp), dtype=torch.uint16, device=eng.device)
+        if min(hi, Z) > lo:
+            out[: min(hi, Z) - lo, :Y, :X] = synth_planes_torch(stack, seed, eng.device, lo, min(hi, Z), dense=args.dense)
+        return out
+
     eng = HipEngine(local_rank)
     if args.weights == "trained" and not os.path.isfile(TRAINED_LIKE_FIXTURE):
         # (a different checkpoint means another mask, skip fraction and CCL workload under the same metric name)
@@ -341,22 +441,26 @@ def main():
     params_all = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch)
     nb = arrayterator_zblock((Z, Y, X))
     if not dist_mode:
-        vol = synth_volume_torch(shape, seed, eng.device, dense=args.dense)
+        vol = planes(0, Zp)
         torch.cuda.synchronize()
         plan = plan_from_params(params_all, 1, None)
-        slo, shi = 0, Z
+        slo, shi = 0, Zp
     else:
         # slab-resident: every rank generates (a real run: reads) and holds only the planes of ITS Z-slab; the shards are
         # balanced by the windows that actually run the network (a brain fills the central slabs, not the outer ones)
         plan, slo, shi, vol = balanced_plan(
-            eng, params_all, lambda lo, hi: synth_planes_torch(shape, seed, eng.device, lo, hi, dense=args.dense), world, rank,
-            dist, Z, 30, nb)
+            eng, params_all, planes, world, rank, dist, Z, 30, nb)
     wb, we = plan.win_ranges[rank]
-    params = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, win_range=(wb, we),
-                                slab=(slo, shi - slo))
-    if we <= wb:  # a rank without windows still takes part in the exchange
-        params = None
-    acc = torch.zeros((shi - slo, Y, X), dtype=torch.float32, device=eng.device)
+
+    def pass_params(precision, skip_threshold=0):
+        """one dlv_sw_params per distinct pass of the schedule (None: this rank has no windows - it still takes part in the exchange)"""
+        if we <= wb:
+            return None
+        return [eng.make_sw_params(shape, roi, 0.5, flip, skip_threshold, precision, sw_batch=args.sw_batch, win_range=(wb, we),
+                                   slab=(slo, shi - slo), repeat=rep_n) for flip, rep_n in schedule]
+
+    params = pass_params(args.precision)
+    acc = torch.zeros((shi - slo, Yp, Xp), dtype=torch.float32, device=eng.device)
 
     stats_last = {}
     cur = {"params": params}
@@ -364,7 +468,8 @@ def main():
     def step():
         acc.zero_()
         if cur["params"] is not None:
-            stats_last.update(eng.sw_infer(cur["params"], vol, acc))
+            for q in cur["params"]:
+                stats_last.update(eng.sw_infer(q, vol, acc))
         if dist_mode:
             eng.sync()
             exchange_seams(acc, plan, rank, dist, z0=slo)
@@ -410,18 +515,14 @@ def main():
     # every window through the network (background skip disabled): the number the MFMA ceiling is quoted against
     elapsed_dense, stats_dense = None, {}
     if not args.no_dense and not args.dense:
-        if params is not None:  # skip_threshold -1: no window's maximum is <= -1
-            cur["params"] = eng.make_sw_params(shape, roi, 0.5, None, -1, args.precision, sw_batch=args.sw_batch,
-                                               win_range=(wb, we), slab=(slo, shi - slo))
+        cur["params"] = pass_params(args.precision, -1)  # skip_threshold -1: no window's maximum is <= -1
         elapsed_dense, _ = timed_steps(1)
         stats_dense = dict(stats_last)
         cur["params"] = params
     # the other 16-bit format, one pass (BASELINE's configs name bf16; fp16 is the default for its closer masks)
     elapsed_alt, alt_prec = None, {"fp16": "bf16", "bf16": "fp16"}.get(args.precision)
     if alt_prec and not args.no_dense and not args.dense:
-        if params is not None:
-            cur["params"] = eng.make_sw_params(shape, roi, 0.5, None, 0, alt_prec, sw_batch=args.sw_batch, win_range=(wb, we),
-                                               slab=(slo, shi - slo))
+        cur["params"] = pass_params(alt_prec)
         step()  # warm-up of the other format's kernels
         elapsed_alt, _ = timed_steps(1)
         cur["params"] = params
@@ -467,6 +568,7 @@ def main():
     vox = float(Z) * Y * X
     value = vox / (elapsed / args.steps)
     n_active = n_windows - n_skipped
+    n_passes = len(schedule)  # distinct passes per step (1, or 3 under TTA: the 13 of the reference weighted 5:4:4)
     tile_vox = float(roi[0] * roi[1] * roi[2])
 
     # ---- roofline of the dominant kernel (rank 0's HIP-event timings) -----------------------------------
@@ -496,7 +598,7 @@ def main():
         try:
             from delivr_cfos_amd._lib import build_fingerprint
 
-            cands = [(f"traffic_r05_{args.workload}.json", False), ("traffic_r05_c2.json", True)]
+            cands = [(f"traffic_r06_{args.workload}.json", False), ("traffic_r06_c2.json", True), ("traffic_r05_c2.json", True)]
             tfile, scaled = next(((os.path.join(ROOT, "profiles", n), sc) for n, sc in cands if os.path.isfile(os.path.join(ROOT, "profiles", n))),
                                  (None, True))
             if tfile is None:
@@ -530,7 +632,7 @@ def main():
             r["traffic_note"] = f"traffic lookup failed: {ex}"
         r["lanes"] = lanes
         net_ms = sum(v["total_ms"] for v in prof.values())
-        r["forward_tflops"] = (FLOP_PER_PATCH_VOXEL * tile_vox * n_active * steps_covered / (1e-3 * net_ms) / 1e12
+        r["forward_tflops"] = (FLOP_PER_PATCH_VOXEL * tile_vox * n_active * n_passes * steps_covered / (1e-3 * net_ms) / 1e12
                                if net_ms > 0 and world == 1 and lanes == 1 else None)
         return r, kernels
 
@@ -573,8 +675,8 @@ def main():
                     "hbm_frac": nbytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9)}
 
         extras = {"voxels": vox}
-        zb = arrayterator_zblock(shape)
-        ms, mask = timed(lambda: eng.finalize(acc, None, vol, shape, 0.5, 30, zb), reps=2)
+        zb = arrayterator_zblock(stack)
+        ms, mask = timed(lambda: eng.finalize(acc, None, vol, stack, 0.5, 30, zb), reps=2)
         extras["finalize"] = entry(ms, vox * 7, "4 (fp32 sums) + 2 (uint16 raw) read, 1 (mask) written")
         mask = mask.contiguous()
         ms, (labels, ncomp) = timed(lambda: eng.ccl26(mask))
@@ -585,23 +687,24 @@ def main():
         extras["cc_stats"] = entry(ms, vox * 4, "4 (labels) read")
         del labels
         # the synthetic cells themselves (blobs of 10-40 voxels, ~4e-4 per tissue voxel): a second, denser cell mask
-        cells = (vol.view(torch.int16) > 6500).to(torch.uint8) if vol.dtype == torch.uint16 else (vol > 6500).to(torch.uint8)
+        volv = vol if tuple(shape) == tuple(stack) else vol[:Z, :Y, :X].contiguous()  # (the stack without its padding)
+        cells = (volv.view(torch.int16) > 6500).to(torch.uint8) if volv.dtype == torch.uint16 else (volv > 6500).to(torch.uint8)
         ms, (labels, ncells) = timed(lambda: eng.ccl26(cells))
         extras["ccl26_cells"] = entry(ms, vox * 5, "1 (mask) read, 4 (uint32 labels) written")
         extras["ccl26_cells"]["components"] = ncells
         ms, _ = timed(lambda: eng.cc_stats(labels, ncells), reps=1)
         extras["cc_stats_cells"] = entry(ms, vox * 4, "4 (labels) read")
         del labels, cells
-        ms, ds = timed(lambda: eng.block_mean_u16(vol, (4, 15, 15)))
+        ms, ds = timed(lambda: eng.block_mean_u16(volv, (4, 15, 15)))
         extras["block_mean_4x15x15"] = entry(ms, vox * 2 + ds.numel() * 2, "2 (uint16) read, 2/900 written")
         small = (ds.to(torch.int32) > 0).to(torch.uint8)
-        ms, _ = timed(lambda: eng.zoom_spline2_u8(small, shape), reps=1)
+        ms, _ = timed(lambda: eng.zoom_spline2_u8(small, stack), reps=1)
         extras["zoom_spline2_to_full"] = entry(ms, vox * 1 + small.numel(), "1 (uint8 mask) written, 1/900 read")
         del small, ds
         # one pass with MONAI's Gaussian importance map instead of constant weights (option)
         if params is not None:
             wsum = torch.zeros_like(acc)
-            gp = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, blend="gaussian", wsum=wsum)
+            gp = eng.make_sw_params(shape, roi, 0.5, None, 0, args.precision, sw_batch=args.sw_batch, blend="gaussian", wsum=wsum)  # (one plain pass)
             acc_g = torch.zeros_like(acc)
             fence()
             t0 = time.perf_counter()
@@ -610,11 +713,18 @@ def main():
             extras["gaussian_blend_pass_ms"] = 1e3 * (time.perf_counter() - t0)
             del wsum, acc_g
 
+    walls = None
+    if not args.no_step_walls and world == 1 and not dist_mode:
+        try:
+            walls = step_walls(eng, vol, stack, shape, roi, tta, args.precision, sd, mask_voxels)
+        except Exception as exc:  # reported, never fatal for the metric
+            walls = {"skipped": f"failed: {exc!r}"}
+
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only (bench contract)
         try:
             threads = os.cpu_count() or 1
-            cpu = cpu_baseline(eng, sd, vol, shape, roi, n_active, vox, threads, args.cpu_crop, args.precision, weights_name, acc, nb)
+            cpu = cpu_baseline(eng, sd, vol, stack, roi, n_active * n_passes, vox, threads, args.cpu_crop, args.precision, weights_name, acc, nb)
         except Exception as exc:  # the baseline is reported, never fatal
             cpu = {"value": None, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc}"}
 
@@ -641,13 +751,17 @@ def main():
         "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain, windows {roi[0]}^3, overlap 0.5, "
-                        f"1 pass (no TTA), {weights_name} BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
+            "workload": f"{args.workload}: {Z}x{Y}x{X} (Z,Y,X) uint16 synthetic brain"
+                        + (f" zero-padded to {Zp}x{Yp}x{Xp}" if shape != tuple(stack) else "")
+                        + f", windows {roi[0]}x{roi[1]}x{roi[2]}, overlap 0.5, "
+                        + ("TTA: the reference's 13 passes as 3 distinct passes (plain, flip Z, flip Y) weighted 5:4:4" if tta else "1 pass (no TTA)")
+                        + f", {weights_name} BasicUNet(32,32,64,128,256,32) weights, {args.precision} operands / fp32 accumulate"
                         + (", dense (no background)" if args.dense else ", ellipsoid brain (background skipped)"),
-            "volume_zyx": [Z, Y, X], "roi": list(roi), "overlap": 0.5,
+            "volume_zyx": [Z, Y, X], "padded_zyx": list(shape), "roi": list(roi), "overlap": 0.5, "tta": bool(tta),
+            "passes_per_step": n_passes, "pass_weights": [r for _, r in schedule],
             "windows": n_windows, "windows_skipped": n_skipped, "per_rank_windows": per_rank,
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
-            "patch_voxels_per_s": tile_vox * n_active / (elapsed / args.steps),
+            "patch_voxels_per_s": tile_vox * n_active * n_passes / (elapsed / args.steps),
             "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),
             "lanes": int(os.environ.get("DLV_LANES", "3")),
             "mask_voxels": mask_voxels, "mask_checksum": mask_checksum,
@@ -663,6 +777,8 @@ def main():
         "cpu_baseline": cpu,
         "kernels": kernels,
         "extras": extras,
+        # the step boundary: wall clock file -> file of the two steps, with the H2D / D2H transfers timed separately
+        "step_walls": walls,
     }
     print(json.dumps(out))
     if dist_mode:

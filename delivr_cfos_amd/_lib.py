@@ -54,7 +54,8 @@ def build_fingerprint(lib_path: str | None = None) -> dict:
 
 
 DLV_OK, DLV_EINVAL, DLV_EHIP, DLV_ENOMEM, DLV_ESTATE, DLV_EUNSUP, DLV_ERANGE = 0, -1, -2, -3, -4, -5, -6
-PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+ABI_VERSION = 2  # include/delivr_hip.h: DLV_ABI_VERSION
+PREC_F32, PREC_BF16, PREC_F16, PREC_BF16_ALL = 0, 1, 2, 3  # (DLV_PREC_*: BF16 = bf16 below fp16 level 0, BF16_ALL = bf16 everywhere)
 N_CONV, N_DECONV = 18, 4
 PROF_MAX = 64
 
@@ -212,7 +213,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dlv_abi_version() != 1:
-        raise ImportError("libdelivr_hip.so ABI version mismatch")
+    if lib.dlv_abi_version() != ABI_VERSION:
+        raise ImportError(f"libdelivr_hip.so reports ABI version {lib.dlv_abi_version()}, this package binds version {ABI_VERSION} "
+                          "(include/delivr_hip.h: DLV_ABI_VERSION): rebuild with make -C delivr_cfos_amd/csrc")
     _lib = lib
     return lib

@@ -471,8 +471,10 @@ int dlv_range_next_shifts(int layer, const float* peaks, const int* shifts, int*
         const int p = cand[i];
         const bool hint = hinted && peaks[p] > 4096.0f;
         if (hinted && !hint) continue;
-        // |mean| + 8 sigma of the stored tensor to <= 1024; without a hint 6 bits at a time
+        // |mean| + 8 sigma of the stored tensor to <= 1024; without a hint 6 bits at a time - but never a block whose recorded
+        // |mean| + 8 sigma would fall below 1 (sigma below 2^-3: its small values would leave fp16's normal range)
         const int step = hint ? std::max(1, (int)std::ceil(std::log2((double)peaks[p] / 1024.0))) : 6;
+        if (!hint && peaks[p] > 0.0f && (double)peaks[p] * std::exp2(-(double)step) < 1.0) continue;
         const int k = std::min(40, shifts[p] + step);
         if (k != shifts[p]) {
             out[p] = k;
@@ -481,19 +483,76 @@ int dlv_range_next_shifts(int layer, const float* peaks, const int* shifts, int*
     }
     return changed;
 }
+}  // extern "C"
+// (internal, C++ linkage: common.h)
+int dlv_unet_apply_conv_shifts(dlv_ctx* ctx, const int* shifts) {
+    if (!ctx || !shifts) return DLV_EINVAL;
+    if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "conv shifts before dlv_unet_load");
+    for (int i = 0; i < DLV_N_CONV; ++i)
+        if (shifts[i] < 0 || shifts[i] > 40) return dlv_fail(ctx, DLV_EINVAL, "conv shift %d of block %d", shifts[i], i);
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    DLV_TRY(dlv_sync_all(ctx));
+    int old[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) {
+        old[i] = ctx->conv[i].shift;
+        ctx->conv[i].shift = shifts[i];
+    }
+    int rc = dlv_pack_weights_bf16(ctx);
+    if (rc == DLV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = dlv_fail(ctx, DLV_EHIP, "repack of the 16-bit weights failed");
+    if (rc != DLV_OK) {  // eps and the packs must agree: back to the shifts the packs were made with (best effort: repack those)
+        for (int i = 0; i < DLV_N_CONV; ++i) ctx->conv[i].shift = old[i];
+        (void)dlv_pack_weights_bf16(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    ctx->range_last = -1;  // the report belongs to the pass before the repack: a second recover without a pass must not reuse it
+    for (int i = 0; i < DLV_N_CONV; ++i) ctx->range_peak[i] = 0.f;
+    return DLV_OK;
+}
+// the next shifts for (layer, peaks) from this context's current ones -> number of blocks that change (0: nothing left);
+// *blind: no block feeding the layer reported a peak (a 6-bit step on no evidence)
+int dlv_range_plan(dlv_ctx* ctx, int layer, const float* peaks, int* nxt, bool* blind) {
+    int cur[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) cur[i] = ctx->conv[i].shift;
+    int cand[2];
+    const int nc = range_producers(layer, cand);
+    *blind = true;
+    for (int i = 0; i < nc; ++i) *blind = *blind && !(peaks[cand[i]] > 4096.0f);
+    return dlv_range_next_shifts(layer, peaks, cur, nxt);
+}
+int dlv_range_step(dlv_ctx* ctx, int layer, const float* peaks, int* n_changed, const int* force_next) {
+    int nxt[DLV_N_CONV];
+    bool blind = false;
+    int changed = dlv_range_plan(ctx, layer, peaks, nxt, &blind);
+    // a blind step that did not move the overflow (the same layer is named again, again without a hint) is not repeated: the
+    // value that leaves the range is not a stored conv output (e.g. the un-normalised transposed conv) and no shift reaches it
+    if (changed > 0 && blind && ctx->range_seq && ctx->range_blind_layer == layer) changed = 0;
+    if (changed <= 0) {
+        if (ctx->range_seq) {  // leave the packs as the caller's next format finds them best: the shifts of before the sequence
+            (void)dlv_unet_apply_conv_shifts(ctx, ctx->range_base);
+            ctx->range_seq = false;
+            ctx->range_blind_layer = -1;
+        }
+        return dlv_fail(ctx, DLV_ERANGE, "range guard: no block shift left to try for conv block %d (repeat the passes with DLV_PREC_BF16_ALL)", layer);
+    }
+    if (!ctx->range_seq) {
+        for (int i = 0; i < DLV_N_CONV; ++i) ctx->range_base[i] = ctx->conv[i].shift;
+        ctx->range_seq = true;
+    }
+    DLV_TRY(dlv_unet_apply_conv_shifts(ctx, force_next ? force_next : nxt));
+    ctx->range_blind_layer = blind ? layer : -1;
+    if (n_changed) *n_changed = changed;
+    return DLV_OK;
+}
+extern "C" {
 int dlv_range_recover(dlv_ctx* ctx, int* n_changed) {
     if (!ctx) return DLV_EINVAL;
     if (n_changed) *n_changed = 0;
     if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_range_recover before dlv_unet_load");
     if (ctx->range_last < 0) return dlv_fail(ctx, DLV_ESTATE, "dlv_range_recover: the last 16-bit pass did not end with DLV_ERANGE");
-    int cur[DLV_N_CONV], nxt[DLV_N_CONV];
-    for (int i = 0; i < DLV_N_CONV; ++i) cur[i] = ctx->conv[i].shift;
-    const int changed = dlv_range_next_shifts(ctx->range_last, ctx->range_peak, cur, nxt);
-    if (changed <= 0) return dlv_fail(ctx, DLV_ERANGE, "range guard: no block shift left to try for conv block %d (repeat the passes in bf16)", ctx->range_last);
-    for (int i = 0; i < DLV_N_CONV; ++i) ctx->conv[i].shift = nxt[i];
-    DLV_TRY(dlv_unet_set_conv_shift(ctx, 0, nxt[0]));  // (re-packs every block with the shifts noted above)
-    if (n_changed) *n_changed = changed;
-    return DLV_OK;
+    float peaks[DLV_N_CONV];
+    for (int i = 0; i < DLV_N_CONV; ++i) peaks[i] = ctx->range_peak[i];
+    return dlv_range_step(ctx, ctx->range_last, peaks, n_changed, nullptr);
 }
 
 int dlv_unet_blob_size(dlv_ctx* ctx, size_t* bytes) {
@@ -518,8 +577,8 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
         return dlv_fail(ctx, DLV_EUNSUP, "patch %dx%dx%d: every dimension must be a multiple of 16", d, h, w);
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     if (precision == DLV_PREC_F32) return dlv_unet_forward_f32(ctx, x_dev, logits_dev, B, d, h, w);
-    if (precision == DLV_PREC_BF16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 0);
-    if (precision == DLV_PREC_F16) return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, 1);
+    if (precision == DLV_PREC_BF16 || precision == DLV_PREC_F16 || precision == DLV_PREC_BF16_ALL)
+        return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, dlv_fmt16(precision));
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
 }
 
@@ -542,7 +601,7 @@ int dlv_debug_stamps(dlv_ctx* ctx, void* buf_dev) {
 }
 
 int dlv_debug_set_format(dlv_ctx* ctx, int precision) {
-    if (!ctx || (precision != DLV_PREC_BF16 && precision != DLV_PREC_F16)) return DLV_EINVAL;
+    if (!ctx || (precision != DLV_PREC_BF16_ALL && precision != DLV_PREC_F16)) return DLV_EINVAL;  // (one layer: one format)
     ctx->debug_f16 = precision == DLV_PREC_F16;
     return DLV_OK;
 }

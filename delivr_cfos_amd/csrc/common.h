@@ -103,6 +103,9 @@ struct dlv_ctx {
                                 // [1 + layer] float bits of the largest |mean| + 8 sigma of the layer's raw output that exceeded 4096
     int range_last = -1;        // layer of the last DLV_ERANGE (-1: none)
     float range_peak[DLV_N_CONV] = {0};  // ... and the peaks read back with it
+    bool range_seq = false;              // dlv_range_recover has changed shifts since the last pass that came to its end
+    int range_base[DLV_N_CONV] = {0};    // ... the shifts before its first step (restored when nothing is left to try)
+    int range_blind_layer = -1;          // layer whose last step was blind (no block reported a peak): not repeated
     void* zero_page = nullptr;  // 256 zero bytes: source of out-of-window lanes of LDS-DMA loads
     void* blob = nullptr;  // one allocation holding every packed parameter
     size_t blob_bytes = 0;
@@ -206,11 +209,13 @@ __device__ __forceinline__ int dlv_xcd_tile(unsigned bx, unsigned gx) {
 
 // ---- internal engine entry points (defined in the .hip files) ---------------------------------
 int dlv_unet_forward_f32(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w);
-int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16);
+// fmt16 (the 16-bit format of a forward): 0 = bf16 everywhere, 1 = fp16 everywhere, 2 = fp16 at level 0 + bf16 below
+static inline int dlv_fmt16(int precision) { return precision == DLV_PREC_F16 ? 1 : (precision == DLV_PREC_BF16 ? 2 : 0); }
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int fmt16);
 // bf16 path fused with the tiler: reads the uint16 volume at the given window starts, adds the
 // logits into acc (see sw_infer.hip)
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
-                        int h, int w, int flip_dim, float scale, float* acc, int f16);
+                        int h, int w, int flip_dim, float scale, float* acc, int fmt16);
 int dlv_pack_weights_bf16(dlv_ctx* ctx);
 // z-marching conv for Cout in {32, 64, ...} (blocks of 32), Cin in {32, 64} (conv_zmarch.hip)
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
@@ -241,7 +246,13 @@ int dlv_upconv2_launch(dlv_ctx* ctx, bool f16, const void* in, const void* wpk, 
 bool dlv_conv3_zreg_supports(int cin, int cout, int c1, int c2, int W);
 // range guard of the 16-bit formats (unet_bf16.hip): reset before a pass / forward, check after it (synchronises the stream)
 int dlv_range_reset(dlv_ctx* ctx);
-int dlv_range_check(dlv_ctx* ctx, bool f16);
+int dlv_range_check(dlv_ctx* ctx, int fmt16);
+// api.hip: all 18 block shifts at once - committed only when the repack succeeded (rolled back otherwise); clears the report
+int dlv_unet_apply_conv_shifts(dlv_ctx* ctx, const int* shifts);
+// api.hip: one step of the recovery policy with the layer / peaks given (dlv_range_recover: the context's own report;
+// dlv_comm_range_recover: the maxima over the ranks) -> DLV_OK + *n_changed, or DLV_ERANGE when nothing is left (shifts restored)
+int dlv_range_step(dlv_ctx* ctx, int layer, const float* peaks, int* n_changed, const int* force_next /* or nullptr */);
+int dlv_range_plan(dlv_ctx* ctx, int layer, const float* peaks, int* nxt, bool* blind);
 size_t dlv_bf16_pack_bytes(const int features[6]);
 #if defined(__HIPCC__)
 // Sum of a value over the 32 lanes of each wave half (lanes 0-31, lanes 32-63) with DPP adds only (five VALU

@@ -194,7 +194,7 @@ conv3_deep_kernel(const uint4* __restrict__ in1, int c1_8, const uint4* __restri
             const int cb = f % NCB, t9 = f / NCB;
             const unsigned frag = (unsigned)__builtin_amdgcn_readfirstlane((((ct * NCB + cb) * 27 + kz * 9 + t9) * KS + sl) * 1024);
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(wbuf_lds + (unsigned)(buf * C::WG_ELEMS + f * 64) * 16u));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(dma_voff), "s"(wrs), "s"(frag) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(dma_voff), "s"(wrs), "s"(frag) : "memory", "m0");
         }
     };
 
@@ -464,7 +464,7 @@ deconv2_deep_kernel(const uint4* __restrict__ in, const uint4* __restrict__ wpk,
             const int f = wave + 8 * i;
             const unsigned src = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)f * 1024u));
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(wst_lds + (unsigned)(st * STAGE + f * 64) * 16u));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(dma_voff), "s"(wrs), "s"(src) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(dma_voff), "s"(wrs), "s"(src) : "memory", "m0");
         }
     };
     dma_pair(0, 0);
@@ -553,9 +553,13 @@ int dd_launch(dlv_ctx* ctx, const void* in, const void* wpk16, const float* bias
 
 }  // namespace
 
-// which layers the kernel takes: the deep levels of a window (at most 32^3 voxels), channel counts in multiples of 32 / 64
+// which layers the kernel takes: the deep levels of a window (at most 32^3 voxels), channel counts in multiples of 32.  Levels
+// smaller than a tile (6 x 6 x 4 and 12 x 12 x 8 of the reference's default 96 x 96 x 64 window, config.json:24-28; 8 x 8 x 4 and
+// 4 x 4 x 2 of run_inference's own (64, 64, 32), inference/inference.py:119) run as partly filled tiles - out-of-window lanes
+// read zeros and store nothing: still 3-4x the generic kernel, whose waves each pull their own weight fragments from L2 - and
+// so do the 32-output-channel layers of a level whose rows are shorter than the 32 voxels the z-reg / z-march tiles need
 bool dlv_conv3_deep_supports(int cin, int cout, int c1, int c2, int D, int H, int W) {
-    return cin % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0 && c1 + c2 == cin && cout % 32 == 0 && cout >= 64 && W >= 8 && H >= 8 && D >= 4 &&
+    return cin % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0 && c1 + c2 == cin && cout % 32 == 0 && cout >= 32 && W >= 2 && H >= 2 && D >= 2 &&
            (long long)D * H * W <= 32768;
 }
 

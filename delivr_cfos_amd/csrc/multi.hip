@@ -477,14 +477,13 @@ int dlv_comm_range_recover(dlv_comm* c, int* n_changed) {
         for (int i = 0; i < DLV_N_CONV; ++i) peaks[i] = std::max(peaks[i], pk[i]);
     }
     if (layer < 0) return comm_fail(c, DLV_ESTATE, "dlv_comm_range_recover: no rank's last 16-bit pass ended with DLV_ERANGE");
-    int cur[DLV_N_CONV], nxt[DLV_N_CONV];
-    for (int i = 0; i < DLV_N_CONV; ++i) DLV_TRY(dlv_unet_get_conv_shift(c->ctx[0], i, &cur[i]));
-    const int changed = dlv_range_next_shifts(layer, peaks, cur, nxt);
-    if (changed <= 0) return comm_fail(c, DLV_ERANGE, "range guard: no block shift left to try for conv block %d (repeat the passes in bf16)", layer);
+    // one decision (rank 0's shifts are everybody's), the same step on every rank: each commits only after its repack succeeded
+    int changed = 0;
     for (int r = 0; r < c->n; ++r) {
-        int rc = dlv_unet_note_conv_shifts(c->ctx[r], nxt);
-        if (rc == DLV_OK) rc = dlv_unet_set_conv_shift(c->ctx[r], 0, nxt[0]);  // (re-packs every block of this rank's blob)
+        int ch = 0;
+        const int rc = dlv_range_step(c->ctx[r], layer, peaks, &ch, nullptr);
         if (rc != DLV_OK) return comm_fail(c, rc, "rank %d: %s", r, dlv_last_error(c->ctx[r]));
+        if (r == 0) changed = ch;
     }
     if (n_changed) *n_changed = changed;
     return DLV_OK;

@@ -361,7 +361,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
                      dlv_sw_stats* stats) {
     if (!ctx || !p || !vol_dev || !acc_dev) return DLV_EINVAL;
     if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_sw_infer_dev before dlv_unet_load");
-    if (p->precision != DLV_PREC_F32 && p->precision != DLV_PREC_BF16 && p->precision != DLV_PREC_F16)
+    if (p->precision != DLV_PREC_F32 && p->precision != DLV_PREC_BF16 && p->precision != DLV_PREC_F16 && p->precision != DLV_PREC_BF16_ALL)
         return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", p->precision);
     if (!(p->flip_dim == -1 || (p->flip_dim >= 2 && p->flip_dim <= 4)))
         return dlv_fail(ctx, DLV_EINVAL, "flip_dim must be -1, 2, 3 or 4");
@@ -500,9 +500,9 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
 
     int sw_batch = p->sw_batch;
     if (sw_batch <= 0) {
-        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 64 of 96x96x64, ...), capped:
-        // ~10 GB of bf16 activations, and enough tiles at the deep levels to fill 256 CUs
-        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 64);
+        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 56 of 96x96x64, 256 of 64x64x32, ...):
+        // ~10 GB of 16-bit activations, and enough tiles at the deep levels to fill 256 CUs
+        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 256);
     }
     int64_t launches = 0;
     const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);
@@ -536,7 +536,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
             if (p->precision != DLV_PREC_F32) {
                 ctx->lane = two_lanes ? lane : 0;
                 ctx->stream = lane_stream(ctx->lane);
-                rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, p->precision == DLV_PREC_F16 ? 1 : 0);
+                rc = dlv_unet_tiles_bf16(ctx, vol_dev, Yp, Xp, st_dev, B, d, h, w, p->flip_dim, (float)rep, acc_dev, dlv_fmt16(p->precision));
                 if (rc == DLV_OK && cnt_dev) {
                     hipLaunchKernelGGL(fill_add_kernel, dim3(bchunks, B), dim3(256), 0, ctx->stream, st_dev, d, h, w, Yp,
                                        Xp, 0.0f, rep, acc_dev, cnt_dev, nullptr, 0.f, nullptr);
@@ -579,7 +579,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     }
     // range guard of the 16-bit formats: every lane has been joined into the main stream; one read-back per pass (a pass is
     // seconds of queued work, and the next one starts with the read-back of its window maxima anyway)
-    if (p->precision != DLV_PREC_F32 && launches > 0) return dlv_range_check(ctx, p->precision == DLV_PREC_F16);
+    if (p->precision != DLV_PREC_F32 && launches > 0) return dlv_range_check(ctx, dlv_fmt16(p->precision));
     return DLV_OK;
 }
 

@@ -18,6 +18,7 @@
 // K runs over 27 taps x Cin/16.  Weights are pre-packed in A-fragment order (one coalesced 1 KiB
 // load per fragment, L2-resident); the input halo tile is staged through LDS.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "prec16.h"
@@ -635,10 +636,11 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
         double var = q * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         // ... and which layer is the large one: the sums are those of the fp32 accumulators, so they stay finite when the STORED
-        // 16-bit value overflows.  |mean| + 8 sigma beyond 4096 (a rare path: one atomic) is recorded per layer; after a
-        // DLV_ERANGE the host reads it as the hint for dlv_unet_set_conv_shift (positive floats order like their bit patterns)
+        // 16-bit value overflows.  The largest |mean| + 8 sigma of every block is recorded (one atomic per (window, channel) of a
+        // 64-thread workgroup); after a DLV_ERANGE the host reads it as the hint for dlv_unet_set_conv_shift: how far to move a
+        // block that reported > 4096, and which blocks are too SMALL to be moved at all (positive floats order like their bit patterns)
         const float peak = (float)(fabs(mean) + 8.0 * sqrt(var));
-        if (peak > 4096.f && peak < 3.0e38f) atomicMax(range_flag + 1 + layer, __float_as_int(peak));
+        if (peak > 0.f && peak < 3.0e38f) atomicMax(range_flag + 1 + layer, __float_as_int(peak));
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = rstd * gamma[c];
         ss[n * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
@@ -648,7 +650,9 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // InstanceNorm apply + Mish (+ MaxPool3d(2) into a second tensor), in place on the raw bf16 tensor
 // ---------------------------------------------------------------------------------------------------
-template <class P>
+// P: the format the raw tensor is stored in; PO: the format of the activated value (the mixed 16-bit mode changes format between
+// levels 0 and 1: DLV_PREC_BF16 keeps fp16 at full resolution, section 5 of DESIGN.md)
+template <class P, class PO = P>
 __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const float* sh, float* mx) {
     float v[8] = {P::lo(u.x), P::hi(u.x), P::lo(u.y), P::hi(u.y), P::lo(u.z), P::hi(u.z), P::lo(u.w), P::hi(u.w)};
 #pragma unroll
@@ -662,17 +666,18 @@ __device__ __forceinline__ uint4 norm_mish8(uint4 u, const float* sc, const floa
         }
     }
     uint4 r;
-    r.x = P::pack2(v[0], v[1]);
-    r.y = P::pack2(v[2], v[3]);
-    r.z = P::pack2(v[4], v[5]);
-    r.w = P::pack2(v[6], v[7]);
+    r.x = PO::pack2(v[0], v[1]);
+    r.y = PO::pack2(v[2], v[3]);
+    r.z = PO::pack2(v[4], v[5]);
+    r.w = PO::pack2(v[6], v[7]);
     return r;
 }
 
 // WB: write the activated tensor back in place.  POOL && !WB: only the pooled tensor is produced - the full-resolution
 // tensor stays raw and every consumer applies scale/shift + Mish while it loads (conv_zreg.hip's staging, the
 // transposed conv below, the final 1x1x1 conv)
-template <class P, bool POOL, bool WB, bool NT = false>
+// PW: format of the written-back tensor, PQ: format of the pooled tensor (both P except at the format seam of the mixed mode)
+template <class P, bool POOL, bool WB, bool NT = false, class PW = P, class PQ = P>
 __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C,
                                                         int D, int H, int W, uint4* __restrict__ pooled) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -687,7 +692,7 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
     uint4* p = x + ((long long)n * (C / 8) + c8) * vox;
     if (!POOL) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vox; i += (long long)gridDim.x * 256)
-            dlv_st16<NT>(p + i, norm_mish8<P>(dlv_ld16<NT>(p + i), sc, sh, nullptr));
+            dlv_st16<NT>(p + i, norm_mish8<P, PW>(dlv_ld16<NT>(p + i), sc, sh, nullptr));
     } else {
         const int d2 = D / 2, h2 = H / 2, w2 = W / 2;
         const long long pv = (long long)d2 * h2 * w2;
@@ -704,17 +709,17 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
                     const long long o = ((long long)(2 * zz + a) * H + (2 * yy + b)) * W + 2 * xx;
                     // (default cache policy here: a wave's two loads / stores each touch every other 16 bytes of the same lines -
                     // with `nt` the second one misses again: 1060 -> 1340 us per forward)
-                    const uint4 r0 = norm_mish8<P>(p[o], sc, sh, mx), r1 = norm_mish8<P>(p[o + 1], sc, sh, mx);
+                    const uint4 r0 = norm_mish8<P, PW>(p[o], sc, sh, mx), r1 = norm_mish8<P, PW>(p[o + 1], sc, sh, mx);
                     if (WB) {
                         p[o] = r0;
                         p[o + 1] = r1;
                     }
                 }
             uint4 r;
-            r.x = P::pack2(mx[0], mx[1]);
-            r.y = P::pack2(mx[2], mx[3]);
-            r.z = P::pack2(mx[4], mx[5]);
-            r.w = P::pack2(mx[6], mx[7]);
+            r.x = PQ::pack2(mx[0], mx[1]);
+            r.y = PQ::pack2(mx[2], mx[3]);
+            r.z = PQ::pack2(mx[4], mx[5]);
+            r.w = PQ::pack2(mx[6], mx[7]);
             q[i] = r;
         }
     }
@@ -725,7 +730,7 @@ __global__ void __launch_bounds__(256) norm_mish_kernel(uint4* __restrict__ x, c
 // every other 16 bytes per instruction and needs the lines to survive in cache between its two loads), so the non-temporal policy
 // applies; the x pair is reduced with one DPP max per value, even lanes store the pooled voxel.  Same values bit for bit (max and
 // the 16-bit rounding commute).
-template <class P, bool WB, bool NT>
+template <class P, bool WB, bool NT, class PQ = P>
 __global__ void __launch_bounds__(256) norm_mish_pool_rows_kernel(uint4* __restrict__ x, const float2* __restrict__ ss, int C, int D, int H,
                                                                   int W, uint4* __restrict__ pooled) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -760,10 +765,10 @@ __global__ void __launch_bounds__(256) norm_mish_pool_rows_kernel(uint4* __restr
             mx[k] = fmaxf(mx[k], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx[k]), 0xB1, 0xf, 0xf, true)));
         if (!(lane & 1)) {
             uint4 r;
-            r.x = P::pack2(mx[0], mx[1]);
-            r.y = P::pack2(mx[2], mx[3]);
-            r.z = P::pack2(mx[4], mx[5]);
-            r.w = P::pack2(mx[6], mx[7]);
+            r.x = PQ::pack2(mx[0], mx[1]);
+            r.y = PQ::pack2(mx[2], mx[3]);
+            r.z = PQ::pack2(mx[4], mx[5]);
+            r.w = PQ::pack2(mx[6], mx[7]);
             dlv_st16<NT>(q + ((long long)zz * h2 + yy) * w2 + xs * 32 + (lane >> 1), r);
         }
     }
@@ -1233,6 +1238,13 @@ const uint16_t* wpack(const DlvConvLayer& L) { return P::IS_F16 ? L.w_f16 : L.w_
 template <class P>
 const uint16_t* wpack(const DlvDeconvLayer& L) { return P::IS_F16 ? L.w_f16 : L.w_bf16; }
 
+// a tensor of the forward: chunk-planar data + the scale/shift it still awaits (nullptr: final values)
+struct Act16 {
+    uint4* p;
+    int C;
+    const float2* ss;
+};
+
 template <class P>
 struct Net16 {
     dlv_ctx* ctx;
@@ -1243,12 +1255,7 @@ struct Net16 {
     float2* ss_of(int li) const { return ss_base + (size_t)li * B * 256; }
     static size_t ss_bytes(int B) { return (size_t)DLV_N_CONV * B * 256 * sizeof(float2); }
 
-    // a tensor of the forward: chunk-planar data + the scale/shift it still awaits (nullptr: final values)
-    struct Act {
-        uint4* p;
-        int C;
-        const float2* ss;
-    };
+    using Act = Act16;
 
     int grid1d(long long n) const { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
 
@@ -1268,10 +1275,12 @@ struct Net16 {
         static const int level_of[DLV_N_CONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
         return ((fuse_levels >> level_of[li]) & 1) && c1 == 32 && zreg_runs(li, c1, c2, d);
     }
-    // InstanceNorm + Mish in place (the tensor becomes final)
+    // InstanceNorm + Mish in place (the tensor becomes final); PW: the format the activated tensor is written in (P, except
+    // where the mixed mode hands a bf16 level-1 tensor to the fp16 level 0)
+    template <class PW = P>
     int materialise(Act& t, Dims d) {
         if (!t.ss) return DLV_OK;
-        DLV_TRY(norm_mish(t.p, t.C, d, nullptr, t.ss, true));
+        DLV_TRY((norm_mish<PW, P>(t.p, t.C, d, nullptr, t.ss, true)));
         t.ss = nullptr;
         return DLV_OK;
     }
@@ -1433,6 +1442,8 @@ struct Net16 {
 
     // InstanceNorm apply + Mish (+ MaxPool into `pooled`); writeback = false (pool only): x stays raw for consumers that
     // activate while loading
+    // PW / PQ: formats of the written-back and of the pooled tensor (norm_mish_kernel)
+    template <class PW = P, class PQ = P>
     int norm_mish(uint4* x, int C, Dims d, uint4* pooled, const float2* ss, bool writeback) {
         const long long work = pooled ? d.vox() / 8 : d.vox();
         // a tensor far beyond L2 + MALL is streamed with the non-temporal policy and two grid-stride iterations per thread
@@ -1440,22 +1451,24 @@ struct Net16 {
         // keep the default policy - their tensors are still on chip when the consumer starts
         const bool nt = (double)d.vox() * B * C * 2 > 768.0 * (1 << 20);
         dim3 grid(std::max(1, std::min(grid1d(work), nt && !pooled ? 4096 : 2048)), C / 8, B);
-        DlvProf pr(ctx, pooled ? (writeback ? (P::IS_F16 ? "norm_mish_pool_f16" : "norm_mish_pool_bf16") : (P::IS_F16 ? "pool_act_f16" : "pool_act_bf16"))
-                               : (P::IS_F16 ? "norm_mish_f16" : "norm_mish_bf16"), 0.0,
+        constexpr bool seam = !std::is_same<PW, P>::value || !std::is_same<PQ, P>::value;  // (the mixed mode's format change)
+        DlvProf pr(ctx, pooled ? (writeback ? (P::IS_F16 ? (seam ? "norm_mish_pool_f16_to_bf16" : "norm_mish_pool_f16") : "norm_mish_pool_bf16")
+                                            : (P::IS_F16 ? "pool_act_f16" : "pool_act_bf16"))
+                               : (P::IS_F16 ? "norm_mish_f16" : (seam ? "norm_mish_bf16_to_f16" : "norm_mish_bf16")), 0.0,
                    (double)d.vox() * B * C * 2 * (writeback ? 2 : 1) + (pooled ? (double)d.vox() / 8 * B * C * 2 : 0.0));
 #define DLV_NM_LAUNCH(POOL_, WB_)                                                                                                  \
     do {                                                                                                                           \
         if (nt)                                                                                                                    \
-            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, true>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
+            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, true, PW, PQ>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
         else                                                                                                                       \
-            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, false>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
+            hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, false, PW, PQ>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
     } while (0)
         static const bool pool_rows_off = getenv("DLV_POOL_ROWS_OFF") != nullptr;  // A/B + tests: the pooled-voxel-per-thread kernel everywhere
         if (pooled && d.W % 64 == 0 && !pool_rows_off) {
             const long long items = (long long)(d.D / 2) * (d.H / 2) * (d.W / 64);
             dim3 g2((unsigned)std::max<long long>(1, std::min<long long>((items + 3) / 4, 4096)), C / 8, B);  // (one item per wave: 4 / 8 / 16 items per workgroup 902 / 914 / 939 us)
 #define DLV_NP_LAUNCH(WB_, NT_) \
-    hipLaunchKernelGGL((norm_mish_pool_rows_kernel<P, WB_, NT_>), g2, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled)
+    hipLaunchKernelGGL((norm_mish_pool_rows_kernel<P, WB_, NT_, PQ>), g2, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled)
             if (writeback && nt) DLV_NP_LAUNCH(true, true);
             else if (writeback) DLV_NP_LAUNCH(true, false);
             else if (nt) DLV_NP_LAUNCH(false, true);
@@ -1534,7 +1547,12 @@ struct Net16 {
 
 // the whole forward; the stem reads either xf (fp32 patches) or the uint16 volume windows, the final
 // layer writes either logits or blends into acc
-template <class P>
+// P0: the format of level 0 (full resolution: stem, conv_0, upcat_1, final conv), PD: of levels 1-4.  P0 = PD: one format
+// throughout (fp16 / bf16 everywhere); P0 = fp16 with PD = bf16 is the mixed mode DLV_PREC_BF16 stands for (DESIGN section 5:
+// the 8 bits of bf16 are lost at full resolution - fp16 there lifts the margin-free mask IoU from 0.998 to 0.9994).  The
+// format changes in two normalisation passes: the pooling pass 0 -> 1 (raw fp16 in, pooled bf16 out) and the pass that
+// activates the level-1 decoder output for upcat_1 (raw bf16 in, activated fp16 out).
+template <class P0, class PD = P0>
 int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int flip_dim,
                  float scale, float* logits, float* acc, int B, int d, int h, int w) {
     const int* f = ctx->features;
@@ -1558,9 +1576,12 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
     const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
     char* sbase;
-    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + Net16<P>::ss_bytes(B) + 256, (void**)&sbase));
-    Net16<P> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};
-    using Act = typename Net16<P>::Act;
+    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + Net16<P0>::ss_bytes(B) + 256, (void**)&sbase));
+    Net16<P0> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};  // level 0
+    Net16<PD> netd{ctx, B, net.partials, pfloats, net.ss_base};                                                // levels 1-4
+    constexpr bool mixed = !std::is_same<P0, PD>::value;
+    using P = P0;
+    using Act = Act16;
     auto buf = [&](int l, int k) { return (uint4*)(base + offs[l][k]); };
     enum { A = 0, Bf = 1, S = 2, U = 3 };
 
@@ -1616,14 +1637,15 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         const int li_cat = 18 - 2 * l;  // upcat conv that takes skip[l-1]: 16, 14, 12, 10
         const int c_up = ctx->deconv[4 - l].cout;
         const bool keep_raw = net.fuses_first_input(li_cat, up.C, c_up, dm[l - 1]);
-        DLV_TRY(net.norm_mish(up.p, up.C, dm[l - 1], buf(l, A), up.ss, !keep_raw));
+        if (l == 1) DLV_TRY((net.template norm_mish<P0, PD>(up.p, up.C, dm[0], buf(1, A), up.ss, !keep_raw)));  // (level 0 stays P0, pooled: PD)
+        else DLV_TRY(netd.norm_mish(up.p, up.C, dm[l - 1], buf(l, A), up.ss, !keep_raw));
         if (!keep_raw) up.ss = nullptr;
         Act a{buf(l, A), encC[l - 1], nullptr};
         Act b{buf(l, Bf), encC[l], nullptr};
-        DLV_TRY(net.conv(2 * l, a, nullptr, b.p, dm[l]));
+        DLV_TRY(netd.conv(2 * l, a, nullptr, b.p, dm[l]));
         b.ss = net.ss_of(2 * l);
         Act s{buf(l, S), encC[l], nullptr};
-        DLV_TRY(net.conv(2 * l + 1, b, nullptr, s.p, dm[l]));
+        DLV_TRY(netd.conv(2 * l + 1, b, nullptr, s.p, dm[l]));
         s.ss = net.ss_of(2 * l + 1);
         skip[l] = s;
     }
@@ -1633,6 +1655,20 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         const int l = 3 - j;
         const int li = 10 + 2 * j;
         Act b{buf(l, Bf), ctx->conv[li].cout, nullptr};
+        if (l >= 1) {
+            DLV_TRY(netd.deconv(j, cur, buf(l, U), dm[l + 1]));
+            Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
+            DLV_TRY(netd.conv(li, skip[l], &u, b.p, dm[l]));
+            b.ss = net.ss_of(li);
+            Act o{buf(l, A), ctx->conv[li + 1].cout, nullptr};
+            DLV_TRY(netd.conv(li + 1, b, nullptr, o.p, dm[l]));
+            o.ss = net.ss_of(li + 1);
+            cur = o;
+            continue;
+        }
+        // level 0.  Mixed mode: the level-1 output is activated here and WRITTEN in the level-0 format (one pass either way: the
+        // folded conv below needs the activated tensor, and the plain transposed conv then finds nothing left to activate)
+        if (mixed) DLV_TRY((netd.template materialise<P0>(cur, dm[1])));
         if (net.folds_up(li, skip[l].C, dm[l])) {
             // upcat_1: the transposed conv folded into the conv (upconv.hip): P from the activated coarse tensor, then the
             // 32-channel conv of the skip half with P as its addend - no up-sampled tensor, 8 coarse taps instead of 27 fine ones
@@ -1763,14 +1799,19 @@ int dlv_range_reset(dlv_ctx* ctx) {
 }
 
 // after everything of the pass / forward has been ordered behind the main stream: read the guard word back
-int dlv_range_check(dlv_ctx* ctx, bool f16) {
+int dlv_range_check(dlv_ctx* ctx, int fmt16) {
+    const bool f16 = fmt16 != 0;  // (the mixed mode: only its fp16 level 0 can leave the range)
     int words[1 + DLV_N_CONV] = {0};
     DLV_HIP(ctx, hipMemcpyAsync(words, ctx->range_flag, sizeof(words), hipMemcpyDeviceToHost, ctx->main_stream));
     DLV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
     const int flag = words[0];
     for (int i = 0; i < DLV_N_CONV; ++i) memcpy(&ctx->range_peak[i], &words[1 + i], sizeof(float));
     ctx->range_last = flag == 0 ? -1 : 100 - flag;
-    if (flag == 0) return DLV_OK;
+    if (flag == 0) {
+        ctx->range_seq = false;  // a pass came to its end: the recovery sequence (if any) is over
+        ctx->range_blind_layer = -1;
+        return DLV_OK;
+    }
     const int layer = 100 - flag;
     static const char* const names[DLV_N_CONV] = {"conv_0.conv_0", "conv_0.conv_1", "down_1.conv_0", "down_1.conv_1", "down_2.conv_0",
                                                   "down_2.conv_1", "down_3.conv_0", "down_3.conv_1", "down_4.conv_0", "down_4.conv_1",
@@ -1778,22 +1819,24 @@ int dlv_range_check(dlv_ctx* ctx, bool f16) {
                                                   "upcat_2.conv_1", "upcat_1.conv_0", "upcat_1.conv_1"};
     if (layer >= 0 && layer < DLV_N_CONV)
         return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: the InstanceNorm sums of conv block %d (%s) are not finite - a value of its input "
-                        "(the block before it or the transposed conv feeding it) left the format%s", f16 ? "fp16" : "bf16", layer, names[layer],
-                        f16 ? "; use dlv_unet_set_conv_shift on the producing block (dlv_range_report) or precision bf16 (8 exponent bits) for this checkpoint" : "");
+                        "(the block before it or the transposed conv feeding it) left the format%s", fmt16 == 2 ? "fp16 (level 0 of DLV_PREC_BF16)" : (f16 ? "fp16" : "bf16"), layer, names[layer],
+                        f16 ? "; use dlv_unet_set_conv_shift on the producing block (dlv_range_report) or DLV_PREC_BF16_ALL (8 exponent bits) for this checkpoint" : "");
     return dlv_fail(ctx, DLV_ERANGE, "%s range exceeded: non-finite logits (raw output of the last conv block, upcat_1.conv_1)%s",
-                    f16 ? "fp16" : "bf16", f16 ? "; use dlv_unet_set_conv_shift on upcat_1.conv_1 (dlv_range_report) or precision bf16 (8 exponent bits) for this checkpoint" : "");
+                    fmt16 == 2 ? "fp16 (level 0 of DLV_PREC_BF16)" : (f16 ? "fp16" : "bf16"), f16 ? "; use dlv_unet_set_conv_shift on upcat_1.conv_1 (dlv_range_report) or DLV_PREC_BF16_ALL (8 exponent bits) for this checkpoint" : "");
 }
 
-int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int f16) {
+int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, int d, int h, int w, int fmt16) {
     DLV_TRY(dlv_range_reset(ctx));
-    if (f16) DLV_TRY(forward_16<PF16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w));
+    if (fmt16 == 1) DLV_TRY(forward_16<PF16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w));
+    else if (fmt16 == 2) DLV_TRY((forward_16<PF16, PBf16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w)));
     else DLV_TRY(forward_16<PBf16>(ctx, x, nullptr, 0, 0, nullptr, -1, 1.f, logits, nullptr, B, d, h, w));
-    return dlv_range_check(ctx, f16 != 0);  // (dlv_unet_forward_dev is synchronous)
+    return dlv_range_check(ctx, fmt16);  // (dlv_unet_forward_dev is synchronous)
 }
 
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d, int h,
-                        int w, int flip_dim, float scale, float* acc, int f16) {
-    if (f16) return forward_16<PF16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
+                        int w, int flip_dim, float scale, float* acc, int fmt16) {
+    if (fmt16 == 1) return forward_16<PF16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
+    if (fmt16 == 2) return forward_16<PF16, PBf16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
     return forward_16<PBf16>(ctx, nullptr, vol, Yp, Xp, starts_dev, flip_dim, scale, nullptr, acc, B, d, h, w);
 }
 

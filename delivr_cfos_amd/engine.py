@@ -12,9 +12,12 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F16, PREC_F32, DelivrHipError
+from ._lib import PREC_BF16, PREC_BF16_ALL, PREC_F16, PREC_F32, DelivrHipError
 
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
+# "bf16": bf16 operands / storage at levels 1-4, fp16 at full resolution (include/delivr_hip.h DLV_PREC_BF16);
+# "bf16_all": bf16 at every level
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "bf16_all": PREC_BF16_ALL}
+RANGE_GUARDED = ("fp16", "f16", "bf16")  # formats with fp16 tensors: DLV_ERANGE is recoverable (range_guard.py)
 
 # checkpoint keys of the 18 conv blocks in forward order (include/delivr_hip.h)
 CONV_BLOCKS = (
@@ -202,33 +205,24 @@ class HipEngine:
             t = t.to(dtype)
         return t.to(self.device).contiguous()
 
-    def upload_volume(self, arr, z_lo: int = 0, z_hi: Optional[int] = None, chunk_bytes: int = 256 << 20):
-        """Host uint16 volume (numpy array or memmap, (..., Z, Y, X)) -> planes [z_lo, z_hi) in HBM, streamed through two
-        pinned staging buffers in z-chunks: no whole-volume pageable copy is made of a memmapped .npy (the reference
-        memmaps the file too, inference/inference.py:234) and a rank of a sharded run reads only the planes of its slab."""
-        torch = self.torch
-        a = arr
+    def upload_volume(self, arr, z_lo: int = 0, z_hi: Optional[int] = None, chunk_bytes: int = 64 << 20):
+        """Host uint16 volume (numpy array or memmap, (..., Z, Y, X)) -> planes [z_lo, z_hi) in HBM through the pinned staging
+        ring of hostio.upload: a memmapped .npy is read with parallel preads straight into pinned memory (no whole-volume
+        pageable copy; the reference memmaps the file too, inference/inference.py:234), the copy engine moves the previous
+        chunk meanwhile, and a rank of a sharded run reads only the planes of its slab."""
+        from . import hostio
+
+        a = arr if isinstance(arr, np.ndarray) else np.asarray(arr)
         lead = a.shape[:-3]
         if any(int(v) != 1 for v in lead):
             raise ValueError("one volume, one channel expected")
-        view = a.reshape(a.shape[-3:]) if isinstance(a, np.ndarray) else np.asarray(a).reshape(a.shape[-3:])
+        if a.dtype != np.uint16:
+            raise TypeError(f"upload_volume: uint16 volume expected, got {a.dtype}")
+        view = a.reshape(a.shape[-3:])
         Z, Y, X = (int(v) for v in view.shape)
         z_hi = Z if z_hi is None else int(z_hi)
-        out = torch.empty(tuple(int(v) for v in lead) + (z_hi - z_lo, Y, X), dtype=torch.uint16, device=self.device)
-        flat = out.reshape(z_hi - z_lo, Y, X)
-        per = max(1, int(chunk_bytes // max(Y * X * 2, 1)))
-        stage = [torch.empty((per, Y, X), dtype=torch.uint16).pin_memory() for _ in range(2)]
-        evs = [torch.cuda.Event(), torch.cuda.Event()]
-        with torch.cuda.device(self.device):
-            for i, z0 in enumerate(range(z_lo, z_hi, per)):
-                z1 = min(z0 + per, z_hi)
-                b = i & 1
-                if i >= 2:
-                    evs[b].synchronize()  # the copy that read this staging buffer has finished
-                np.copyto(stage[b][: z1 - z0].numpy(), view[z0:z1], casting="no")
-                flat[z0 - z_lo: z1 - z_lo].copy_(stage[b][: z1 - z0], non_blocking=True)
-                evs[b].record()
-            torch.cuda.synchronize(self.device)
+        out = self.torch.empty(tuple(int(v) for v in lead) + (z_hi - z_lo, Y, X), dtype=self.torch.uint16, device=self.device)
+        hostio.upload(self, view[z_lo:z_hi], out=out, chunk_bytes=chunk_bytes, what="h2d_volume")
         return out
 
     # ---- weights -----------------------------------------------------------------------------------
@@ -320,7 +314,8 @@ class HipEngine:
         else:
             dco = [self.features[4] // 2, self.features[3] // 2, self.features[2] // 2, self.features[1]]
             out = torch.empty((B, dco[index], 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=self.device)
-        self._check(self.lib.dlv_debug_set_format(self.ctx, PRECISIONS[precision]))
+        # (one layer runs in ONE format: "bf16" here is bf16 proper)
+        self._check(self.lib.dlv_debug_set_format(self.ctx, PREC_F16 if precision in ("fp16", "f16") else PREC_BF16_ALL))
         self._enter()
         self._check(self.lib.dlv_debug_layer_bf16(
             self.ctx, kind, index, self._dev(in1, torch.float32, "in1"), int(c1),

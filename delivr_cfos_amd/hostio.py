@@ -1,0 +1,267 @@
+"""File <-> HBM transfers of the step boundaries: the reference's steps hand volumes over as .npy files
+(masked_nifti.npy in, inference/inference.py:234; binaries.npy out, :312-318; the label volume and its re-read,
+count_blobs.py:45-65,86-88), so a 5 s GPU pass sits between an 8.6 GB read and a 4.3 GB write, and 20 ms of labelling
+between a 4.3 GB read and a 17 GB write.  Everything here is a chunked pipeline through a small ring of PINNED staging
+buffers: reader / writer threads move file bytes with pread / pwrite straight from / into the pinned memory (both
+release the GIL: the threads run side by side), the copy engine moves the previous chunk in the meantime, and no
+whole-volume pageable copy is ever made.
+
+    upload(engine, src, ...)        file / memmap / ndarray  -> tensor in HBM
+    download(engine, tensor, dst)   tensor in HBM            -> bytes of a file (at an offset) / ndarray
+    create_npy(path, dtype, shape)  an empty .npy with numpy's own header (what np.save / open_memmap write) -> offset
+
+`last_transfer` holds the figures of the most recent call of each kind (bytes, seconds, GB/s) - bench.py reports them.
+"""
+from __future__ import annotations
+
+import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor, wait
+from typing import Optional
+
+import numpy as np
+
+CHUNK_BYTES = 64 << 20
+N_STAGE = 4
+_MAX_IO = 1 << 30  # (one pread / pwrite moves at most 0x7ffff000 bytes on Linux)
+
+last_transfer = {}
+_pool_lock = threading.Lock()
+_pool = None
+
+
+def io_threads() -> int:
+    """threads that move file bytes: DLV_IO_THREADS, else 16 (fewer on small hosts)"""
+    env = os.environ.get("DLV_IO_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(2, min(16, (os.cpu_count() or 2)))
+
+
+def _executor() -> ThreadPoolExecutor:
+    global _pool
+    with _pool_lock:
+        if _pool is None or _pool._max_workers != io_threads():
+            _pool = ThreadPoolExecutor(max_workers=io_threads(), thread_name_prefix="dlv-io")
+        return _pool
+
+
+class _Stage:
+    """a ring of pinned byte buffers kept by the engine (hipHostMalloc of 256 MB is not free: allocated once)"""
+
+    def __init__(self, torch, n: int, nbytes: int):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(n)]
+        self.views = [memoryview(b.numpy()) for b in self.bufs]
+        self.nbytes = nbytes
+
+
+def _stage_of(engine, chunk_bytes: int) -> _Stage:
+    st = getattr(engine, "_io_stage", None)
+    if st is None or st.nbytes < chunk_bytes:
+        st = _Stage(engine.torch, N_STAGE, chunk_bytes)
+        engine._io_stage = st
+    return st
+
+
+def _pread_full(fd: int, mv: memoryview, off: int) -> None:
+    done, n = 0, len(mv)
+    while done < n:
+        got = os.preadv(fd, [mv[done:min(n, done + _MAX_IO)]], off + done)
+        if got <= 0:
+            raise EOFError(f"short read: {n - done} bytes missing at offset {off + done}")
+        done += got
+
+
+def _pwrite_full(fd: int, mv: memoryview, off: int) -> None:
+    done, n = 0, len(mv)
+    while done < n:
+        done += os.pwrite(fd, mv[done:min(n, done + _MAX_IO)], off + done)
+
+
+def _split(n: int, parts: int, align: int = 1 << 20):
+    """[0, n) in up to `parts` pieces whose cuts sit at multiples of `align`"""
+    per = -(-n // parts)
+    per = -(-per // align) * align
+    return [(s, min(s + per, n)) for s in range(0, n, per)]
+
+
+def _file_backing(src):
+    """(path, byte offset of element 0) when `src` is a C-contiguous np.memmap of a file region, else None"""
+    if isinstance(src, np.memmap) and src.flags.c_contiguous and getattr(src, "filename", None) is not None:
+        base = src
+        while isinstance(getattr(base, "base", None), np.memmap):  # views keep the mmap's own offset: walk to the owner
+            base = base.base
+        start = src.__array_interface__["data"][0] - base.__array_interface__["data"][0]
+        return str(src.filename), int(base.offset) + int(start)
+    return None
+
+
+def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk_bytes: int = CHUNK_BYTES, what: str = "h2d"):
+    """`src` -> tensor in HBM (a new one, or the contiguous tensor `out`).
+    src: a path (with `dtype`, `shape`, byte `offset` of the payload), a C-contiguous np.memmap (read through its file),
+    or any ndarray (copied by the reader threads).  dtype: numpy dtype of the elements."""
+    torch = engine.torch
+    fd, arr = None, None
+    if isinstance(src, (str, os.PathLike)):
+        path, off0 = os.fspath(src), int(offset)
+        dt = np.dtype(dtype)
+        shape = tuple(int(v) for v in shape)
+    else:
+        a = src if isinstance(src, np.ndarray) else np.asarray(src)
+        dt, shape = a.dtype, tuple(int(v) for v in a.shape)
+        fb = _file_backing(a)
+        if fb is not None:
+            path, off0 = fb
+        else:
+            path, arr = None, np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    tdt = {"uint8": torch.uint8, "uint16": torch.uint16, "int16": torch.int16, "int32": torch.int32, "uint32": torch.int32,
+           "float32": torch.float32, "float16": torch.float16}[dt.name]
+    if out is None:
+        out = torch.empty(shape, dtype=tdt, device=engine.device)
+    elif not out.is_contiguous() or out.numel() * out.element_size() != nbytes:
+        raise ValueError("upload: `out` must be a contiguous tensor of the source's size")
+    if nbytes == 0:
+        return out
+    dst = out.reshape(-1).view(torch.uint8)
+    st = _stage_of(engine, chunk_bytes)
+    pool, nthr = _executor(), io_threads()
+    t0 = time.perf_counter()
+    if path is not None:
+        fd = os.open(path, os.O_RDONLY)
+    try:
+        copy_stream = torch.cuda.Stream(device=engine.device)
+        evs = [torch.cuda.Event() for _ in range(N_STAGE)]
+        pending = []  # (buffer index, byte range, futures) whose reads are in flight
+
+        def fill(b, lo, hi):
+            mv = st.views[b]
+            if fd is not None:
+                return [pool.submit(_pread_full, fd, mv[s:e], off0 + lo + s) for s, e in _split(hi - lo, nthr)]
+            return [pool.submit(_copy_bytes, mv[s:e], arr[lo + s:lo + e]) for s, e in _split(hi - lo, nthr)]
+
+        def finish(b, lo, hi, futs):
+            for f in futs:
+                f.result()
+            with torch.cuda.stream(copy_stream):
+                dst[lo:hi].copy_(st.bufs[b][: hi - lo], non_blocking=True)
+                evs[b].record(copy_stream)
+
+        with torch.cuda.device(engine.device):
+            for i, lo in enumerate(range(0, nbytes, chunk_bytes)):
+                hi, b = min(lo + chunk_bytes, nbytes), i % N_STAGE
+                if i >= N_STAGE:
+                    evs[b].synchronize()  # the H2D copy that read this buffer has finished
+                pending.append((b, lo, hi, fill(b, lo, hi)))
+                if len(pending) >= 2:  # reads of chunk i run while chunk i-1 is handed to the copy engine
+                    finish(*pending.pop(0))
+            while pending:
+                finish(*pending.pop(0))
+            copy_stream.synchronize()
+    finally:
+        if fd is not None:
+            os.close(fd)
+    dt_s = time.perf_counter() - t0
+    last_transfer[what] = {"bytes": nbytes, "s": dt_s, "GBps": nbytes / dt_s / 1e9, "threads": nthr,
+                           "source": "file (pread into pinned staging)" if fd is not None else "host array"}
+    return out
+
+
+def _copy_bytes(dst_mv: memoryview, src_arr) -> None:
+    np.copyto(np.frombuffer(dst_mv, dtype=np.uint8), src_arr, casting="no")
+
+
+def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTES, what: str = "d2h", sync_file: bool = False):
+    """contiguous tensor in HBM -> `dst`: a path (bytes written at `offset`; the file must exist, e.g. from create_npy), an
+    open file descriptor (int), or a C-contiguous writeable ndarray of the same byte size."""
+    torch = engine.torch
+    if not tensor.is_contiguous():
+        raise ValueError("download: the tensor must be contiguous")
+    src = tensor.reshape(-1).view(torch.uint8)
+    nbytes = int(src.numel())
+    fd, own_fd, arr = None, False, None
+    if isinstance(dst, (str, os.PathLike)):
+        fd, own_fd = os.open(os.fspath(dst), os.O_WRONLY), True
+    elif isinstance(dst, int):
+        fd = dst
+    else:
+        if not (isinstance(dst, np.ndarray) and dst.flags.c_contiguous and dst.flags.writeable and dst.nbytes == nbytes):
+            raise ValueError("download: destination array must be C-contiguous, writeable and of the tensor's size")
+        arr = dst.reshape(-1).view(np.uint8)
+    if nbytes == 0:
+        if own_fd:
+            os.close(fd)
+        return
+    st = _stage_of(engine, chunk_bytes)
+    pool, nthr = _executor(), io_threads()
+    t0 = time.perf_counter()
+    try:
+        engine.sync()
+        copy_stream = torch.cuda.Stream(device=engine.device)
+        copy_stream.wait_stream(torch.cuda.current_stream(engine.device))
+        evs = [torch.cuda.Event() for _ in range(N_STAGE)]
+        writes = [[] for _ in range(N_STAGE)]
+        inflight = []  # (buffer, lo, hi) whose D2H copy has been queued
+
+        def drain(b, lo, hi):
+            evs[b].synchronize()
+            mv = st.views[b]
+            if fd is not None:
+                writes[b] = [pool.submit(_pwrite_full, fd, mv[s:e], offset + lo + s) for s, e in _split(hi - lo, nthr)]
+            else:
+                writes[b] = [pool.submit(_copy_out, arr[lo + s:lo + e], mv[s:e]) for s, e in _split(hi - lo, nthr)]
+
+        with torch.cuda.device(engine.device):
+            for i, lo in enumerate(range(0, nbytes, chunk_bytes)):
+                hi, b = min(lo + chunk_bytes, nbytes), i % N_STAGE
+                for f in writes[b]:
+                    f.result()  # the writers have emptied this buffer
+                writes[b] = []
+                with torch.cuda.stream(copy_stream):
+                    st.bufs[b][: hi - lo].copy_(src[lo:hi], non_blocking=True)
+                    evs[b].record(copy_stream)
+                inflight.append((b, lo, hi))
+                if len(inflight) >= 2:  # chunk i is on the copy engine while chunk i-1 goes to the writers
+                    drain(*inflight.pop(0))
+            while inflight:
+                drain(*inflight.pop(0))
+            for w in writes:
+                for f in w:
+                    f.result()
+        if fd is not None and sync_file:
+            os.fsync(fd)
+    finally:
+        if own_fd:
+            os.close(fd)
+    dt_s = time.perf_counter() - t0
+    last_transfer[what] = {"bytes": nbytes, "s": dt_s, "GBps": nbytes / dt_s / 1e9, "threads": nthr,
+                           "sink": "file (pwrite from pinned staging)" if fd is not None else "host array"}
+
+
+def _copy_out(dst_arr, src_mv: memoryview) -> None:
+    np.copyto(dst_arr, np.frombuffer(src_mv, dtype=np.uint8), casting="no")
+
+
+def create_npy(path: str, dtype, shape) -> int:
+    """An .npy file of this dtype / shape with numpy's own header and an unwritten payload of the right size (what
+    np.lib.format.open_memmap(mode="w+") leaves: the reference creates binaries.npy that way, inference/inference.py:312).
+    -> byte offset of the payload."""
+    mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.dtype(dtype), shape=tuple(int(v) for v in shape))
+    off = int(mm.offset)
+    del mm
+    return off
+
+
+def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: bool = False) -> None:
+    """np.save(path, tensor) without a host copy of the tensor: header by numpy, payload streamed from HBM.  `dtype`: the
+    numpy dtype the file declares (same item size as the tensor's: e.g. uint32 for labels held in an int32 tensor).
+    partial: write under `<path>.partial` and rename when complete (a killed run leaves no complete-looking file)."""
+    npdt = np.dtype(dtype) if dtype is not None else np.dtype(str(tensor.dtype).replace("torch.", ""))
+    if npdt.itemsize != tensor.element_size():
+        raise ValueError("save_npy: dtype must have the tensor's item size")
+    target = path + ".partial" if partial else path
+    off = create_npy(target, npdt, tuple(tensor.shape))
+    download(engine, tensor, target, offset=off, what=what)
+    if partial:
+        os.replace(target, path)

@@ -39,12 +39,10 @@ def cells_csv_text(stats: dict, n: int) -> str:
     ``,Blob,Coords,Size``; one row per label 1..N-1 (the reference's ``range(1, N)`` drops the last
     label); index column always 0; Coords = python repr of [z, y, x] floats, quoted by the CSV
     writer because it contains commas."""
-    cent = stats["centroids"]
-    counts = stats["voxel_counts"]
+    cent = np.asarray(stats["centroids"], dtype=np.float64)[1:max(int(n), 1)].tolist()  # (python floats: repr as pandas writes them)
+    counts = np.asarray(stats["voxel_counts"])[1:max(int(n), 1)].tolist()
     lines = [",Blob,Coords,Size"]
-    for i in range(1, int(n)):
-        coords = [float(cent[i][0]), float(cent[i][1]), float(cent[i][2])]
-        lines.append(f'0,{i},"{coords!r}",{int(counts[i])}')
+    lines.extend(f'0,{i},"{c!r}",{k}' for i, (c, k) in enumerate(zip(cent, counts), 1))
     return "\n".join(lines) + "\n"
 
 

@@ -13,6 +13,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from ..hostio import save_npy
 from ..hostlogic import arrayterator_zblock, padded_shape, pass_schedule
 from .._lib import DLV_ERANGE, DelivrHipError
 from ..range_guard import next_shifts, run_with_range_recovery
@@ -39,13 +40,11 @@ def create_nifti_seg(threshold, model_output, output_file, network_output_file, 
                           want_prob=network_output_file is not None)
     mask, prob = res if network_output_file is not None else (res, None)
     engine.sync()
-    out = np.lib.format.open_memmap(output_file, mode="w+", dtype=np.uint8, shape=(Z, Y, X))
-    out[...] = mask.cpu().numpy()
-    out.flush()
+    # the reference creates binaries.npy with open_memmap (:312) and fills it block by block; here numpy writes the same
+    # header and the payload streams out of HBM through pinned staging with parallel writers (hostio.py)
+    save_npy(engine, mask, output_file, np.uint8, what="d2h_mask")
     if network_output_file is not None:
-        act = np.lib.format.open_memmap(network_output_file, mode="w+", dtype=np.float32, shape=(Z, Y, X))
-        act[...] = prob.cpu().numpy()
-        act.flush()
+        save_npy(engine, prob, network_output_file, np.float32, what="d2h_prob")
     return mask
 
 
@@ -68,10 +67,17 @@ def run_inference(
     precision: Optional[str] = None,
     state_dict=None,
 ):
-    """Same parameters as the reference (:113-129) plus ``precision`` ("fp16" default / "bf16" / "fp32",
+    """Same parameters as the reference (:113-129) plus ``precision`` ("fp16" default / "bf16" / "bf16_all" / "fp32",
     also settings["mi355x"]["precision"]) and ``state_dict`` (use instead of reading
     ``model_weights``).  Returns "<abs output_folder>/<comment>"."""
+    import time
+
     import torch
+
+    marks = [("start", time.perf_counter())]  # wall-clock marks of this call -> run_inference.last_timings (bench.py: step2_wall_s)
+
+    def mark(name):
+        marks.append((name, time.perf_counter()))
 
     print(f"{datetime.datetime.now()} : Setting up inference parameters ")
     if settings is not None:
@@ -112,6 +118,7 @@ def run_inference(
 
         broadcast_weights(eng, dist, rank)  # ONE broadcast instead of DataParallel's per-forward replicate
     model.eval()
+    mark("model")
     # settings["mi355x"]["blend"] = "gaussian" makes the mode argument take effect (option; the reference's own call
     # passes mode="gaussian" too, but its inferer blends with constant weights: SURVEY D2)
     gaussian = bool(settings and settings.get("mi355x", {}).get("blend", "constant") == "gaussian")
@@ -159,7 +166,8 @@ def run_inference(
                   f"{budget / 2**30:.1f} GiB: streaming {n_slabs} Z-slabs through the device")
     resident = not sharded and stream_plan is None
     if resident:
-        dataset = eng.upload_volume(dataset_host[0, 0])  # chunked through pinned staging buffers
+        dataset = eng.upload_volume(dataset_host[0, 0])  # parallel preads -> pinned staging ring -> HBM (hostio.py)
+        mark("upload")
     output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device) if resident else None
     count_map = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device) if (need_count and resident) else None
     if need_count and cm_dtype == torch.uint8:
@@ -222,6 +230,7 @@ def run_inference(
         # range guard (DLV_ERANGE): this checkpoint drives a raw activation beyond fp16's 65504 - the library reports it instead
         # of painting a garbage mask; the block is rescaled (range_guard.py: fp16 keeps its 11 bits), bf16 is the last resort
         precision = run_with_range_recovery(eng, model.precision, run_passes, reset_sums)
+        mark("passes")
         # block-wise averaging + binarisation (reference :282-329) happen in one fused finalize pass
         print(f"{datetime.datetime.now()} : Creating binarized blob output")
         os.makedirs(binaries_path, exist_ok=True)
@@ -257,7 +266,7 @@ def run_inference(
                                                             slab=(slo, shi - slo), repeat=repeat), dataset, output_image, count_map)
                 eng.sync()
             except DelivrHipError as e:
-                if e.code != DLV_ERANGE or prec != "fp16":
+                if e.code != DLV_ERANGE or prec not in ("fp16", "bf16"):
                     raise
                 print(f"WARNING (rank {rank}): {e}")
                 return 1
@@ -274,16 +283,16 @@ def run_inference(
             if not rep[0].item():
                 break
             shifts = next_shifts(int(rep[1].item()), [float(v) for v in rep[2:].tolist()], eng.conv_shifts()) if attempt < 4 else None
-            if shifts is None or precision != "fp16":
-                if precision != "fp16":
-                    raise RuntimeError("unreachable: bf16 range errors are raised")
+            if shifts is None or precision not in ("fp16", "bf16"):
+                if precision not in ("fp16", "bf16"):
+                    raise RuntimeError("unreachable: bf16_all range errors are raised")
                 if rank == 0:
-                    print("WARNING: repeating the inference passes with bf16 operands on every rank")
-                precision = "bf16"
+                    print("WARNING: repeating the inference passes with bf16 operands at every level on every rank")
+                precision = "bf16_all"
             else:
                 for p, k in sorted(shifts.items()):
                     if rank == 0:
-                        print(f"WARNING: conv block {p}: storing its raw output scaled by 2^-{k} on every rank and repeating the passes in fp16")
+                        print(f"WARNING: conv block {p}: storing its raw output scaled by 2^-{k} on every rank and repeating the passes in {precision}")
                     eng.set_conv_shift(p, k)
             output_image.zero_()
             if count_map is not None:
@@ -308,14 +317,13 @@ def run_inference(
         if rank == 0:
             print(f"{datetime.datetime.now()} : Creating binarized blob output")
             os.makedirs(binaries_path, exist_ok=True)
-            out = np.lib.format.open_memmap(output_file, mode="w+", dtype=np.uint8, shape=(Z, Y, X))
-            out[...] = full.cpu().numpy()
-            out.flush()
+            save_npy(eng, full, output_file, np.uint8, what="d2h_mask")
             if save_activated:
                 os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
-                act = np.lib.format.open_memmap(network_output_file, mode="w+", dtype=np.float32, shape=(Z, Y, X))
-                act[...] = pfull.cpu().numpy()
-                act.flush()
+                save_npy(eng, pfull, network_output_file, np.float32, what="d2h_prob")
         dist.barrier()
+    mark("finalize+write")
+    run_inference.last_timings = {"total_s": marks[-1][1] - marks[0][1],
+                                  **{f"{b[0]}_s": b[1] - a[1] for a, b in zip(marks, marks[1:])}}
     print(f"{datetime.datetime.now()} : Blob Detection finished")
     return testing_session_path

@@ -10,7 +10,7 @@ from .engine import HipEngine
 class HipBasicUNet:
     """BasicUNet(spatial_dims=3, in_channels=1, out_channels=1, features=(32,32,64,128,256,32),
     act="mish", norm=instance) with its parameters resident in HBM.  ``precision``: "fp16" (MFMA on IEEE-half
-    operands, default: mask IoU >= 0.999 vs the fp32 path), "bf16" (MFMA, 3 % faster, 8 significant bits) or "fp32"
+    operands, default: mask IoU >= 0.999 vs the fp32 path), "bf16" (bf16 at levels 1-4, fp16 at full resolution), "bf16_all" (bf16 everywhere, 8 significant bits) or "fp32"
     (VALU parity mode)."""
 
     def __init__(self, device: int = 0, precision: str = "fp16", engine: Optional[HipEngine] = None):

@@ -255,10 +255,17 @@ def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]]
     (fp32 + MFMA-packed bf16 parameters, ~35 MB) with ONE broadcast."""
     import torch
 
-    meta = torch.zeros(6 + 18, dtype=torch.int64, device=engine.device)  # features + the per-block shifts the packs were made with
+    from ._lib import ABI_VERSION
+
+    # features + the per-block shifts the packs were made with + the sender's ABI version (the blob's layout is part of it: a
+    # rank on another build of the library must refuse the blob, not misread it)
+    meta = torch.zeros(6 + 18 + 1, dtype=torch.int64, device=engine.device)
     if rank == src:
-        meta[:] = torch.tensor(list(engine.features) + list(engine.conv_shifts()), dtype=torch.int64)
+        meta[:] = torch.tensor(list(engine.features) + list(engine.conv_shifts()) + [int(engine.lib.dlv_abi_version())], dtype=torch.int64)
     dist.broadcast(meta, src, group=group)
+    if int(meta[24].item()) != int(engine.lib.dlv_abi_version()) or int(meta[24].item()) != ABI_VERSION:
+        raise RuntimeError(f"broadcast_weights: rank {src} packed the weights with ABI version {int(meta[24].item())}, rank {rank} runs "
+                           f"libdelivr_hip ABI version {int(engine.lib.dlv_abi_version())} - the blob layouts may differ")
     if rank != src:
         engine.alloc_weight_blob([int(v) for v in meta[:6].tolist()])
     blob = engine.weight_blob()
@@ -266,7 +273,7 @@ def broadcast_weights(engine, dist, rank: int, features: Optional[Sequence[int]]
     dist.broadcast(blob, src, group=group)
     torch.cuda.synchronize(engine.device)
     if rank != src:
-        engine.note_conv_shifts([int(v) for v in meta[6:].tolist()])
+        engine.note_conv_shifts([int(v) for v in meta[6:24].tolist()])
 
 
 def gather_slabs(slab, plan: ShardPlan, rank: int, dist, out=None, dst: int = 0, group=None):

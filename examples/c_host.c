@@ -111,7 +111,7 @@ static int run_sharded(int n, int same_device, const dlv_unet_weights* w, const 
             break;
         }
         fprintf(stderr, "range guard: %s\n", dlv_comm_last_error(comm));
-        if (attempt == 4 || dlv_comm_range_recover(comm, &changed) != DLV_OK) p.precision = DLV_PREC_BF16;
+        if (attempt == 4 || dlv_comm_range_recover(comm, &changed) != DLV_OK) p.precision = DLV_PREC_BF16_ALL;
         else ++recoveries;
         for (r = 0; r < n; ++r)
             if (nz[r] > 0) {
@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
             break;
         }
         fprintf(stderr, "range guard: %s\n", dlv_last_error(ctx));
-        if (attempt == 4 || dlv_range_recover(ctx, &changed) != DLV_OK) p.precision = DLV_PREC_BF16;
+        if (attempt == 4 || dlv_range_recover(ctx, &changed) != DLV_OK) p.precision = DLV_PREC_BF16_ALL;
         else ++recoveries;
         CHECK(dlv_memset_dev(ctx, acc_dev, 0, nvox * 4));
     }

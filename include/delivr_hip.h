@@ -38,12 +38,18 @@ extern "C" {
 #define DLV_EUNSUP (-5)   /* shape not supported by the kernels */
 #define DLV_ERANGE (-6)   /* a 16-bit forward produced a non-finite value: the format's range was exceeded (fp16: use bf16) */
 
-#define DLV_ABI_VERSION 1
+/* 2 (round 6): DLV_PREC_BF16 is the mixed format, DLV_PREC_BF16_ALL added; dlv_set_cu_split / dlv_set_conv_algo gone, the range
+ * guard entry points (dlv_unet_set_conv_shift ... dlv_comm_range_recover) added and the weight blob re-laid out in round 5; the
+ * dlv_debug_* hooks moved to delivr_hip_diag.h.  A host built against version 1 must be rebuilt: dlv_abi_version() tells. */
+#define DLV_ABI_VERSION 2
 
 /* compute precision of the U-Net forward */
 #define DLV_PREC_F32 0  /* fp32 VALU kernels, NCDHW: parity mode (matches torch fp32 to ~1e-5) */
-#define DLV_PREC_BF16 1 /* bf16 MFMA implicit-GEMM kernels, fp32 accumulate + fp32 norm stats */
-#define DLV_PREC_F16 2  /* same kernels on IEEE-half operands (11 significant bits, same MFMA rate) */
+#define DLV_PREC_BF16 1 /* MFMA implicit-GEMM kernels, fp32 accumulate + fp32 norm statistics: bf16 operands and storage at levels
+                           1-4 of the U-Net, IEEE half at level 0 (full resolution), where bf16's 8 significant bits cost the mask
+                           its tolerance - the format changes in two normalisation passes */
+#define DLV_PREC_F16 2  /* the same kernels on IEEE-half operands everywhere (11 significant bits, same MFMA rate): the default */
+#define DLV_PREC_BF16_ALL 3 /* bf16 at every level (8 significant bits, fp32's exponent range): the last resort of the range guard */
 
 #define DLV_N_CONV 18
 #define DLV_N_DECONV 4
@@ -359,7 +365,8 @@ typedef struct dlv_prof_entry {
  * not affected.  Shifts are reset by dlv_unet_load / dlv_unet_alloc_blob; a rank that received its weights by broadcast sets
  * the same shifts itself.  dlv_range_report: the layer the last DLV_ERANGE named (-1: none; 18: the logits) - its INPUT
  * overflowed, i.e. the block(s) feeding it - and per conv block the largest |mean| + 8 sigma of its raw output (in stored
- * units, 0 where it stayed below 4096) seen since the last pass started: the hint for k.  inference/inference.py's
+ * units; 0: the block did not run) seen since the last pass started: above 4096 it is the hint for k, and it tells which blocks
+ * are too small to be moved at all.  inference/inference.py's
  * run_inference applies both before it falls back to bf16.  No reference counterpart (the reference network is fp32:
  * inference/sliding_window_inferer.py:205-229). */
 int dlv_unet_set_conv_shift(dlv_ctx* ctx, int layer, int shift);
@@ -369,9 +376,11 @@ int dlv_range_report(dlv_ctx* ctx, int* layer, float* peaks /* [DLV_N_CONV] or N
  * test compares them).  dlv_range_next_shifts is pure host logic: given the layer and peaks of dlv_range_report and the current
  * shifts it writes the next shifts to out[DLV_N_CONV] and returns how many blocks changed (0: nothing left to try; -1: null
  * argument) - the blocks feeding `layer` (MONAI BasicUNet's wiring, inference/inference.py:190-197) move so that |mean| + 8 sigma
- * of their stored output falls to <= 1024, or by 6 bits where no block reported a peak.  dlv_range_recover applies it to one
- * context after a DLV_ERANGE: DLV_OK = shifts changed, repeat the passes (zero the accumulators first); DLV_ERANGE = nothing left
- * (the caller's last resort is DLV_PREC_BF16); run_inference gives up after four such steps.  dlv_comm_range_recover does the
+ * of their stored output falls to <= 1024, or by 6 bits where no block reported a peak above 4096 (never a block whose peak would
+ * fall below 1).  dlv_range_recover applies it to one context after a DLV_ERANGE: DLV_OK = shifts changed (committed only after
+ * the weights were re-packed; the report is cleared), repeat the passes (zero the accumulators first); DLV_ERANGE = nothing left,
+ * or a 6-bit step on no evidence did not move the overflow - the shifts are back where the sequence started (the caller's last
+ * resort is DLV_PREC_BF16_ALL); run_inference gives up after four steps.  dlv_comm_range_recover does the
  * same for every rank of a dlv_comm with the largest layer / peaks any rank saw, so all ranks keep the same shifts. */
 int dlv_range_next_shifts(int layer, const float* peaks, const int* shifts, int* out /* [DLV_N_CONV] each */);
 int dlv_range_recover(dlv_ctx* ctx, int* n_changed /* or NULL */);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libdelivr_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding lacks {name}"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.dlv_abi_version() == 1
+    assert lib.dlv_abi_version() == 2
 
 
 def test_host_tiler_matches_reference_golden(golden_dir):

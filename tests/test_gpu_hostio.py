@@ -1,0 +1,125 @@
+"""hostio.py: the file <-> HBM pipelines of the step boundaries (masked_nifti.npy in, binaries.npy / labels out;
+reference inference/inference.py:234,312-318, count_blobs.py:45-65,86-88) move exactly the bytes np.load / np.save would."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+
+def test_file_backing_of_memmap_views(tmp_path):
+    """CPU: a slice of a memmapped .npy resolves to (file, byte offset of its first element)"""
+    from delivr_cfos_amd import hostio
+
+    a = np.arange(4 * 6 * 8, dtype=np.uint16).reshape(1, 1, 4, 6, 8)
+    path = str(tmp_path / "v.npy")
+    np.save(path, a)
+    mm = np.memmap(path, dtype=np.uint16, mode="r", shape=a.shape, offset=128)
+    f, off = hostio._file_backing(mm[0, 0])
+    assert f == path and off == 128
+    f, off = hostio._file_backing(mm[0, 0][1:3])
+    assert f == path and off == 128 + 1 * 6 * 8 * 2
+    assert hostio._file_backing(mm[0, 0][:, 1:3]) is None  # (not contiguous: copied by the reader threads instead)
+    assert hostio._file_backing(np.zeros(4)) is None
+    mm2 = np.load(path, mmap_mode="r")
+    f, off = hostio._file_backing(mm2[0, 0, 2:])
+    assert f == path and off == mm2.offset + 2 * 6 * 8 * 2
+    with open(path, "rb") as fh:
+        fh.seek(off)
+        assert np.array_equal(np.frombuffer(fh.read(2 * 6 * 8 * 2), dtype=np.uint16), a[0, 0, 2:].reshape(-1))
+
+
+def test_split_and_create_npy(tmp_path):
+    from delivr_cfos_amd import hostio
+
+    for n, parts in ((1, 16), (64 << 20, 16), ((64 << 20) + 5, 7), (3 << 20, 2)):
+        pieces = hostio._split(n, parts)
+        assert pieces[0][0] == 0 and pieces[-1][1] == n and len(pieces) <= parts
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    path = str(tmp_path / "x.npy")
+    off = hostio.create_npy(path, np.uint8, (3, 5, 7))
+    buf = io.BytesIO()
+    np.save(buf, np.zeros((3, 5, 7), np.uint8))
+    with open(path, "rb") as fh:
+        assert fh.read(off) == buf.getvalue()[:off]  # numpy's own header, byte for byte
+    assert os.path.getsize(path) == off + 3 * 5 * 7 and off == 128
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads):
+    import torch
+
+    from delivr_cfos_amd import hostio
+    from delivr_cfos_amd.engine import HipEngine
+
+    monkeypatch.setenv("DLV_IO_THREADS", threads)
+    eng = HipEngine(0)
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 65535, size=(1, 1, 37, 130, 257), dtype=np.uint16)  # (chunks of 3 MiB below: ragged last chunk)
+    path = str(tmp_path / "masked_nifti.npy")
+    np.save(path, vol)
+    mm = np.memmap(path, dtype=np.uint16, mode="r", shape=vol.shape, offset=128)
+    for src in (mm[0, 0], mm[0, 0][5:29], vol[0, 0], vol[0, 0][:, ::2]):
+        t = hostio.upload(eng, src, chunk_bytes=3 << 20)
+        assert t.dtype == torch.uint16 and np.array_equal(t.cpu().numpy(), np.asarray(src))
+    t = hostio.upload(eng, path, np.uint16, vol.shape, offset=128, chunk_bytes=1 << 20)
+    assert np.array_equal(t.cpu().numpy(), vol)
+    assert hostio.last_transfer["h2d"]["bytes"] == vol.nbytes
+    slab = eng.upload_volume(mm, 3, 30, chunk_bytes=1 << 20)  # the slab upload of a sharded rank
+    assert tuple(slab.shape) == (1, 1, 27, 130, 257) and np.array_equal(slab.cpu().numpy()[0, 0], vol[0, 0, 3:30])
+    # download: into an array, into a file region, as a whole .npy (header = np.save's)
+    dev = t[0, 0].contiguous()
+    host = np.empty(dev.shape, dtype=np.uint16)
+    hostio.download(eng, dev, host, chunk_bytes=3 << 20)
+    assert np.array_equal(host, vol[0, 0])
+    out = str(tmp_path / "out.npy")
+    hostio.save_npy(eng, dev, out, np.uint16, partial=True)
+    assert not os.path.exists(out + ".partial")
+    ref = str(tmp_path / "ref.npy")
+    np.save(ref, vol[0, 0])
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    lab = torch.arange(dev.numel(), dtype=torch.int32, device=eng.device).reshape(dev.shape)  # uint32 labels live in int32 tensors
+    hostio.save_npy(eng, lab, out, np.uint32)
+    back = np.load(out)
+    assert back.dtype == np.uint32 and np.array_equal(back.reshape(-1), np.arange(dev.numel(), dtype=np.uint32))
+    # a slab written into the middle of an existing file (the sharded count_blobs)
+    off = hostio.create_npy(out, np.uint16, vol.shape[2:])
+    hostio.download(eng, dev[10:20].contiguous(), out, offset=off + 10 * 130 * 257 * 2, chunk_bytes=1 << 20)
+    got = np.load(out)
+    assert np.array_equal(got[10:20], vol[0, 0, 10:20]) and not got[:10].any() and not got[20:].any()
+    with pytest.raises(ValueError):
+        hostio.download(eng, dev[:, ::2], host)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_count_blobs_writes_uint16_labels_for_few_components_and_reuses_them(tmp_path):
+    """fewer than 2^16 components: the label file is uint16 (cc3d's smallest fitting type), converted in HBM; a second call
+    finds the cached labelling and widens it in HBM for the statistics - same pickle, same CSV"""
+    import pickle
+
+    from delivr_cfos_amd.count_blobs import count_blobs
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(11)
+    mask = (rng.random((40, 64, 72)) < 0.02).astype(np.uint8)
+    d = tmp_path / "in" / "brain" / "binary_segmentations"
+    os.makedirs(d)
+    np.save(str(d / "binaries.npy"), mask)
+    settings = {"postprocessing": {"output_location": str(tmp_path / "post") + "/"}}
+    n = count_blobs(settings, str(tmp_path / "in"), 0, "brain", (1, 1) + mask.shape)
+    lab_ref, n_ref = orc.ccl26(mask)
+    assert n == n_ref and n < 2**16
+    post = str(tmp_path / "post")
+    labels = np.load(os.path.join(post, f"brain-{n}-cc3d.npy"))
+    assert labels.dtype == np.uint16 and np.array_equal(labels.astype(np.uint32), lab_ref)
+    assert not any(f.endswith(".partial") for f in os.listdir(post))
+    first = pickle.load(open(os.path.join(post, "brain-stats.pickle"), "rb"))
+    csv = open(os.path.join(post, f"{mask.shape}_brain.csv")).read()
+    os.remove(os.path.join(post, "brain-stats.pickle"))
+    assert count_blobs(settings, str(tmp_path / "in"), 0, "brain", (1, 1) + mask.shape) == n  # cached labels, fresh statistics
+    again = pickle.load(open(os.path.join(post, "brain-stats.pickle"), "rb"))
+    for k in first:
+        np.testing.assert_array_equal(first[k], again[k])
+    assert open(os.path.join(post, f"{mask.shape}_brain.csv")).read() == csv == orc.cells_csv_text(orc.cc_stats(lab_ref, n_ref), n_ref)

@@ -7,9 +7,11 @@ the LDS-weights variant of the 8^3 level and the pipeline lanes only occur at th
 Tolerances (north_star: "mask IoU >= 0.999 vs reference"):
     fp32 VALU path   max |logit - oracle| <= 5e-4 (logit std ~0.4), sign agreement >= 0.9995
     fp16 MFMA path   relative RMS <= 1e-2, sign agreement >= 0.999, mask IoU vs the ORACLE's mask >= 0.999
-    bf16 MFMA path   relative RMS <= 5e-2, sign agreement >= 0.99; mask IoU is REPORTED and asserted >= 0.995 only:
-                     bf16 (8 significant bits) does NOT meet the north_star tolerance on the margin-free logits of the
-                     seeded random weights - fp16 is the default format for that reason.
+    bf16 MFMA path   "bf16" = DLV_PREC_BF16: bf16 at levels 1-4 of the U-Net, fp16 at level 0 (full resolution, where bf16's 8
+                     significant bits were lost: oracle/bf16_budget.py) - relative RMS <= 5e-2, sign agreement >= 0.99, mask
+                     IoU >= 0.999 (north_star), also on the margin-free logits of the seeded random weights;
+                     "bf16_all" = bf16 at every level: mask IoU REPORTED and asserted >= 0.995 only - it does NOT meet the
+                     north_star tolerance on margin-free logits (strict expected failure below).
 The oracle needs ~1.7 s per 128^3 window on the GPU box's host cores, so the module computes the 27 windows of the crop once
 (and once more per flip of the TTA schedule for the 13-pass comparison).
 
@@ -55,7 +57,7 @@ def _stats(out, ref):
     return rel, agree, float(np.abs(out - ref).max())
 
 
-TOL = {"fp32": (1e-3, 0.9995), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.99)}
+TOL = {"fp32": (1e-3, 0.9995), "fp16": (1e-2, 0.999), "bf16": (5e-2, 0.99), "bf16_all": (5e-2, 0.99)}
 
 
 def _check(tag, prec, out, ref):
@@ -89,7 +91,7 @@ def crop(net):
     return {"vol": vol, "wins": np.asarray(wins), "logits": logits, "acc": acc, "cnt": cnt, "mask": mask, "cache": cache}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16", "bf16_all"])
 def test_c1_single_64cube_patch_vs_oracle(eng, net, prec):
     """BASELINE config 1 / SURVEY 8(d) C1: x = randn(1,1,64,64,64, seed 0)*100 + 500."""
     import torch
@@ -125,11 +127,14 @@ def test_default_window_96_96_64_vs_oracle(eng, net, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
-@pytest.mark.parametrize("roi,batch", [((80, 96, 112), 3), ((128, 64, 160), 2)])
+@pytest.mark.parametrize("roi,batch", [((80, 96, 112), 3), ((128, 64, 160), 2), ((96, 96, 64), 3), ((64, 64, 32), 5)])
 def test_uneven_windows_through_the_deep_level_kernels_vs_oracle(eng, net, prec, roi, batch):
     """Windows whose deep levels do not fill the tiles of conv_deep.hip (4 x 8 x 16 / 8 x 8 x 8 voxels): (80,96,112) -> 20x24x28,
-    10x12x14 (the 8-wide tile, partial in y and x), 5x6x7 (too small: the generic kernel); (128,64,160) -> 32x16x40, 16x8x20,
-    8x4x10 - several windows per launch (the persistent walk crosses item and window boundaries), each against the oracle."""
+    10x12x14 (the 8-wide tile, partial in y and x), 5x6x7; (128,64,160) -> 32x16x40, 16x8x20, 8x4x10; the reference's shipped
+    window (96,96,64) (config.json:24-28) -> 24x24x16, 12x12x8, 6x6x4; run_inference's own default (64,64,32)
+    (inference/inference.py:119) -> level 1 of 32x32x16 (rows of 16: the 32-channel layers leave the z-reg conv), 16x16x8, 8x8x4,
+    4x4x2 - several windows per launch (the persistent walk crosses item and window boundaries), each against the oracle; no
+    layer of a 16-bit forward of these windows falls back to the generic conv3_mfma kernel."""
     import torch
     from delivr_cfos_amd.synth import synth_volume_np
     from oracle import delivr_oracle as orc
@@ -145,6 +150,7 @@ def test_uneven_windows_through_the_deep_level_kernels_vs_oracle(eng, net, prec,
     ran = [k for k, e in eng.prof_report().items() if e["launches"]]
     assert st["n_windows"] == batch and st["n_skipped"] == 0
     assert any(k.startswith("conv3_deep_") for k in ran) and any(k.startswith("deconv2_deep_") for k in ran), ran
+    assert not any(k.startswith("conv3_mfma_") for k in ran), ran
     out = acc.cpu().numpy()
     for b in range(batch):
         sl = slice(b * roi[2], (b + 1) * roi[2])
@@ -215,7 +221,7 @@ def test_mask_iou_vs_oracle_256cube(eng, crop):
 
     v = eng.to_device(crop["vol"])
     ious = {}
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16", "bf16", "bf16_all"):
         acc = torch.zeros(CROP, dtype=torch.float32, device="cuda")
         cnt = torch.zeros(CROP, dtype=torch.uint8, device="cuda")
         st = eng.sw_infer(eng.make_sw_params(CROP, ROI, 0.5, None, 0, prec), v, acc, cnt)
@@ -234,7 +240,8 @@ def test_mask_iou_vs_oracle_256cube(eng, crop):
             assert abs(float(ref03.mean()) - fg) > 1e-3  # the other threshold really selects another mask
     assert ious["fp32"] >= 0.9995, ious
     assert ious["fp16"] >= 0.999, ious
-    assert ious["bf16"] >= 0.995, ious  # reported; bf16 does not meet 0.999 (module docstring)
+    assert ious["bf16"] >= 0.999, ious      # bf16 below an fp16 level 0: BASELINE configs[1]'s format meets north_star
+    assert ious["bf16_all"] >= 0.995, ious  # reported; bf16 at every level does not meet 0.999 (module docstring)
 
 
 def _hip_mask(eng, v, prec, tta, threshold=0.5):
@@ -251,7 +258,7 @@ def _hip_mask(eng, v, prec, tta, threshold=0.5):
     return acc, cnt, eng.finalize(acc, cnt, v, CROP, threshold, 30, 0).cpu().numpy()
 
 
-REF_ARITH_TOL = {"fp32": 0.9995, "fp16": 0.999, "bf16": 0.995}
+REF_ARITH_TOL = {"fp32": 0.9995, "fp16": 0.999, "bf16": 0.999, "bf16_all": 0.995}
 
 
 @pytest.mark.parametrize("tta", [False, True], ids=["1pass", "13pass_tta"])
@@ -272,7 +279,7 @@ def test_mask_vs_reference_accumulate_arithmetic(eng, crop, tta):
     print(f"oracle fp32-accumulate vs reference arithmetic ({'13 passes' if tta else '1 pass'}): {json.dumps(d5)}")
     assert d5["iou"] >= 0.9999, d5
     v = eng.to_device(crop["vol"])
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16", "bf16", "bf16_all"):
         acc, cnt, mask = _hip_mask(eng, v, prec, tta)
         assert np.array_equal(cnt.cpu().numpy(), ref["cnt"])  # 5+4+4 weighted counts == 13 passes of uint8 += 1
         rep = flip_report(mask, ref["mask"], ref["mean"])
@@ -283,13 +290,12 @@ def test_mask_vs_reference_accumulate_arithmetic(eng, crop, tta):
 
 
 
-@pytest.mark.xfail(strict=True, reason="bf16 (8 significant bits) does NOT meet the north_star tolerance (mask IoU >= 0.999 vs the "
-                                       "reference arithmetic) on the margin-free logits of seeded random weights: measured 0.998 / 0.9988. "
-                                       "It does on realistic logits (tests/test_gpu_trained_like.py: 0.9998); fp16 is the default format")
 @pytest.mark.parametrize("tta", [False, True], ids=["1pass", "13pass_tta"])
 def test_bf16_meets_the_north_star_tolerance_on_margin_free_logits(eng, crop, tta):
-    """The statement the suite makes about bf16 (BASELINE.json's configs name it): an EXPECTED failure, strict - should a
-    later build lift bf16 above 0.999 on this crop the test turns red until the claim is updated."""
+    """BASELINE.json's configs name bf16; north_star asks for mask IoU >= 0.999 vs the reference path.  Rounds 1-5 carried this
+    test as a strict expected failure (bf16 at every level: 0.998 / 0.9988).  The format "bf16" now keeps fp16 at level 0 -
+    the five full-resolution blocks where oracle/bf16_budget.py located the loss - and is held to the tolerance here, on the
+    worst case (margin-free logits of seeded random weights), for 1 pass and for the 13-pass schedule."""
     from oracle.parity import flip_report, reference_arithmetic
     from oracle import delivr_oracle as orc
 
@@ -297,6 +303,21 @@ def test_bf16_meets_the_north_star_tolerance_on_margin_free_logits(eng, crop, tt
     _acc, _cnt, mask = _hip_mask(eng, eng.to_device(crop["vol"]), "bf16", tta)
     rep = flip_report(mask, ref["mask"], ref["mean"])
     print(f"bf16 vs reference arithmetic ({'13 passes' if tta else '1 pass'}): IoU {rep['iou']:.5f}, {rep['flipped']} flipped voxels")
+    assert rep["iou"] >= 0.999, rep
+
+
+@pytest.mark.xfail(strict=True, reason="bf16 at EVERY level (8 significant bits at full resolution) does NOT meet the north_star tolerance "
+                                       "(mask IoU >= 0.999 vs the reference arithmetic) on the margin-free logits of seeded random weights: "
+                                       "measured 0.998 / 0.9988.  It is the range guard's last resort, not a format to choose")
+@pytest.mark.parametrize("tta", [False, True], ids=["1pass", "13pass_tta"])
+def test_bf16_at_every_level_misses_the_tolerance_on_margin_free_logits(eng, crop, tta):
+    from oracle.parity import flip_report, reference_arithmetic
+    from oracle import delivr_oracle as orc
+
+    ref = reference_arithmetic(orc, crop["vol"], ROI, crop["cache"], tta)
+    _acc, _cnt, mask = _hip_mask(eng, eng.to_device(crop["vol"]), "bf16_all", tta)
+    rep = flip_report(mask, ref["mask"], ref["mean"])
+    print(f"bf16_all vs reference arithmetic ({'13 passes' if tta else '1 pass'}): IoU {rep['iou']:.5f}, {rep['flipped']} flipped voxels")
     assert rep["iou"] >= 0.999, rep
 
 

@@ -52,7 +52,7 @@ def test_fp16_overflow_is_reported_not_painted(key, layer_next):
         eng.sync()
         return acc.cpu().numpy()
 
-    base16, base_bf = run(sd, "fp16"), run(sd, "bf16")
+    base16, base_bf = run(sd, "fp16"), run(sd, "bf16_all")
     big = _scaled(sd, key, 1.0e6)
     with pytest.raises(DelivrHipError) as ei:
         run(big, "fp16")
@@ -63,7 +63,7 @@ def test_fp16_overflow_is_reported_not_painted(key, layer_next):
         assert "non-finite logits" in str(ei.value), str(ei.value)
     print(str(ei.value))
     # bf16 holds the range: the same checkpoint runs, and - InstanceNorm being scale invariant - gives the unscaled result
-    got = run(big, "bf16")
+    got = run(big, "bf16_all")
     assert np.isfinite(got).all()
     rel = float(np.sqrt(np.mean((got - base_bf) ** 2)) / base_bf.std())
     print(f"bf16 on the scaled checkpoint vs bf16 on the original: rel rms {rel:.2e}")
