@@ -350,6 +350,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the stages either side of the pass (finalize, CCL-26 + statistics, "
                     "resamplers, one Gaussian-blend pass: BASELINE configs 4/5), which run by default at N=1")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-lane step that times the kernels alone")
+    ap.add_argument("--diag", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs: a kernel-selection switch of include/delivr_hip_diag.h (dlv_diag_set) for the benchmark's engine, e.g. "
+                         "--diag fuse_levels=1; recorded in config.diag")
     ap.add_argument("--no-step-walls", action="store_true", help="skip the file -> file wall-clock of run_inference and count_blobs "
                     "on this volume (N = 1; ~30 GiB of files on /dev/shm for c3)")
     args = ap.parse_args()
@@ -424,6 +427,9 @@ def main():
         return out
 
     eng = HipEngine(local_rank)
+    for kv in args.diag:
+        name, _, val = kv.partition("=")
+        eng.diag_set(name, int(val or 1))
     if args.weights == "trained" and not os.path.isfile(TRAINED_LIKE_FIXTURE):
         # (a different checkpoint means another mask, skip fraction and CCL workload under the same metric name)
         raise SystemExit(f"bench.py: the trained-like checkpoint {TRAINED_LIKE_FIXTURE} is missing; pass --weights random to "
@@ -636,7 +642,7 @@ def main():
                                if net_ms > 0 and world == 1 and lanes == 1 else None)
         return r, kernels
 
-    lanes_used = 1 if os.environ.get("DLV_ONE_LANE") else int(os.environ.get("DLV_LANES", "3"))
+    lanes_used = int(os.environ.get("DLV_LANES", "3"))
     roofline, kernels = roofline_of(prof, lanes_used, args.steps)
     # the timed region runs two overlapping lanes, which stretches every kernel's event-to-event time; one extra,
     # untimed step on a single lane gives the dominant kernel's own efficiency
@@ -763,7 +769,7 @@ def main():
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
             "patch_voxels_per_s": tile_vox * n_active * n_passes / (elapsed / args.steps),
             "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),
-            "lanes": int(os.environ.get("DLV_LANES", "3")),
+            "lanes": int(os.environ.get("DLV_LANES", "3")), "diag": args.diag or None,
             "mask_voxels": mask_voxels, "mask_checksum": mask_checksum,
             "parallelism": f"windows sharded in {world} contiguous Z-slabs, seam exchange p2p" if world > 1 else "1 GPU",
             "dist_backend": (dist.get_backend() + (" (forced at world size 1: DLV_BENCH_FORCE_DIST)" if world == 1 else "")) if dist_mode else None,

@@ -257,12 +257,9 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
 #ifdef DLV_DIAG  // the product library takes no kernel variant from the environment (diagnostic builds: make diag)
     if (const char* e = getenv("DLV_ZM_VARIANT")) ctx->zm_variant = atoi(e);
 #endif
-    ctx->no_zmarch = getenv("DLV_NO_ZMARCH") != nullptr;  // test switch: generic conv kernel everywhere
-    ctx->upconv_simple = getenv("DLV_UPCONV_SIMPLE") ? 1 : 0;
 #ifdef DLV_DIAG  // timing-only ablations (WRONG results): the diagnostic library only (make diag), never the product
     ctx->upconv_dbg = getenv("DLV_UPCONV_DBG") ? atoi(getenv("DLV_UPCONV_DBG")) : 0;
 #endif
-    ctx->fold_up = getenv("DLV_NO_UPCONV") ? 0 : 1;  // A/B + tests: the transposed conv + 64-channel conv of upcat_1 unfolded
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return DLV_EHIP;
@@ -282,7 +279,7 @@ int dlv_ctx_create(int device_id, void* stream, dlv_ctx** out) {
         (void)dlv_ctx_destroy(ctx);
         return DLV_ENOMEM;
     }
-    if (!getenv("DLV_ONE_LANE")) {
+    {
         bool ok = true;
         for (int k = 0; k < DLV_MAX_LANES - 1 && ok; ++k) ok = hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; k < DLV_MAX_LANES + 1 && ok; ++k) ok = hipEventCreateWithFlags(&ctx->ev_lane[k], hipEventDisableTiming) == hipSuccess;
@@ -580,6 +577,29 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
     if (precision == DLV_PREC_BF16 || precision == DLV_PREC_F16 || precision == DLV_PREC_BF16_ALL)
         return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, dlv_fmt16(precision));
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
+}
+
+// test / A-B switches (include/delivr_hip_diag.h): kernel selection per context, never from the environment
+int dlv_diag_set(dlv_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return DLV_EINVAL;
+    const std::string n(name);
+    if (n == "no_zmarch") ctx->no_zmarch = value != 0;
+    else if (n == "no_upconv") ctx->fold_up = value ? 0 : 1;
+    else if (n == "upconv_simple") ctx->upconv_simple = value ? 1 : 0;
+    else if (n == "fuse_levels") ctx->fuse_levels = value;
+    else if (n == "zreg_mask") ctx->zreg_mask = value;
+    else if (n == "deep_mask") ctx->deep_mask = value;
+    else if (n == "generic_ncb") ctx->generic_ncb = value;
+    else if (n == "zreg_dbg") ctx->zreg_dbg = value;
+    else if (n == "deep_small") ctx->deep_small = value;
+    else if (n == "pool_rows_off") ctx->pool_rows_off = value != 0;
+    else if (n == "erode_xy_split") ctx->erode_xy_split = value != 0;
+    else if (n == "erode_z_two_sweeps") ctx->erode_z_two_sweeps = value != 0;
+    else if (n == "ccl_simple") ctx->ccl_simple = value != 0;
+    else if (n == "resample_simple") ctx->resample_simple = value != 0;
+    else if (n == "resample_run16") ctx->resample_run16 = value != 0;
+    else return dlv_fail(ctx, DLV_EINVAL, "dlv_diag_set: unknown switch '%s'", name);
+    return DLV_OK;
 }
 
 int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant) {

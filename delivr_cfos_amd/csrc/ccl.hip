@@ -657,7 +657,7 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     // bytes: the byte mask is read once (1 B), its bit mask written once and scanned by five kernels (6/8 B), the labels are
     // written once (4 B)
     DlvProf pr(ctx, "ccl26", 0.0, (double)n * (1 + 0.75 + 4));
-    static const bool simple = getenv("DLV_CCL_SIMPLE") != nullptr;  // A/B: whole-volume relabel stores instead of memset + list
+    const bool simple = ctx->ccl_simple;  // A/B (dlv_diag_set): whole-volume relabel stores instead of memset + list
     DLV_HIP(ctx, hipMemsetAsync(list_n, 0, 4, ctx->stream));
     if (!simple) DLV_HIP(ctx, hipMemsetAsync(labels_dev, 0, (size_t)n * 4, ctx->stream));
     hipLaunchKernelGGL(ccl_init_kernel, dim3(gs), dim3(256), 0, ctx->stream, mask_dev, L, n, aligned, bm, list, list_n);

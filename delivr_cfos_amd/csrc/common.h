@@ -95,8 +95,8 @@ struct dlv_ctx {
     float blend_min = 0.f;
     float* blend_wsum = nullptr;
     int upconv_dbg = 0;         // DLV_UPCONV_DBG, diagnostic library only (timing, WRONG results): 1 = no stores, 2 = no halo loads
-    int upconv_simple = 0;      // DLV_UPCONV_SIMPLE=1: the one-tile-per-workgroup upconv kernel for every shape (A/B, tests)
-    int fold_up = 1;            // fold the transposed conv into the first conv of upcat_1 (upconv.hip); DLV_NO_UPCONV=1: A/B, the unfolded path
+    int upconv_simple = 0;      // dlv_diag_set "upconv_simple": the one-tile-per-workgroup upconv kernel for every shape (A/B, tests)
+    int fold_up = 1;            // fold the transposed conv into the first conv of upcat_1 (upconv.hip); dlv_diag_set "no_upconv": the unfolded path
     int zm_variant = 0;         // kernel variant of the z-march conv (0 = default; others: A/B and diagnostic builds)
     void* stamp_buf = nullptr;  // dlv_debug_stamps: timeline buffer of the diagnostic z-march build (DLV_ZM_VARIANT=30)
     int* range_flag = nullptr;  // device words: [0] 0, or 100 - (first layer whose InstanceNorm sums were not finite; 18 = logits);
@@ -119,6 +119,18 @@ struct dlv_ctx {
     // timing
     bool debug_f16 = false;  // format used by dlv_debug_layer_bf16
     bool no_zmarch = false;  // test switch: force the generic conv kernel
+    // Kernel-selection switches of tests and A/B runs (same results, other kernels).  The library takes NONE of them from the
+    // environment (a stray DLV_* in a user's shell must not change kernels): dlv_diag_set (include/delivr_hip_diag.h) sets them
+    // per context.  What the library does read from the environment: DLV_LANES, DLV_LAUNCH_LOG, DLV_RCCL_PATH / ROCM_PATH /
+    // DLV_FORCE_RCCL (transport), nothing else.
+    int fuse_levels = 0;     // bit l: raw tensors of level l are activated by the z-reg conv that stages them (no norm pass)
+    int zreg_mask = 3;       // 1 = Cin 32, 2 = Cin 64 layers may take the register-resident-weights conv
+    int deep_mask = 2;       // conv_deep.hip: bit 0 = the layers the LDS-weights z-march also takes, bit 1 = the others
+    int generic_ncb = 0;     // cout blocks per workgroup of the generic conv (0: its own choice)
+    int zreg_dbg = 0;        // 1 = edge-step code on every plane of the z-reg conv
+    int deep_small = 1;      // 0 = levels smaller than a tile of conv_deep.hip and its 32-output-channel layers take the generic conv (A/B)
+    bool pool_rows_off = false, erode_xy_split = false, erode_z_two_sweeps = false, ccl_simple = false;
+    bool resample_simple = false, resample_run16 = false;
     bool prof_on = false;
     std::vector<DlvProfSlot> prof_slots;
     std::vector<DlvProfPending> prof_pending;

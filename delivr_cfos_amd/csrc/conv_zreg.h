@@ -19,11 +19,13 @@ struct ZrArgs {
 ZR_DECLARE(dlv_zr_f16_c32_t8_a0);
 ZR_DECLARE(dlv_zr_f16_c32_t8_a1);
 ZR_DECLARE(dlv_zr_f16_c32_t16_a0);
+ZR_DECLARE(dlv_zr_f16_c32_t16_a1);
 ZR_DECLARE(dlv_zr_f16_c64_t8_a0);
 ZR_DECLARE(dlv_zr_f16_c64_t8_a1);
 ZR_DECLARE(dlv_zr_bf16_c32_t8_a0);
 ZR_DECLARE(dlv_zr_bf16_c32_t8_a1);
 ZR_DECLARE(dlv_zr_bf16_c32_t16_a0);
+ZR_DECLARE(dlv_zr_bf16_c32_t16_a1);
 ZR_DECLARE(dlv_zr_bf16_c64_t8_a0);
 ZR_DECLARE(dlv_zr_bf16_c64_t8_a1);
 // Cin 32 with an addend (the up half of an UpCat conv, upconv.hip)
@@ -31,3 +33,8 @@ ZR_DECLARE(dlv_zr_f16_c32_t8_add);
 ZR_DECLARE(dlv_zr_f16_c32_t16_add);
 ZR_DECLARE(dlv_zr_bf16_c32_t8_add);
 ZR_DECLARE(dlv_zr_bf16_c32_t16_add);
+// ... whose 32-channel input is still raw (scale/shift + Mish applied while staging)
+ZR_DECLARE(dlv_zr_f16_c32_t8_adda1);
+ZR_DECLARE(dlv_zr_f16_c32_t16_adda1);
+ZR_DECLARE(dlv_zr_bf16_c32_t8_adda1);
+ZR_DECLARE(dlv_zr_bf16_c32_t16_adda1);

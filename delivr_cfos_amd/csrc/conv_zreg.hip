@@ -57,7 +57,7 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
                           int* nparts, const void* addend) {
     if (!dlv_conv3_zreg_supports(cin, cout, c1, c2, W))
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: needs Cout %% 32 == 0, W >= 32 and inputs of 32, 32+32 or 64 channels");
-    if (addend && (cin != 32 || ss1 != nullptr)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: an addend needs Cin 32 and a final input");
+    if (addend && cin != 32) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: an addend needs Cin 32");
     if (ss2 != nullptr || (ss1 != nullptr && c1 != 32))
         return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: only a 32-channel first input can be activated while staging");
     if ((long long)D * H * W >= (1ll << 26)) return dlv_fail(ctx, DLV_EUNSUP, "z-reg conv: window too large for 32-bit plane offsets (buffer resources of 2 x 16 B x voxels)");
@@ -67,10 +67,10 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     // least 64 planes.  The choice depends on the window shape only, never on the batch size: the InstanceNorm partial
     // sums are per tile, so a window's result must not depend on how many windows share its launch
     int tyt = 8;
-    if (cin == 32 && !act && H % 16 == 0 && (long long)(H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 16) tyt = 16;
+    if (cin == 32 && H % 16 == 0 && (long long)(H / 16) * dlv_cdiv(W, 32) * ncb * dlv_cdiv(D, 64) >= 16) tyt = 16;
 #ifdef DLV_DIAG  // A/B switches of the diagnostic library (profiles/tools/tyt_ab.sh, minwg_ab.sh)
     static const int force_tyt = getenv("DLV_ZREG_TYT") ? atoi(getenv("DLV_ZREG_TYT")) : 0;
-    if (force_tyt == 8 || (force_tyt == 16 && cin == 32 && !act)) tyt = force_tyt;
+    if (force_tyt == 8 || (force_tyt == 16 && cin == 32)) tyt = force_tyt;
     static const int min_wg = getenv("DLV_ZREG_MINWG") ? atoi(getenv("DLV_ZREG_MINWG")) : 256;
 #else
     const int min_wg = 256;
@@ -84,7 +84,7 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     *nparts = tilesY * tilesX * ((D + 15) / 16);
     char* trash;  // target of the masked-out stores of edge steps / partial tiles
     DLV_TRY(dlv_ws_get(ctx, WS_MISC, 65536, (void**)&trash));
-    static const int dbg = getenv("DLV_ZREG_DBG") ? atoi(getenv("DLV_ZREG_DBG")) : 0;  // development: 1 = no interior steps
+    const int dbg = ctx->zreg_dbg;  // (dlv_diag_set "zreg_dbg") 1 = no interior steps
     ZrArgs a;
     a.in1 = in1; a.ss1 = ss1; a.in2 = in2; a.ss2 = ss2; a.wpk16 = wpk16; a.addend = addend;
     a.out = out; a.partials = partials; a.trash = trash;
@@ -92,13 +92,23 @@ int dlv_conv3_zreg_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void*
     a.dbg = dbg;
     a.gx = (unsigned)(tilesY * tilesX); a.gy = (unsigned)(nseg * ncb); a.gz = (unsigned)B;
     if (addend) {
+        if (act) {
+            if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_adda1(ctx, a) : dlv_zr_f16_c32_t8_adda1(ctx, a);
+            return tyt == 16 ? dlv_zr_bf16_c32_t16_adda1(ctx, a) : dlv_zr_bf16_c32_t8_adda1(ctx, a);
+        }
         if (f16) return tyt == 16 ? dlv_zr_f16_c32_t16_add(ctx, a) : dlv_zr_f16_c32_t8_add(ctx, a);
         return tyt == 16 ? dlv_zr_bf16_c32_t16_add(ctx, a) : dlv_zr_bf16_c32_t8_add(ctx, a);
     }
     if (f16) {
-        if (cin == 32) return act ? dlv_zr_f16_c32_t8_a1(ctx, a) : (tyt == 16 ? dlv_zr_f16_c32_t16_a0(ctx, a) : dlv_zr_f16_c32_t8_a0(ctx, a));
+        if (cin == 32) {
+            if (act) return tyt == 16 ? dlv_zr_f16_c32_t16_a1(ctx, a) : dlv_zr_f16_c32_t8_a1(ctx, a);
+            return tyt == 16 ? dlv_zr_f16_c32_t16_a0(ctx, a) : dlv_zr_f16_c32_t8_a0(ctx, a);
+        }
         return act ? dlv_zr_f16_c64_t8_a1(ctx, a) : dlv_zr_f16_c64_t8_a0(ctx, a);
     }
-    if (cin == 32) return act ? dlv_zr_bf16_c32_t8_a1(ctx, a) : (tyt == 16 ? dlv_zr_bf16_c32_t16_a0(ctx, a) : dlv_zr_bf16_c32_t8_a0(ctx, a));
+    if (cin == 32) {
+        if (act) return tyt == 16 ? dlv_zr_bf16_c32_t16_a1(ctx, a) : dlv_zr_bf16_c32_t8_a1(ctx, a);
+        return tyt == 16 ? dlv_zr_bf16_c32_t16_a0(ctx, a) : dlv_zr_bf16_c32_t8_a0(ctx, a);
+    }
     return act ? dlv_zr_bf16_c64_t8_a1(ctx, a) : dlv_zr_bf16_c64_t8_a0(ctx, a);
 }

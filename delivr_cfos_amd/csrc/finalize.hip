@@ -472,7 +472,7 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
     const long long nvox = (long long)Z * Y * X;
     DLV_TRY(dlv_ws_get(ctx, WS_ERODE, (size_t)nvox, (void**)&dist));
     const bool v4 = (X % 4 == 0);
-    static const bool split_xy = getenv("DLV_ERODE_XY_SPLIT") != nullptr;  // A/B + cross-check in tests: separate x and y passes
+    const bool split_xy = ctx->erode_xy_split;  // A/B + cross-check in tests (dlv_diag_set): separate x and y passes
     const int nchunk8 = (X + 7) / 8;
     if (cap <= 57 && nchunk8 <= 1024 && !split_xy) {
         // x and y fused: the x distance never reaches HBM
@@ -513,7 +513,7 @@ static int finalize_impl(dlv_ctx* ctx, const float* acc_dev, const uint8_t* cnt_
     {
         const int nblk = (int)(((long long)Z + zphase + zblock - 1) / zblock);
         DlvProf p(ctx, "erode_z_final", 0.0, (4.0 + 4.0 + 1.0) * nvox);
-        static const bool two_sweeps = getenv("DLV_ERODE_Z_TWO_SWEEPS") != nullptr;  // A/B + cross-check in tests
+        const bool two_sweeps = ctx->erode_z_two_sweeps;  // A/B + cross-check in tests (dlv_diag_set)
         if (erode_iters <= 31 && !two_sweeps) {  // one sweep with a shift register per column (the reference's 30 iterations)
             if (v4)
                 hipLaunchKernelGGL(erode_z_shift_kernel<4>, dim3(dlv_cdiv((long long)nblk * Y * (X / 4), 256)), dim3(256), 0,

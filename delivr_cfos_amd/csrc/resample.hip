@@ -579,7 +579,7 @@ int dlv_block_mean_u16_dev(dlv_ctx* ctx, const uint16_t* in_dev, int Z, int Y, i
     long long l = fx;
     while (l % 8) l += fx;  // lcm(fx, 8)
     const bool strip = X % 8 == 0 && (reinterpret_cast<unsigned long long>(in_dev) & 15ull) == 0 && (long long)fz * fy <= 65536 &&
-                       l <= 2048 && oz <= 65535 && !getenv("DLV_RESAMPLE_SIMPLE");
+                       l <= 2048 && oz <= 65535 && !ctx->resample_simple;
     if (strip) {
         const int chunk_w = (int)((2048 / l) * l);
         hipLaunchKernelGGL((block_mean_strip_kernel<2048>), dim3(oy, oz), dim3(256), 0, ctx->stream, in_dev, Z, Y, X, fz, fy, fx,
@@ -603,17 +603,17 @@ int dlv_zoom_spline2_u8_dev(dlv_ctx* ctx, const uint8_t* in_dev, int iz, int iy,
     sc.z = oz > 1 ? (double)(iz - 1) / (double)(oz - 1) : 0.0;
     sc.y = oy > 1 ? (double)(iy - 1) / (double)(oy - 1) : 0.0;
     sc.x = ox > 1 ? (double)(ix - 1) / (double)(ox - 1) : 0.0;
-    if (getenv("DLV_RESAMPLE_SIMPLE"))  // the one-voxel-per-thread kernel (A/B and cross-check in tests)
+    if (ctx->resample_simple)  // the one-voxel-per-thread kernel (A/B and cross-check in tests: dlv_diag_set)
         hipLaunchKernelGGL(zoom_spline2_u8_kernel, dim3(grid_for((long long)oz * oy * ox)), dim3(256), 0, ctx->stream, in_dev,
                            iz, iy, ix, out_dev, oz, oy, ox, sc);
     else {
         // row-organised kernel whenever its tables fit LDS and 16-bit indices (always, for the pipeline's masks); the
-        // run-per-thread kernel otherwise (DLV_RESAMPLE_RUN16: A/B and cross-check in tests)
+        // run-per-thread kernel otherwise (dlv_diag_set "resample_run16": A/B and cross-check in tests)
         const int runs = (ox + 15) / 16;
         const int nrows_max = (int)std::ceil((ZR_ROWS - 1) * sc.y) + 4;  // centre rows of a group's first and last output row, +-1, +1
         const size_t lds = (((size_t)ix * 2 + 15) & ~(size_t)15) + (size_t)ZR_ROWS * runs * 4 + (size_t)runs * 4 + (size_t)3 * nrows_max * ix;
         const long long groups = (long long)oz * ((oy + ZR_ROWS - 1) / ZR_ROWS);
-        if (ix <= 32767 && runs <= 32767 && lds <= 60 * 1024 && groups < (1ll << 31) && !getenv("DLV_RESAMPLE_RUN16")) {
+        if (ix <= 32767 && runs <= 32767 && lds <= 60 * 1024 && groups < (1ll << 31) && !ctx->resample_run16) {
             const int aligned = (ox % 16 == 0) && ((reinterpret_cast<unsigned long long>(out_dev) & 15ull) == 0);
             char* wsp;
             const size_t runk_b = ((size_t)runs * sizeof(short2) + 31) & ~(size_t)31;

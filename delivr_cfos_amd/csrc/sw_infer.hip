@@ -500,9 +500,11 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
 
     int sw_batch = p->sw_batch;
     if (sw_batch <= 0) {
-        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 56 of 96x96x64, 256 of 64x64x32, ...):
-        // ~10 GB of 16-bit activations, and enough tiles at the deep levels to fill 256 CUs
-        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 256);
+        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 56 of 96x96x64, ...), capped at 64 windows:
+        // ~10 GB of 16-bit activations, and enough tiles at the deep levels to fill 256 CUs.  (64 x 64 x 32 windows, measured in
+        // round 6: 256 per launch instead of 64 make the pass 20 % SLOWER - the level-0 tensors of a launch grow from 0.5 to 2 GB
+        // and stop finding each other's lines in L2 / MALL)
+        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 64);
     }
     int64_t launches = 0;
     const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);

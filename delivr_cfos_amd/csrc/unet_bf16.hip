@@ -1262,7 +1262,7 @@ struct Net16 {
     // does the register-resident-weights conv run this layer (and with which inputs may it apply the activation itself)?
     bool zreg_runs(int li, int c1, int c2, Dims d) const {
         const DlvConvLayer& L = ctx->conv[li];
-        static const int zreg_mask = getenv("DLV_ZREG_MASK") ? atoi(getenv("DLV_ZREG_MASK")) : 3;  // development: 1 = Cin 32, 2 = Cin 64
+        const int zreg_mask = ctx->zreg_mask;  // (dlv_diag_set) 1 = Cin 32, 2 = Cin 64
         return (ctx->zm_variant == 0 || ctx->zm_variant == 50) && !ctx->no_zmarch && d.vox() > 32768 &&
                dlv_conv3_zreg_supports(L.cin, L.cout, c1, c2, d.W) && ((L.cin == 32 ? 1 : 2) & zreg_mask);
     }
@@ -1270,8 +1270,8 @@ struct Net16 {
         // which levels' raw tensors are activated by the consuming conv while it stages them (bit l = level l).  Measured
         // (profiles/README.md, round 2): the Mish costs the staging conv more VALU time than the separate pass costs HBM
         // time at level 0, so the default fuses nothing into the convs; the transposed convs and the final 1x1x1 conv
-        // always activate on load.  DLV_FUSE_LEVELS overrides (A/B).
-        static const int fuse_levels = getenv("DLV_FUSE_LEVELS") ? atoi(getenv("DLV_FUSE_LEVELS")) : 0;
+        // always activate on load.  dlv_diag_set "fuse_levels" overrides (A/B).
+        const int fuse_levels = ctx->fuse_levels;
         static const int level_of[DLV_N_CONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
         return ((fuse_levels >> level_of[li]) & 1) && c1 == 32 && zreg_runs(li, c1, c2, d);
     }
@@ -1307,7 +1307,7 @@ struct Net16 {
     int conv_folded(int li, Act& sk, Act& coarse, uint4* pbuf, uint4* out, Dims d, Dims dc) {
         const DlvConvLayer& L = ctx->conv[li];
         DLV_TRY(materialise(coarse, dc));  // the folded weights multiply the ACTIVATED coarse tensor
-        DLV_TRY(materialise(sk, d));
+        if (!fuses_first_input(li, 32, 32, d)) DLV_TRY(materialise(sk, d));  // (else: activated by the conv while it stages the planes)
         if (coarse.C != 32) return dlv_fail(ctx, DLV_ESTATE, "folded conv %d: %d coarse channels, expected 32", li, coarse.C);
         {
             char nm[48];
@@ -1317,12 +1317,12 @@ struct Net16 {
             pr.end();
         }
         char zname[48];
-        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add", P::IS_F16 ? "f16" : "bf16", L.cout, d.D);
+        snprintf(zname, sizeof(zname), "conv3_zreg_%s_c32x%d_d%d_add%s", P::IS_F16 ? "f16" : "bf16", L.cout, d.D, sk.ss ? "_act" : "");
         DlvProf zp(ctx, zname, 2.0 * 27 * 32 * L.cout * (double)d.vox() * B, 2.0 * (double)d.vox() * B * (32 + 2 * L.cout));
         int np = 0;
         if ((size_t)B * dlv_cdiv(d.H, 8) * dlv_cdiv(d.W, 32) * dlv_cdiv(d.D, 16) * L.cout * 2 > partials_floats)
             return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small (zreg)");
-        DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, 32, L.cout, sk.p, 32, nullptr, nullptr, 0, nullptr, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, out,
+        DLV_TRY(dlv_conv3_zreg_launch(ctx, P::IS_F16, 32, L.cout, sk.p, 32, sk.ss, nullptr, 0, nullptr, P::IS_F16 ? L.wskip_f16 : L.wskip_bf16, out,
                                       partials, B, d.D, d.H, d.W, &np, pbuf));
         zp.end();
         return stats(np, li, d);
@@ -1351,12 +1351,14 @@ struct Net16 {
             zp.end();
             return stats(np, li, d);
         }
-        // deep levels (conv_deep.hip): weights shared through LDS, persistent workgroups.  DLV_DEEP_MASK (A/B): bit 0 = the layers
+        // deep levels (conv_deep.hip): weights shared through LDS, persistent workgroups.  deep_mask (A/B, dlv_diag_set): bit 0 = the layers
         // the LDS-weights z-march below takes (Cin, Cout <= 64 at the 32^3 level: 64->64 equal, 32->64 69 vs 78 us - they
         // stay with the z-march), bit 1 = the others (Cin or Cout >= 128: 1.4-1.5x the generic kernel's rate)
-        static const int deep_mask = getenv("DLV_DEEP_MASK") ? atoi(getenv("DLV_DEEP_MASK")) : 2;
+        const int deep_mask = ctx->deep_mask;
         const bool zmarch_ok = (L.cout == 32 || L.cout == 64) && (L.cin == 32 || L.cin == 64) && d.W >= 32;
-        if (!ctx->no_zmarch && ((zmarch_ok ? 1 : 2) & deep_mask) && dlv_conv3_deep_supports(L.cin, L.cout, c1, c2, d.D, d.H, d.W)) {
+        const bool deep_full = L.cout >= 64 && d.W >= 8 && d.H >= 8 && d.D >= 4;  // (what the kernel took before round 6: A/B switch "deep_small")
+        if (!ctx->no_zmarch && ((zmarch_ok ? 1 : 2) & deep_mask) && (deep_full || ctx->deep_small) &&
+            dlv_conv3_deep_supports(L.cin, L.cout, c1, c2, d.D, d.H, d.W)) {
             char zname[48];
             snprintf(zname, sizeof(zname), "conv3_deep_%s_c%dx%d_d%d", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, d.D);
             // (algorithmic bytes: activations in and out + the weights once - at these levels they are 10-50 % of the activations)
@@ -1392,8 +1394,8 @@ struct Net16 {
         const bool wlds = d.vox() <= 1024;
         int ncb = wlds ? (L.cout >= 64 ? 2 : 1) : (L.cout >= 128 ? 4 : (L.cout >= 64 ? 2 : 1));
         while (ncb > 1 && (long long)B * ntiles * (L.cout / (32 * ncb)) < 512) ncb >>= 1;
-        if (const char* e = getenv("DLV_GENERIC_NCB")) {  // A/B switch (profiles/README.md)
-            const int want = atoi(e);
+        if (ctx->generic_ncb) {  // A/B switch (dlv_diag_set; profiles/README.md)
+            const int want = ctx->generic_ncb;
             if ((want == 1 || want == 2 || (want == 4 && !wlds)) && L.cout % (32 * want) == 0) ncb = want;
         }
         if ((size_t)B * ntiles * L.cout * 2 > partials_floats) return dlv_fail(ctx, DLV_ESTATE, "partials buffer too small");
@@ -1463,7 +1465,7 @@ struct Net16 {
         else                                                                                                                       \
             hipLaunchKernelGGL((norm_mish_kernel<P, POOL_, WB_, false, PW, PQ>), grid, dim3(256), 0, ctx->stream, x, ss, C, d.D, d.H, d.W, pooled); \
     } while (0)
-        static const bool pool_rows_off = getenv("DLV_POOL_ROWS_OFF") != nullptr;  // A/B + tests: the pooled-voxel-per-thread kernel everywhere
+        const bool pool_rows_off = ctx->pool_rows_off;  // A/B + tests (dlv_diag_set): the pooled-voxel-per-thread kernel everywhere
         if (pooled && d.W % 64 == 0 && !pool_rows_off) {
             const long long items = (long long)(d.D / 2) * (d.H / 2) * (d.W / 64);
             dim3 g2((unsigned)std::max<long long>(1, std::min<long long>((items + 3) / 4, 4096)), C / 8, B);  // (one item per wave: 4 / 8 / 16 items per workgroup 902 / 914 / 939 us)
@@ -1500,7 +1502,7 @@ struct Net16 {
                           din.vox() * 8 * 4 * 16 < (1ll << 32);  // (its stores address one sample's output with 32-bit offsets)
         if (regw) grid.x = dlv_cdiv((long long)din.D * din.H * segs, 4 * DC_IPW);
         char dname[48];
-        static const bool deep_off = getenv("DLV_DEEP_MASK") && atoi(getenv("DLV_DEEP_MASK")) == 0;  // (A/B: the round-4 kernels)
+        const bool deep_off = ctx->deep_mask == 0;  // (A/B: the round-4 kernels)
         const bool deep = rows && !deep_off && L.w16_f16 && a.ss == nullptr && dlv_deconv2_deep_supports(L.cin, L.cout, din.D, din.H, din.W);
         snprintf(dname, sizeof(dname), "deconv2_%s_%s_c%dx%d_d%d", deep ? "deep" : "mfma", P::IS_F16 ? "f16" : "bf16", L.cin, L.cout, din.D);
         DlvProf pr(ctx, dname, 2.0 * 8 * L.cin * L.cout * (double)din.vox() * B,

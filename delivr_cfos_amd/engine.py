@@ -295,6 +295,11 @@ class HipEngine:
         self._leave()
         return out
 
+    def diag_set(self, name: str, value: int = 1) -> None:
+        """a kernel-selection switch of this context (include/delivr_hip_diag.h: dlv_diag_set) - tests and A/B runs; the library
+        reads no such switch from the environment"""
+        self._check(self.lib.dlv_diag_set(self.ctx, name.encode(), int(value)))
+
     def set_zm_variant(self, variant: int) -> None:
         """A/B and diagnostic builds of the z-march conv (dlv_debug_set_zm_variant); 0 = default."""
         self._check(self.lib.dlv_debug_set_zm_variant(self.ctx, int(variant)))

@@ -395,25 +395,10 @@ int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch wit
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
 
-/* ---- test hook ------------------------------------------------------------------------------ */
-/* Runs ONE layer of the bf16 MFMA path on fp32 NCDHW device tensors (converted on the device) so
- * that tests/ can compare each kernel with the oracle in isolation.  kind 0: conv block `index`
- * (1..17: Conv3d k3 + InstanceNorm + Mish) on the channel concatenation [in1 (c1), in2 (c2, may be
- * 0)] -> out (B,Cout,D,H,W); kind 1: ConvTranspose3d `index` (0..3) -> out (B,Cout,2D,2H,2W). */
-/* Diagnostic library only (libdelivr_hip_diag.so, `make diag`): selects an A/B, stamped or timing-only build of the
- * LDS-weights z-marching conv (3/4/6 tile, stagger and streaming-store variants; 20/24 double-buffered half-planes; 40
- * software-pipelined step; 11-13, 30, 41-45 timing-only or stamped builds, profiles/README.md).  The PRODUCT library holds
- * none of them: it accepts 0 / 50 (default: register-resident-weights conv) and 51 (the LDS-weights kernel for every
- * z-march layer, an A/B that gives the same results), refuses every other value with DLV_EUNSUP and ignores the
- * DLV_ZM_VARIANT environment variable.  No reference counterpart. */
-int dlv_debug_set_zm_variant(dlv_ctx* ctx, int variant);
-/* diagnostic: buffer (caller-owned, HBM, >= tiles*8*(D+4)*64 bytes, zeroed) that the stamped build of the z-march
- * conv (DLV_ZM_VARIANT=30) fills with s_memtime stamps of window 0; NULL switches it off.  No reference counterpart. */
-int dlv_debug_stamps(dlv_ctx* ctx, void* buf_dev);
-/* selects the 16-bit format dlv_debug_layer_bf16 runs in (DLV_PREC_BF16 default, DLV_PREC_F16) */
-int dlv_debug_set_format(dlv_ctx* ctx, int precision);
-int dlv_debug_layer_bf16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int c1, const float* in2_dev,
-                         int c2, float* out_dev, int B, int D, int H, int W);
+/* Test hooks and A/B switches (dlv_debug_*, dlv_diag_set) are declared in delivr_hip_diag.h: they are not part of the drop-in
+ * boundary.  The library reads these environment variables and no others: DLV_LANES (default of dlv_set_lanes), DLV_LAUNCH_LOG
+ * (file that receives one line per kernel launch: profiles/make_traffic.py), and for the transport of dlv_comm_init_all
+ * DLV_RCCL_PATH / ROCM_PATH (where librccl.so is looked for) and DLV_FORCE_RCCL (RCCL also for a one-rank communicator). */
 
 #ifdef __cplusplus
 }

@@ -167,7 +167,7 @@ def test_sw_pass_bf16_matches_fp32_engine(eng, golden_dir, flip, fmt):
 
 def test_sw_pass_fast_kernels_vs_generic_and_fp32(net):
     """Window 16x32x48 (W >= 32: z-marching convs + MFMA stem, ragged x tiles) against the generic
-    kernels (DLV_NO_ZMARCH=1) and the fp32 engine."""
+    kernels (diag switch "no_zmarch") and the fp32 engine."""
     import os
     import torch
     from delivr_cfos_amd.engine import HipEngine
@@ -178,12 +178,9 @@ def test_sw_pass_fast_kernels_vs_generic_and_fp32(net):
     roi = (16, 32, 48)
     out = {}
     for tag, env, prec in (("fast", None, "bf16"), ("generic", "1", "bf16"), ("fp32", None, "fp32")):
+        e = HipEngine(0)
         if env:
-            os.environ["DLV_NO_ZMARCH"] = env
-        try:
-            e = HipEngine(0)
-        finally:
-            os.environ.pop("DLV_NO_ZMARCH", None)
+            e.diag_set("no_zmarch", 1)
         e.load_state_dict({"state_dict": net.state_dict()})
         acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
         st = e.sw_infer(e.make_sw_params(vol.shape, roi, 0.5, 3, 0, prec), e.to_device(vol), acc)
@@ -328,57 +325,55 @@ def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     assert (out - base).abs().max() < 2 * tol_max
 
 
-_SWITCH_SNIPPET = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from delivr_cfos_amd.engine import HipEngine
-from delivr_cfos_amd.synth import synth_volume_np
-from delivr_cfos_amd.weights import random_state_dict
-eng = HipEngine(0)
-eng.load_state_dict({"state_dict": random_state_dict(0)})
-big = len(sys.argv) > 4 and sys.argv[4] == "128"
-vol = synth_volume_np((128, 128, 256) if big else (64, 96, 128), seed=9, dense=True)
-acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
-eng.sw_infer(eng.make_sw_params(vol.shape, (128, 128, 128) if big else (64, 64, 64), 0.5, None, 0, sys.argv[3]), eng.to_device(vol), acc)
-eng.sync()
-np.save(sys.argv[2], acc.cpu().numpy())
-"""
+def _pass_with_switches(prec, switches, lanes=None, big=False):
+    """one sliding-window pass on a fresh engine whose kernel-selection switches were set through dlv_diag_set
+    (include/delivr_hip_diag.h): 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1), or two 128^3 windows"""
+    import torch
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    eng = HipEngine(0)
+    try:
+        for k, v in switches.items():
+            eng.diag_set(k, v)
+        if lanes:
+            eng.set_lanes(lanes)
+        eng.load_state_dict({"state_dict": random_state_dict(0)})
+        vol = synth_volume_np((128, 128, 256) if big else (64, 96, 128), seed=9, dense=True)
+        acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
+        eng.sw_infer(eng.make_sw_params(vol.shape, (128, 128, 128) if big else (64, 64, 64), 0.5, None, 0, prec), eng.to_device(vol), acc)
+        eng.sync()
+        return acc.cpu().numpy()
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
-def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, prec):
-    """Every environment switch the product library reads selects kernels, never results: the activation fused into the
-    z-reg conv's staging (DLV_FUSE_LEVELS), edge-step code on every plane (DLV_ZREG_DBG), the LDS-weights z-march instead
-    of the z-reg conv (DLV_ZREG_MASK), cout blocks of the generic conv (DLV_GENERIC_NCB), lanes, the pooling pass by pooled voxels
-    instead of by full lines (DLV_POOL_ROWS_OFF), upcat_1 unfolded
-    (DLV_NO_UPCONV) or folded with the one-tile kernel (DLV_UPCONV_SIMPLE).  The switches are read once
-    per process, hence one process per setting; 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1)."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-    def run(env):
-        out = str(tmp_path / ("acc_" + "_".join(f"{k}{v}" for k, v in env.items()) + ".npy"))
-        e = dict(os.environ)
-        e.update(env)
-        subprocess.check_call([sys.executable, "-c", _SWITCH_SNIPPET, root, out, prec], env=e, timeout=600)
-        return np.load(out)
-
-    base = run({})
+def test_library_switches_that_pick_other_kernels_give_the_same_pass(prec):
+    """Every kernel-selection switch (dlv_diag_set; the library reads none from the environment) selects kernels, never results:
+    the activation fused into the z-reg conv's staging ("fuse_levels": levels 0 and 1, incl. the 16-row and the addend
+    instantiations), edge-step code on every plane ("zreg_dbg"), the LDS-weights z-march instead of the z-reg conv
+    ("zreg_mask"), cout blocks of the generic conv ("generic_ncb"), lanes, the pooling pass by pooled voxels instead of by
+    full lines ("pool_rows_off"), upcat_1 unfolded ("no_upconv") or folded with the one-tile kernel ("upconv_simple"), the
+    generic kernel for the deep levels ("deep_mask" 0)."""
+    base = _pass_with_switches(prec, {})
     std = float(base.std())
     # bit-identical: same arithmetic in another order of execution / another code path of the same kernel
-    for env in ({"DLV_LANES": "1"}, {"DLV_ZREG_DBG": "1"}, {"DLV_GENERIC_NCB": "1"}, {"DLV_POOL_ROWS_OFF": "1"}):
-        np.testing.assert_array_equal(run(env), base, err_msg=str(env))
+    np.testing.assert_array_equal(_pass_with_switches(prec, {}, lanes=1), base, err_msg="lanes")
+    for sw in ({"zreg_dbg": 1}, {"generic_ncb": 1}, {"pool_rows_off": 1}):
+        np.testing.assert_array_equal(_pass_with_switches(prec, sw), base, err_msg=str(sw))
     # same values up to the rounding of one 16-bit store (activation applied while staging: the activated tensor is never
     # rounded through HBM differently, but the InstanceNorm partial sums are taken over other tiles) / another kernel
     tol = 2e-3 if prec == "fp16" else 2e-2
-    for env in ({"DLV_FUSE_LEVELS": "1"}, {"DLV_FUSE_LEVELS": "3"}, {"DLV_ZREG_MASK": "0"}, {"DLV_NO_UPCONV": "1"}, {"DLV_UPCONV_SIMPLE": "1"}):
-        a = run(env)
+    for sw in ({"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"no_upconv": 1}, {"upconv_simple": 1}, {"deep_mask": 0},
+               {"no_upconv": 1, "fuse_levels": 3}):
+        a = _pass_with_switches(prec, sw)
         rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
-        print(env, "rel rms vs default:", rel)
-        assert rel < tol, (env, rel)
+        print(sw, "rel rms vs default:", rel)
+        assert rel < tol, (sw, rel)
+    with pytest.raises(Exception):
+        _pass_with_switches(prec, {"no_such_switch": 1})
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -392,7 +387,7 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(tmp_path, p
     ((128, 128, 128), (128, 128, 128), "upconv2m"),
 ])
 def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, shape, kernel):
-    """The folded path (default) must agree with the unfolded one (DLV_NO_UPCONV=1: ConvTranspose kernel + 64-channel conv) to
+    """The folded path (default) must agree with the unfolded one (diag switch "no_upconv": ConvTranspose kernel + 64-channel conv) to
     the rounding of the 16-bit format, both kernels of the folded path with each other, and each with the fp32 VALU path of
     the library within the tolerance of the other 16-bit tests; the profile labels prove which kernel ran.  The switches are
     read when a context is created."""
@@ -405,16 +400,14 @@ def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, sh
 
     engs = {}
     try:
-        for tag, env in (("folded", {}), ("simple", {"DLV_UPCONV_SIMPLE": "1"}), ("unfolded", {"DLV_NO_UPCONV": "1"})):
-            for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+        for tag, sw in (("folded", {}), ("simple", {"upconv_simple": 1}), ("unfolded", {"no_upconv": 1})):
             e = HipEngine(0)
+            for k, v in sw.items():
+                e.diag_set(k, v)
             e.load_state_dict({"state_dict": net.state_dict()})
             engs[tag] = e
     finally:
-        for k in ("DLV_UPCONV_SIMPLE", "DLV_NO_UPCONV"):
-            os.environ.pop(k, None)
+        pass
     vol = synth_volume_np(shape, seed=13, dense=True)
     dvol = engs["folded"].to_device(vol)
     out, ran = {}, {}
@@ -448,20 +441,10 @@ def test_folded_upcat_conv_against_the_unfolded_path_and_fp32(net, prec, roi, sh
     assert kernels < tol16 / 4, kernels  # same products, the face correction enters the fp32 sum first instead of last
 
 
-def test_pooling_pass_by_full_lines_is_bit_identical_at_128(tmp_path):
+def test_pooling_pass_by_full_lines_is_bit_identical_at_128():
     """Windows of 128^3: the full-line pooling kernel runs on levels 0 and 1 (W = 128 / 64, two / one 64-voxel segments per row) with
-    the non-temporal policy on level 0; DLV_POOL_ROWS_OFF=1 runs the pooled-voxel-per-thread kernel instead.  Same bits."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for tag, env in (("rows", {}), ("voxels", {"DLV_POOL_ROWS_OFF": "1"})):
-        out = str(tmp_path / f"acc_{tag}.npy")
-        e = dict(os.environ)
-        e.update(env)
-        subprocess.check_call([sys.executable, "-c", _SWITCH_SNIPPET, root, out, "fp16", "128"], env=e, timeout=600)
-        outs.append(np.load(out))
-    assert np.isfinite(outs[0]).all() and outs[0].std() > 0
-    np.testing.assert_array_equal(outs[0], outs[1])
+    the non-temporal policy on level 0; the diag switch "pool_rows_off" runs the pooled-voxel-per-thread kernel instead.  Same bits."""
+    rows = _pass_with_switches("fp16", {}, big=True)
+    voxels = _pass_with_switches("fp16", {"pool_rows_off": 1}, big=True)
+    assert np.isfinite(rows).all() and rows.std() > 0
+    np.testing.assert_array_equal(rows, voxels)

@@ -46,14 +46,15 @@ def test_split_and_create_npy(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", ["1", "5"])
-def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads):
+@pytest.mark.parametrize("threads,write_mode", [("1", "mmap"), ("5", "mmap"), ("5", "pwrite")])
+def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads, write_mode):
     import torch
 
     from delivr_cfos_amd import hostio
     from delivr_cfos_amd.engine import HipEngine
 
     monkeypatch.setenv("DLV_IO_THREADS", threads)
+    monkeypatch.setattr(hostio, "WRITE_MODE", write_mode)
     eng = HipEngine(0)
     rng = np.random.default_rng(3)
     vol = rng.integers(0, 65535, size=(1, 1, 37, 130, 257), dtype=np.uint16)  # (chunks of 3 MiB below: ragged last chunk)
@@ -90,6 +91,9 @@ def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads):
     assert np.array_equal(got[10:20], vol[0, 0, 10:20]) and not got[:10].any() and not got[20:].any()
     with pytest.raises(ValueError):
         hostio.download(eng, dev[:, ::2], host)
+    if write_mode == "mmap":
+        with pytest.raises(ValueError):  # the file must already have its size (create_npy)
+            hostio.download(eng, dev, out, offset=off + 1)
     eng.close()
 
 

@@ -476,72 +476,64 @@ def test_window_maxima_one_pass_and_general_path_vs_numpy(eng):
 
 
 @pytest.mark.parametrize("in_shape,out_shape", [((12, 20, 24), (48, 300, 352)), ((9, 14, 30), (33, 207, 451)), ((255, 9, 137), (1024, 130, 2048))])
-def test_zoom_kernels_agree_bitwise(eng, in_shape, out_shape, monkeypatch):
-    """The three zoom kernels - row-organised (default), run-per-thread (DLV_RESAMPLE_RUN16), one voxel per thread
-    (DLV_RESAMPLE_SIMPLE) - on the same blobby mask incl. the production zoom factors (4, 15, 15) along a 2048-voxel row."""
+def test_zoom_kernels_agree_bitwise(eng, in_shape, out_shape):
+    """The three zoom kernels - row-organised (default), run-per-thread (diag switch "resample_run16"), one voxel per thread
+    ("resample_simple") - on the same blobby mask incl. the production zoom factors (4, 15, 15) along a 2048-voxel row."""
     rng = np.random.default_rng(in_shape[2])
     m = (rng.random(in_shape) < 0.5).astype(np.uint8)
     m[:, : in_shape[1] // 2] = 1
     m[: in_shape[0] // 3, :, : in_shape[2] // 2] = 0
     src = eng.to_device(m)
     rows = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
-    monkeypatch.setenv("DLV_RESAMPLE_RUN16", "1")
-    run16 = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
-    monkeypatch.delenv("DLV_RESAMPLE_RUN16")
-    monkeypatch.setenv("DLV_RESAMPLE_SIMPLE", "1")
-    simple = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+    try:
+        eng.diag_set("resample_run16", 1)
+        run16 = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+        eng.diag_set("resample_run16", 0)
+        eng.diag_set("resample_simple", 1)
+        simple = eng.zoom_spline2_u8(src, out_shape).cpu().numpy()
+    finally:
+        eng.diag_set("resample_run16", 0)
+        eng.diag_set("resample_simple", 0)
     assert np.array_equal(rows, simple) and np.array_equal(run16, simple)
     assert 0 < int(rows.sum()) < rows.size
 
 
-_FINALIZE_SNIPPET = """
-import sys
-import numpy as np
-import torch
-sys.path.insert(0, sys.argv[1])
-from delivr_cfos_amd.engine import HipEngine
-from delivr_cfos_amd.synth import synth_volume_np
-eng = HipEngine(0)
-shape = (70, 90, int(sys.argv[3]))
-vol = synth_volume_np(shape, seed=5, dense=True)
-vol[:, :7] = 0
-vol[20:50, 30:60, 25:70] = 0
-rng = np.random.default_rng(1)
-acc = rng.normal(0.2, 1.0, size=shape).astype(np.float32)
-v, a = eng.to_device(vol), eng.to_device(acc)
-out = {}
-for er in (2, 7, 30):
-    for nb in (0, 24):
-        out[f"m_{er}_{nb}"] = eng.finalize(a, None, v, shape, 0.5, er, nb).cpu().numpy()
-cells = (vol > 3200).astype(np.uint8)
-lab, n = eng.ccl26(eng.to_device(cells))
-out["labels"] = lab.cpu().numpy()
-out["n"] = np.int64(n)
-np.savez(sys.argv[2], **out)
-"""
-
-
 @pytest.mark.parametrize("X", [96, 100])
-def test_finalize_and_ccl_kernel_switches_give_identical_results(tmp_path, X):
+def test_finalize_and_ccl_kernel_switches_give_identical_results(X):
     """The A/B switches of round 4 select kernels, never results: fused x+y distance pass vs separate passes
-    (DLV_ERODE_XY_SPLIT), one-sweep z decision vs forward + backward sweeps (DLV_ERODE_Z_TWO_SWEEPS), zero fill + listed
-    chunks vs whole-volume label stores (DLV_CCL_SIMPLE) - erosion radii 2 / 7 / 30, with and without z-blocks, rows that
-    are / are not multiples of 8.  One process per setting (the switches are read once)."""
-    import subprocess
-    import sys
+    ("erode_xy_split"), one-sweep z decision vs forward + backward sweeps ("erode_z_two_sweeps"), zero fill + listed
+    chunks vs whole-volume label stores ("ccl_simple") - erosion radii 2 / 7 / 30, with and without z-blocks, rows that
+    are / are not multiples of 8.  The switches are per context (dlv_diag_set): one engine per setting."""
+    from delivr_cfos_amd.engine import HipEngine
+    from delivr_cfos_amd.synth import synth_volume_np
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shape = (70, 90, X)
+    vol = synth_volume_np(shape, seed=5, dense=True)
+    vol[:, :7] = 0
+    vol[20:50, 30:60, 25:70] = 0
+    acc = np.random.default_rng(1).normal(0.2, 1.0, size=shape).astype(np.float32)
+    cells = (vol > 3200).astype(np.uint8)
 
-    def run(env):
-        out = str(tmp_path / ("r_" + "_".join(env) + ".npz"))
-        e = dict(os.environ)
-        e.update({k: "1" for k in env})
-        subprocess.check_call([sys.executable, "-c", _FINALIZE_SNIPPET, root, out, str(X)], env=e, timeout=600)
-        return np.load(out)
+    def run(switches):
+        eng = HipEngine(0)
+        try:
+            for k in switches:
+                eng.diag_set(k, 1)
+            v, a = eng.to_device(vol), eng.to_device(acc)
+            out = {}
+            for er in (2, 7, 30):
+                for nb in (0, 24):
+                    out[f"m_{er}_{nb}"] = eng.finalize(a, None, v, shape, 0.5, er, nb).cpu().numpy()
+            lab, n = eng.ccl26(eng.to_device(cells))
+            out["labels"] = lab.cpu().numpy()
+            out["n"] = np.int64(n)
+            return out
+        finally:
+            eng.close()
 
     base = run(())
     assert base["m_30_0"].any() and int(base["n"]) > 10
-    for env in (("DLV_ERODE_XY_SPLIT",), ("DLV_ERODE_Z_TWO_SWEEPS",), ("DLV_ERODE_XY_SPLIT", "DLV_ERODE_Z_TWO_SWEEPS"), ("DLV_CCL_SIMPLE",)):
-        other = run(env)
-        for k in base.files:
-            assert np.array_equal(other[k], base[k]), (env, k)
+    for sw in (("erode_xy_split",), ("erode_z_two_sweeps",), ("erode_xy_split", "erode_z_two_sweeps"), ("ccl_simple",)):
+        other = run(sw)
+        for k in base:
+            assert np.array_equal(other[k], base[k]), (sw, k)

@@ -61,7 +61,7 @@ def test_zreg_kernels_have_no_mfma_hazard_no_scratch_and_fit_one_wave_per_simd()
     _need_tools()
     hs = _tool()
     rep = hs.library_report(LIB)
-    assert len(rep) == 14, sorted(rep)  # 2 formats x (Cin 32: t8 a0/a1, t16 a0, t8 / t16 with an addend; Cin 64: t8 a0/a1)
+    assert len(rep) == 20, sorted(rep)  # 2 formats x (Cin 32: t8 / t16 x a0 / a1, t8 / t16 with an addend x a0 / a1; Cin 64: t8 a0/a1)
     for name, r in rep.items():
         assert r["hazards"] == 0, (name, r["first"])
         assert r["readback_hazards"] == 0, (name, r["first_readback"])  # asm MFMA result read too early by non-MFMA code
