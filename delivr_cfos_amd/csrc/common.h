@@ -229,6 +229,7 @@ int dlv_unet_forward_bf16(dlv_ctx* ctx, const float* x, float* logits, int B, in
 int dlv_unet_tiles_bf16(dlv_ctx* ctx, const uint16_t* vol, int Yp, int Xp, const int* starts_dev, int B, int d,
                         int h, int w, int flip_dim, float scale, float* acc, int fmt16);
 int dlv_pack_weights_bf16(dlv_ctx* ctx);
+int dlv_unet_reserve_16(dlv_ctx* ctx, int B, int d, int h, int w, int lanes);
 // z-marching conv for Cout in {32, 64, ...} (blocks of 32), Cin in {32, 64} (conv_zmarch.hip)
 int dlv_conv3_zmarch_launch(dlv_ctx* ctx, bool f16, int cin, int cout, const void* in1, int c1, const void* in2, int c2,
                             const void* wpk, const float* bias, void* out, float* partials, int B, int D, int H, int W,

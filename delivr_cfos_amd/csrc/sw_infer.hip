@@ -357,6 +357,32 @@ int dlv_sw_window_max_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* 
     return window_maxima(ctx, vol_dev, p->Yp, p->Xp, t.roi, starts, n, wmax);
 }
 
+// windows per forward launch when the caller leaves it to the library (dlv_sw_params.sw_batch == 0)
+static int default_sw_batch(long long tile_vox) {
+    // ~2^25 patch voxels per forward (16 windows of 128^3, 56 of 96x96x64, ...), capped at 64 windows: ~10 GB of 16-bit
+    // activations, and enough tiles at the deep levels to fill 256 CUs.  (64 x 64 x 32 windows, measured in round 6: 256 per
+    // launch instead of 64 make the pass 20 % SLOWER - the level-0 tensors of a launch grow from 0.5 to 2 GB and stop finding
+    // each other's lines in L2 / MALL)
+    return (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 64);
+}
+
+int dlv_reserve_dev(dlv_ctx* ctx, const dlv_sw_params* p, int Z, int Y, int X) {
+    if (!ctx || !p) return DLV_EINVAL;
+    if (p->roi[0] <= 0 || p->roi[1] <= 0 || p->roi[2] <= 0) return dlv_fail(ctx, DLV_EINVAL, "dlv_reserve_dev: window dimensions");
+    DLV_HIP(ctx, hipSetDevice(ctx->device));
+    const long long tile_vox = (long long)p->roi[0] * p->roi[1] * p->roi[2];
+    const int B = p->sw_batch > 0 ? p->sw_batch : default_sw_batch(tile_vox);
+    if (p->precision != DLV_PREC_F32) {
+        const int lanes = ctx->aux[0] != nullptr ? std::max(1, std::min(ctx->lanes_wanted, DLV_MAX_LANES)) : 1;
+        DLV_TRY(dlv_unet_reserve_16(ctx, B, p->roi[0], p->roi[1], p->roi[2], lanes));
+    }
+    if (Z > 0 && Y > 0 && X > 0) {  // the distance map of the eroded re-mask (finalize.hip)
+        void* q;
+        DLV_TRY(dlv_ws_get(ctx, WS_ERODE, (size_t)Z * Y * X, &q));
+    }
+    return DLV_OK;
+}
+
 int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_dev, float* acc_dev, uint8_t* cnt_dev,
                      dlv_sw_stats* stats) {
     if (!ctx || !p || !vol_dev || !acc_dev) return DLV_EINVAL;
@@ -499,13 +525,7 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     DLV_HIP(ctx, hipMemcpyAsync(list_dev, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
     int sw_batch = p->sw_batch;
-    if (sw_batch <= 0) {
-        // default: ~2^25 patch voxels per forward (16 windows of 128^3, 56 of 96x96x64, ...), capped at 64 windows:
-        // ~10 GB of 16-bit activations, and enough tiles at the deep levels to fill 256 CUs.  (64 x 64 x 32 windows, measured in
-        // round 6: 256 per launch instead of 64 make the pass 20 % SLOWER - the level-0 tensors of a launch grow from 0.5 to 2 GB
-        // and stop finding each other's lines in L2 / MALL)
-        sw_batch = (int)std::min<long long>(std::max<long long>(((long long)1 << 25) / tile_vox, 1), 64);
-    }
+    if (sw_batch <= 0) sw_batch = default_sw_batch(tile_vox);
     int64_t launches = 0;
     const int bchunks = (int)std::min<long long>(std::max<long long>(tile_vox / (256 * 16), 1), 256);
     // Pipeline lanes (HIP streams): consecutive batches of the 16-bit path rotate over them so

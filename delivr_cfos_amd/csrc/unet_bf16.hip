@@ -1549,6 +1549,26 @@ struct Net16 {
 
 // the whole forward; the stem reads either xf (fp32 patches) or the uint16 volume windows, the final
 // layer writes either logits or blends into acc
+// workspace of one 16-bit forward of B windows (one pipeline lane): the activations (4 buffers per level), the InstanceNorm partial
+// sums + scale/shift tables.  Shared by forward_16 and dlv_unet_reserve_16 (the same arithmetic, or the reservation is useless).
+struct Ws16 {
+    size_t act, stats, pfloats;
+};
+static Ws16 ws16_bytes(const int* f, int B, int d, int h, int w, size_t (*offs)[4]) {
+    const int lvlC[5] = {32, f[1], f[2], f[3], f[4]};
+    size_t off = 0;
+    for (int l = 0; l < 5; ++l)
+        for (int k = 0; k < 4; ++k) {
+            if (offs) offs[l][k] = off;
+            off += (size_t)B * lvlC[l] * ((size_t)(d >> l) * (h >> l) * (w >> l)) * 2;
+            off = (off + 255) & ~(size_t)255;
+        }
+    // partial sums: the level-0 convs have the most tiles (256 voxels each); the stem has fewer blocks
+    const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
+    const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
+    return Ws16{off, pfloats * 4 + (size_t)DLV_N_CONV * B * 256 * sizeof(float2) + 256, pfloats};
+}
+
 // P0: the format of level 0 (full resolution: stem, conv_0, upcat_1, final conv), PD: of levels 1-4.  P0 = PD: one format
 // throughout (fp16 / bf16 everywhere); P0 = fp16 with PD = bf16 is the mixed mode DLV_PREC_BF16 stands for (DESIGN section 5:
 // the 8 bits of bf16 are lost at full resolution - fp16 there lifts the margin-free mask IoU from 0.998 to 0.9994).  The
@@ -1564,21 +1584,13 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
     if ((long long)d * h * w >= (1ll << 31)) return dlv_fail(ctx, DLV_EUNSUP, "16-bit path: a window of %d x %d x %d voxels exceeds the 2^31 voxel index range", d, h, w);
     Dims dm[5];
     for (int l = 0; l < 5; ++l) dm[l] = Dims{d >> l, h >> l, w >> l};
-    const int lvlC[5] = {32, f[1], f[2], f[3], f[4]};
-    size_t off = 0, offs[5][4];
-    for (int l = 0; l < 5; ++l)
-        for (int k = 0; k < 4; ++k) {
-            offs[l][k] = off;
-            off += (size_t)B * lvlC[l] * dm[l].vox() * 2;
-            off = (off + 255) & ~(size_t)255;
-        }
+    size_t offs[5][4];
+    Ws16 wsz = ws16_bytes(f, B, d, h, w, offs);
+    const size_t off = wsz.act, pfloats = wsz.pfloats;
     char* base;
     DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_ACT0 + (ctx->lane - 1) : WS_BF16_ACT, off, (void**)&base));
-    // partial sums: the level-0 convs have the most tiles (256 voxels each); the stem has fewer blocks
-    const long long max_tiles = (long long)dlv_cdiv(d, 4) * dlv_cdiv(h, 4) * dlv_cdiv(w, 8) + 64;
-    const size_t pfloats = (size_t)B * max_tiles * 64 * 2;
     char* sbase;
-    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, pfloats * 4 + Net16<P0>::ss_bytes(B) + 256, (void**)&sbase));
+    DLV_TRY(dlv_ws_get(ctx, ctx->lane ? WS_LANE_STATS0 + (ctx->lane - 1) : WS_STATS, wsz.stats, (void**)&sbase));
     Net16<P0> net{ctx, B, (float*)sbase, pfloats, (float2*)(sbase + ((pfloats * 4 + 255) & ~(size_t)255))};  // level 0
     Net16<PD> netd{ctx, B, net.partials, pfloats, net.ss_base};                                                // levels 1-4
     constexpr bool mixed = !std::is_same<P0, PD>::value;
@@ -1793,6 +1805,19 @@ int debug_layer_16(dlv_ctx* ctx, int kind, int index, const float* in1_dev, int 
 int dlv_pack_weights_bf16(dlv_ctx* ctx) {
     DLV_TRY(pack_weights_16<PBf16>(ctx));
     return pack_weights_16<PF16>(ctx);
+}
+
+// the workspaces `lanes` pipeline lanes of a 16-bit forward of B windows of d x h x w will ask for (dlv_reserve_dev): hipMalloc
+// costs ~28 ms per GB on this platform (the driver clears what it hands out) and a pass needs ~10 GB per lane
+int dlv_unet_reserve_16(dlv_ctx* ctx, int B, int d, int h, int w, int lanes) {
+    if (!ctx->weights_loaded && ctx->features[1] == 0) return DLV_OK;  // (channel counts unknown before dlv_unet_load / alloc_blob)
+    const Ws16 wsz = ws16_bytes(ctx->features, B, d, h, w, nullptr);
+    void* p;
+    for (int lane = 0; lane < std::max(1, std::min(lanes, DLV_MAX_LANES)); ++lane) {
+        DLV_TRY(dlv_ws_get(ctx, lane ? WS_LANE_ACT0 + (lane - 1) : WS_BF16_ACT, wsz.act, &p));
+        DLV_TRY(dlv_ws_get(ctx, lane ? WS_LANE_STATS0 + (lane - 1) : WS_STATS, wsz.stats, &p));
+    }
+    return DLV_OK;
 }
 
 int dlv_range_reset(dlv_ctx* ctx) {

@@ -127,7 +127,25 @@ class HipComm:
         return [{"n_windows": s.n_windows, "n_skipped": s.n_skipped, "n_forward_launches": s.n_forward_launches} for s in st]
 
 
+_shared_engines: Dict[int, "HipEngine"] = {}
+
+
+def shared_engine(device: int = 0) -> "HipEngine":
+    """The process-wide engine of a device.  run_inference and count_blobs use it by default, so that one `python -m
+    delivr_cfos_amd` run keeps its context between steps and brains: the workspaces of a pass (~35 GB) and of the labelling
+    (~20 GB) and the pinned staging ring are allocated once (device allocation costs ~28 ms per GB here - 1-2 s per step
+    otherwise).  The reference's counterpart is PyTorch's caching allocator living as long as the process."""
+    eng = _shared_engines.get(int(device))
+    if eng is None or eng.ctx is None:
+        eng = HipEngine(int(device))
+        eng.shared = True
+        _shared_engines[int(device)] = eng
+    return eng
+
+
 class HipEngine:
+    shared = False  # True: owned by shared_engine() - callers that "own" their engine must not close it
+
     def __init__(self, device: int = 0, _ctx=None):
         import torch
 
@@ -385,6 +403,12 @@ class HipEngine:
         self._leave()
         return out
 
+    def reserve(self, params, stack_shape=None) -> None:
+        """dlv_reserve_dev: allocate now what a pass with `params` (and the finalize of `stack_shape`) will ask for.  Meant for a
+        second thread while the volume is read; the engine must not be used by another thread meanwhile."""
+        Z, Y, X = (int(v) for v in stack_shape) if stack_shape is not None else (0, 0, 0)
+        self._check(self.lib.dlv_reserve_dev(self.ctx, C.byref(params), Z, Y, X))
+
     def sw_infer(self, params, vol, acc, cnt=None) -> dict:
         """One sliding-window pass; vol uint16 (nz,Yp,Xp), acc fp32 and cnt uint8 (optional) are
         mutated in place (inference/sliding_window_inferer.py:232-251)."""
@@ -398,8 +422,9 @@ class HipEngine:
         return {"n_windows": st.n_windows, "n_skipped": st.n_skipped, "n_forward_launches": st.n_forward_launches}
 
     # ---- finalize ----------------------------------------------------------------------------------
-    def finalize(self, acc, cnt, raw, stack_shape, threshold=0.5, erode_iters=30, zblock=0, want_prob=False):
-        """-> uint8 (Z,Y,X) binaries [, fp32 sigmoid] (inference/inference.py:285-299, :31-95)."""
+    def finalize(self, acc, cnt, raw, stack_shape, threshold=0.5, erode_iters=30, zblock=0, want_prob=False, out=None):
+        """-> uint8 (Z,Y,X) binaries [, fp32 sigmoid] (inference/inference.py:285-299, :31-95).  `out`: a uint8 (Z,Y,X) tensor to
+        write the mask into (allocated ahead of the passes)."""
         torch = self.torch
         Z, Y, X = (int(v) for v in stack_shape)
         Yp, Xp = int(acc.shape[-2]), int(acc.shape[-1])
@@ -407,7 +432,10 @@ class HipEngine:
             # Gaussian blend: the count map holds weight sums; the mean logit is formed here, the kernel sees no count
             acc = acc / cnt.clamp_min(torch.finfo(torch.float32).tiny)
             cnt = None
-        out = torch.empty((Z, Y, X), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((Z, Y, X), dtype=torch.uint8, device=self.device)
+        elif tuple(out.shape) != (Z, Y, X):
+            raise ValueError(f"finalize: out has shape {tuple(out.shape)}, the stack {(Z, Y, X)}")
         prob = torch.empty((Z, Y, X), dtype=torch.float32, device=self.device) if want_prob else None
         self._enter()
         self._check(self.lib.dlv_finalize_dev(

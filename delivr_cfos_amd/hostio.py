@@ -2,10 +2,10 @@
 (masked_nifti.npy in, inference/inference.py:234; binaries.npy out, :312-318; the label volume and its re-read,
 count_blobs.py:45-65,86-88), so a 5 s GPU pass sits between an 8.6 GB read and a 4.3 GB write, and 20 ms of labelling
 between a 4.3 GB read and a 17 GB write.  Everything here is a chunked pipeline through a small ring of PINNED staging
-buffers: reader threads pread file bytes straight into the pinned memory, writer threads copy out of it into a shared
-mapping of the output file (both release the GIL: the threads run side by side; buffered pwrite()s of ONE file serialise
-on the inode lock - 4-6 GB/s on tmpfs whatever the thread count, measured - page faults on a mapping do not), the copy
-engine moves the previous chunk in the meantime, and no whole-volume pageable copy is ever made.
+buffers: reader threads pread file bytes straight into the pinned memory (27 GB/s from tmpfs with 16 threads), writer
+threads pwrite out of it (both release the GIL; buffered writes of ONE file serialise on its inode lock in the kernel: 4-7
+GB/s on tmpfs whatever the thread count - see WRITE_MODE), the copy engine moves the previous chunk in the meantime, and
+no whole-volume pageable copy is ever made.
 
     upload(engine, src, ...)        file / memmap / ndarray  -> tensor in HBM
     download(engine, tensor, dst)   tensor in HBM            -> bytes of a file (at an offset) / ndarray
@@ -25,7 +25,13 @@ import numpy as np
 
 CHUNK_BYTES = 64 << 20
 N_STAGE = 4
-WRITE_MODE = "mmap"  # "mmap": memcpy into a MAP_SHARED mapping of the file; "pwrite": positional writes (serialised per file)
+# "pwrite": positional writes from a few threads; "mmap": memcpy into a MAP_SHARED mapping of the file.  Measured on the GPU
+# box's /dev/shm (2 x 64-core EPYC, profiles/r06b_step_probe.json, 8 GB file): pwrite 7.1 / 3.9 / 6.1 / 3.5 / 2.1 GB/s with 8 / 16 /
+# 32 / 64 / 128 threads - buffered writes of ONE file serialise on its inode lock, more threads only add hand-overs - and the
+# mapping 3.5 / 3.8 / 2.1 / 1.1 / 0.7 GB/s: page faults that allocate tmpfs pages scale negatively.  A single file takes 4-7 GB/s
+# from the kernel, whatever the host does; the writers exist to keep the copy engine and the coordinator from waiting.
+WRITE_MODE = "pwrite"
+WRITE_THREADS = 8
 _MAX_IO = 1 << 30  # (one pread / pwrite moves at most 0x7ffff000 bytes on Linux)
 
 last_transfer = {}
@@ -34,11 +40,11 @@ _pool = None
 
 
 def io_threads() -> int:
-    """threads that move file bytes: DLV_IO_THREADS, else 32 (fewer on small hosts)"""
+    """threads that read file bytes: DLV_IO_THREADS, else 16 (fewer on small hosts)"""
     env = os.environ.get("DLV_IO_THREADS")
     if env:
         return max(1, int(env))
-    return max(2, min(32, (os.cpu_count() or 2)))
+    return max(2, min(16, (os.cpu_count() or 2)))
 
 
 def _executor() -> ThreadPoolExecutor:
@@ -174,9 +180,11 @@ def _copy_bytes(dst_mv: memoryview, src_arr) -> None:
     np.copyto(np.frombuffer(dst_mv, dtype=np.uint8), src_arr, casting="no")
 
 
-def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTES, what: str = "d2h", sync_file: bool = False):
+def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTES, what: str = "d2h", sync_file: bool = False,
+             synced: bool = False):
     """contiguous tensor in HBM -> `dst`: a path (bytes written at `offset`; the file must exist, e.g. from create_npy), an
-    open file descriptor (int), or a C-contiguous writeable ndarray of the same byte size."""
+    open file descriptor (int), or a C-contiguous writeable ndarray of the same byte size.  synced=True: the caller has already
+    synchronised the engine (a download running in a side thread must not touch the context)."""
     torch = engine.torch
     if not tensor.is_contiguous():
         raise ValueError("download: the tensor must be contiguous")
@@ -196,7 +204,7 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
             os.close(fd)
         return
     st = _stage_of(engine, chunk_bytes)
-    pool, nthr = _executor(), io_threads()
+    pool, nthr = _executor(), (io_threads() if isinstance(dst, np.ndarray) else min(io_threads(), WRITE_THREADS))
     writes = None
     t0 = time.perf_counter()
     try:
@@ -210,7 +218,8 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
                 arr = np.frombuffer(fmap, dtype=np.uint8)[offset:offset + nbytes]
             except (OSError, ValueError):  # (a file system without shared writable mappings: positional writes)
                 fmap, arr = None, None
-        engine.sync()
+        if not synced:
+            engine.sync()
         copy_stream = torch.cuda.Stream(device=engine.device)
         copy_stream.wait_stream(torch.cuda.current_stream(engine.device))
         evs = [torch.cuda.Event() for _ in range(N_STAGE)]
@@ -275,7 +284,7 @@ def create_npy(path: str, dtype, shape) -> int:
     return off
 
 
-def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: bool = False) -> None:
+def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: bool = False, synced: bool = False) -> None:
     """np.save(path, tensor) without a host copy of the tensor: header by numpy, payload streamed from HBM.  `dtype`: the
     numpy dtype the file declares (same item size as the tensor's: e.g. uint32 for labels held in an int32 tensor).
     partial: write under `<path>.partial` and rename when complete (a killed run leaves no complete-looking file)."""
@@ -284,6 +293,6 @@ def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: 
         raise ValueError("save_npy: dtype must have the tensor's item size")
     target = path + ".partial" if partial else path
     off = create_npy(target, npdt, tuple(tensor.shape))
-    download(engine, tensor, target, offset=off, what=what)
+    download(engine, tensor, target, offset=off, what=what, synced=synced)
     if partial:
         os.replace(target, path)

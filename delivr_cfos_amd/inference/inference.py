@@ -22,11 +22,11 @@ from .sliding_window_inferer import SlidingWindowInferer
 
 
 def create_nifti_seg(threshold, model_output, output_file, network_output_file, dataset, original_stack_shape,
-                     count_map=None, engine=None, erode_iters: int = 30):
+                     count_map=None, engine=None, erode_iters: int = 30, mask_out=None):
     """sigmoid >= threshold, eroded re-mask, crop to the original stack, write binaries.npy
     (reference :31-95).  ``model_output``: (1,1,Zp,Yp,Xp) or (Zp,Yp,Xp) fp32 tensor in HBM holding the
     blended logits (sum; pass ``count_map`` to divide, or the mean already); ``dataset``: the uint16
-    volume in HBM."""
+    volume in HBM; ``mask_out``: a uint8 (Z,Y,X) tensor in HBM to hold the mask (allocated ahead of the passes)."""
     Z, Y, X = (int(v) for v in original_stack_shape[-3:])
     if count_map is None and float(threshold) != 0.5:
         # sigmoid(sum of the window logits) >= t equals the reference's sigmoid(sum / count) >= t (:295) only at t = 0.5
@@ -37,7 +37,7 @@ def create_nifti_seg(threshold, model_output, output_file, network_output_file, 
     cnt = None if count_map is None else (count_map[0, 0] if count_map.dim() == 5 else count_map)
     zb = arrayterator_zblock((Z, Y, X))
     res = engine.finalize(acc, cnt, raw, (Z, Y, X), float(threshold), erode_iters, 0 if zb >= Z else zb,
-                          want_prob=network_output_file is not None)
+                          want_prob=network_output_file is not None, out=mask_out)
     mask, prob = res if network_output_file is not None else (res, None)
     engine.sync()
     # the reference creates binaries.npy with open_memmap (:312) and fills it block by block; here numpy writes the same
@@ -105,7 +105,8 @@ def run_inference(
         device_index = 0
 
     # ~~<< M O D E L >>~~  (reference :190-222)
-    model = HipBasicUNet(device=device_index, precision=precision)
+    # the process-wide engine of the device: its context, workspaces and pinned staging survive between brains and steps
+    model = HipBasicUNet(device=device_index, precision=precision, shared=True)
     eng = model.engine
     if rank == 0:
         if state_dict is None:
@@ -165,11 +166,38 @@ def run_inference(
             print(f"volume of {pad_vox * bpv / 2**30:.1f} GiB (+ {fixed / 2**30:.1f} GiB workspace) exceeds the HBM budget of "
                   f"{budget / 2**30:.1f} GiB: streaming {n_slabs} Z-slabs through the device")
     resident = not sharded and stream_plan is None
+    output_image = count_map = mask_buf = None
     if resident:
-        dataset = eng.upload_volume(dataset_host[0, 0])  # parallel preads -> pinned staging ring -> HBM (hostio.py)
-        mark("upload")
-    output_image = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device) if resident else None
-    count_map = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device) if (need_count and resident) else None
+        # Device allocation is not free here (~28 ms per GB: the driver clears what it hands out) and this step needs ~70 GB for a
+        # 1024 x 2048 x 2048 brain - sums, the pass's activation workspaces, the finalize maps.  A second thread allocates them
+        # while this one reads the volume (preads -> pinned staging -> HBM, hostio.py); a process that has already served a brain
+        # of this size finds all of it in the shared engine and in torch's caching allocator.
+        import threading
+
+        side, side_err = {}, []
+
+        def preallocate():
+            try:
+                with torch.cuda.device(eng.device):
+                    side["acc"] = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
+                    if need_count:
+                        side["cnt"] = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device)
+                    side["mask"] = torch.empty(tuple(stack_shape[2:]), dtype=torch.uint8, device=eng.device)
+                    eng.reserve(eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision), stack_shape[2:])
+                    torch.cuda.current_stream(eng.device).synchronize()
+            except Exception as exc:  # re-raised on the main thread
+                side_err.append(exc)
+
+        th = threading.Thread(target=preallocate, name="dlv-prealloc")
+        th.start()
+        try:
+            dataset = eng.upload_volume(dataset_host[0, 0])  # parallel preads -> pinned staging ring -> HBM (hostio.py)
+        finally:
+            th.join()
+        if side_err:
+            raise side_err[0]
+        output_image, count_map, mask_buf = side["acc"], side.get("cnt"), side["mask"]
+        mark("upload+alloc")
     if need_count and cm_dtype == torch.uint8:
         # uint8 like the reference's LOAD_ALL_RAM map (:241): refuse geometries whose multiplicity cannot be held
         from ..hostlogic import max_window_multiplicity
@@ -238,7 +266,7 @@ def run_inference(
             os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
         create_nifti_seg(threshold=threshold, model_output=output_image, output_file=output_file,
                          network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
-                         count_map=count_map, engine=eng)
+                         count_map=count_map, engine=eng, mask_out=mask_buf)
     else:
         from ..parallel import balanced_plan, exchange_seams, finalize_owned, gather_slabs
 

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from typing import Optional
 
-from .engine import HipEngine
+from .engine import HipEngine, shared_engine
 
 
 class HipBasicUNet:
@@ -13,8 +13,10 @@ class HipBasicUNet:
     operands, default: mask IoU >= 0.999 vs the fp32 path), "bf16" (bf16 at levels 1-4, fp16 at full resolution), "bf16_all" (bf16 everywhere, 8 significant bits) or "fp32"
     (VALU parity mode)."""
 
-    def __init__(self, device: int = 0, precision: str = "fp16", engine: Optional[HipEngine] = None):
-        self.engine = engine if engine is not None else HipEngine(device)
+    def __init__(self, device: int = 0, precision: str = "fp16", engine: Optional[HipEngine] = None, shared: bool = False):
+        """engine: run on this engine; shared=True: on the process-wide engine of `device` (engine.shared_engine: context and
+        workspaces survive between brains), else a fresh engine of its own"""
+        self.engine = engine if engine is not None else (shared_engine(device) if shared else HipEngine(device))
         self.precision = precision
 
     # torch.nn.Module look-alikes used by the reference's call sequence (inference.py:217-222,262)

@@ -395,6 +395,14 @@ int dlv_prof_enable(dlv_ctx* ctx, int on); /* on: bracket each kernel launch wit
 int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
 
+/* Allocates now what a pass with these parameters (window shape, precision, batch; dlv_set_lanes) and the finalize of a Z x Y x X
+ * stack (0s: none) will ask for later - ~10 GB of activations per pipeline lane, the erosion's distance map.  Device allocation
+ * costs ~28 ms per GB on this platform (the driver clears what it hands out): a host calls this from a second thread while it
+ * reads the volume (inference/inference.py does), and a context that is kept between brains pays it once.  Optional: the pass
+ * allocates on demand otherwise.  The ctx must not be used by another thread meanwhile.  No reference counterpart (PyTorch's
+ * caching allocator plays this role there, inference/inference.py:240-247). */
+int dlv_reserve_dev(dlv_ctx* ctx, const dlv_sw_params* p, int Z, int Y, int X);
+
 /* Test hooks and A/B switches (dlv_debug_*, dlv_diag_set) are declared in delivr_hip_diag.h: they are not part of the drop-in
  * boundary.  The library reads these environment variables and no others: DLV_LANES (default of dlv_set_lanes), DLV_LAUNCH_LOG
  * (file that receives one line per kernel launch: profiles/make_traffic.py), and for the transport of dlv_comm_init_all

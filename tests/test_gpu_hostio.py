@@ -127,3 +127,45 @@ def test_count_blobs_writes_uint16_labels_for_few_components_and_reuses_them(tmp
     for k in first:
         np.testing.assert_array_equal(first[k], again[k])
     assert open(os.path.join(post, f"{mask.shape}_brain.csv")).read() == csv == orc.cells_csv_text(orc.cc_stats(lab_ref, n_ref), n_ref)
+
+
+@pytest.mark.gpu
+def test_reserve_allocates_what_the_pass_asks_for_and_the_shared_engine_is_one_per_device():
+    """dlv_reserve_dev (run_inference calls it from a second thread while it reads the volume): after it, a pass and a finalize of
+    that geometry allocate (almost) nothing in the library - and the result is the one of an engine that allocated on demand."""
+    import torch
+
+    from delivr_cfos_amd.engine import HipEngine, shared_engine
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    assert shared_engine(0) is shared_engine(0) and shared_engine(0).shared
+    shape, roi = (64, 128, 192), (64, 64, 64)
+    vol = synth_volume_np(shape, seed=3, dense=True)
+    sd = random_state_dict(2)
+    outs = []
+    for reserve in (True, False):
+        eng = HipEngine(0)
+        eng.load_state_dict({"state_dict": sd})
+        v = eng.to_device(vol)
+        acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        mask = torch.empty(shape, dtype=torch.uint8, device="cuda")
+        p = eng.make_sw_params(shape, roi, 0.5, None, 0, "fp16")
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        if reserve:
+            eng.reserve(p, shape)
+            free1 = torch.cuda.mem_get_info()[0]
+            assert free0 - free1 > 3 * 100 * 2**20  # three lanes of 15 windows x 64^3 voxels x ~400 B of activations
+        eng.sw_infer(p, v, acc)
+        out = eng.finalize(acc, None, v, shape, 0.5, 30, 0, out=mask)
+        eng.sync()
+        assert out.data_ptr() == mask.data_ptr()
+        if reserve:
+            assert free1 - torch.cuda.mem_get_info()[0] < 64 * 2**20, "the pass allocated what dlv_reserve_dev should have"
+        outs.append((acc.cpu().numpy(), mask.cpu().numpy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(ValueError):
+        eng2 = HipEngine(0)
+        eng2.finalize(torch.zeros(shape, device="cuda"), None, torch.zeros(shape, dtype=torch.uint16, device="cuda"), shape, out=torch.empty((1, 2, 3), dtype=torch.uint8, device="cuda"))
