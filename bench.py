@@ -468,8 +468,11 @@ def main():
     else:
         # slab-resident: every rank generates (a real run: reads) and holds only the planes of ITS Z-slab; the shards are
         # balanced by the windows that actually run the network (a brain fills the central slabs, not the outer ones)
+        t_plan = time.perf_counter()
         plan, slo, shi, vol = balanced_plan(
             eng, params_all, planes, world, rank, dist, Z, 30, nb)
+        torch.cuda.synchronize()
+        plan_s = time.perf_counter() - t_plan  # (unweighted slab -> window maxima -> all_gather -> weighted plan -> the slab completed)
     wb, we = plan.win_ranges[rank]
 
     def pass_params(precision, skip_threshold=0):
@@ -485,15 +488,28 @@ def main():
     stats_last = {}
     cur = {"params": params}
 
-    def step():
+    phase_s = {}  # (filled by step(phases=True): one extra, untimed step with a device synchronisation after every phase)
+
+    def step(phases=False):
+        def lap(name, t0):
+            if phases:
+                eng.sync()
+                torch.cuda.synchronize()
+                phase_s[name] = time.perf_counter() - t0
+            return time.perf_counter()
+
+        t = lap("", 0.0)
         acc.zero_()
         if cur["params"] is not None:
             for q in cur["params"]:
                 stats_last.update(eng.sw_infer(q, vol, acc))
+        t = lap("windows_ms", t)
         if dist_mode:
             eng.sync()
             exchange_seams(acc, plan, rank, dist, z0=slo)
+            t = lap("seam_ms", t)
         slab, _, _ = finalize_owned(eng, plan, rank, acc, None, vol, (Z, Y, X), 0.5, 30, z0=slo)
+        t = lap("finalize_ms", t)
         if slab is None:
             slab = torch.empty((0, Y, X), dtype=torch.uint8, device=eng.device)
         # N > 1: the mask stays on the ranks as Z-slabs (the planes each rank owns) - what the sharded count_blobs /
@@ -539,6 +555,18 @@ def main():
         elapsed_dense, _ = timed_steps(1)
         stats_dense = dict(stats_last)
         cur["params"] = params
+    # N > 1: where a rank's step goes - its windows, the seam exchange, the finalize of the planes it owns - from one extra step with
+    # a synchronisation after every phase (the first 8-GPU record can be held against DESIGN section 6's model line by line)
+    per_rank_phases = None
+    if dist_mode:
+        fence()
+        step(phases=True)
+        fence()
+        mine = {k: round(1e3 * v, 3) for k, v in phase_s.items() if k}
+        mine["window_max_gather_ms"] = round(1e3 * plan_s, 3)
+        mine["slab_planes"] = [int(slo), int(shi)]
+        per_rank_phases = [None] * world
+        dist.all_gather_object(per_rank_phases, mine)
     # the other 16-bit format, one pass (BASELINE's configs name bf16; fp16 is the default for its closer masks)
     elapsed_alt, alt_prec = None, {"fp16": "bf16", "bf16": "fp16"}.get(args.precision)
     if alt_prec and not args.no_dense and not args.dense:
@@ -780,6 +808,9 @@ def main():
             "volume_zyx": [Z, Y, X], "padded_zyx": list(shape), "roi": list(roi), "overlap": 0.5, "tta": bool(tta),
             "passes_per_step": n_passes, "pass_weights": [r for _, r in schedule],
             "windows": n_windows, "windows_skipped": n_skipped, "per_rank_windows": per_rank,
+            # per rank: ms of its windows / the seam exchange / the finalize of its planes in one synchronised step, and of the
+            # balanced plan (slab generation + window maxima + their all_gather) at start-up
+            "per_rank_phases": per_rank_phases,
             "skipped_fraction": (n_skipped / n_windows) if n_windows else None,
             "patch_voxels_per_s": tile_vox * n_active * n_passes / (elapsed / args.steps),
             "timed_region": "uint16 volume in HBM -> uint8 eroded mask in HBM" + (" (Z-slabs resident on their ranks)" if world > 1 else ""),

@@ -1,8 +1,11 @@
 // api.hip - context, memory helpers, weight loading and the in-library kernel timer of
 // libdelivr_hip.so (C ABI declared in include/delivr_hip.h).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -59,7 +62,42 @@ static FILE* launch_log() {
     return f;
 }
 
+// roctx (rocprofiler-sdk): ranges named like the kernel labels of dlv_prof_report.  The symbols are taken from a roctx library
+// that is already in the process (a profiler's); DLV_ROCTX=1 loads one.  Without either nothing is called.
+typedef int (*dlv_roctx_push_t)(const char*);
+typedef int (*dlv_roctx_pop_t)(void);
+static dlv_roctx_push_t g_roctx_push = nullptr;
+static dlv_roctx_pop_t g_roctx_pop = nullptr;
+static void roctx_init() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* push = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        void* pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+        if ((!push || !pop) && getenv("DLV_ROCTX")) {
+            void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                push = dlsym(h, "roctxRangePushA");
+                pop = dlsym(h, "roctxRangePop");
+            }
+        }
+        if (push && pop) {
+            g_roctx_push = (dlv_roctx_push_t)push;
+            g_roctx_pop = (dlv_roctx_pop_t)pop;
+        }
+    });
+}
+
+DlvProf::~DlvProf() {
+    if (ranged) (void)g_roctx_pop();
+}
+
 DlvProf::DlvProf(dlv_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+    roctx_init();
+    if (g_roctx_push) {
+        (void)g_roctx_push(name);
+        ranged = true;
+    }
     if (FILE* f = launch_log()) {
         fprintf(f, "%s\t%.0f\t%.0f\n", name, flops, bytes);
         fflush(f);
@@ -94,6 +132,10 @@ DlvProf::DlvProf(dlv_ctx* c, const char* name, double flops, double bytes) : ctx
 }
 void DlvProf::end() {
     if (idx >= 0) (void)hipEventRecord(ctx->prof_pending[idx].b, ctx->stream);
+    if (ranged) {
+        (void)g_roctx_pop();
+        ranged = false;
+    }
 }
 
 static int prof_drain(dlv_ctx* ctx) {

@@ -166,10 +166,14 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out);
 int dlv_sync_all(dlv_ctx* ctx);
 
 // kernel timer: DlvProf p(ctx, "name", flops, bytes); <launch>; p.end();
+// ... and, when a roctx library is in the process (rocprofv3 --marker-trace; or DLV_ROCTX=1 loads it), a roctx range of the same
+// name around the launch(es) of the layer: an external trace shows a forward's layers by name
 struct DlvProf {
     dlv_ctx* ctx;
     int idx = -1;
+    bool ranged = false;
     DlvProf(dlv_ctx* c, const char* name, double flops, double bytes);
+    ~DlvProf();
     void end();
 };
 

@@ -639,8 +639,12 @@ __global__ void __launch_bounds__(64) stats_finalize_kernel(const float* __restr
         // 16-bit value overflows.  The largest |mean| + 8 sigma of every block is recorded (one atomic per (window, channel) of a
         // 64-thread workgroup); after a DLV_ERANGE the host reads it as the hint for dlv_unet_set_conv_shift: how far to move a
         // block that reported > 4096, and which blocks are too SMALL to be moved at all (positive floats order like their bit patterns)
+        // (a plain read first: one atomic per (window, channel) on ONE address cost 40-160 us per launch - 16 k workgroups of a
+        // 64-window batch queue up on it, +24 % on a pass of 64 x 64 x 32 windows, measured; after the first few workgroups the
+        // word already holds a larger value and the others only read it.  A stale read is harmless: atomicMax decides.)
         const float peak = (float)(fabs(mean) + 8.0 * sqrt(var));
-        if (peak > 0.f && peak < 3.0e38f) atomicMax(range_flag + 1 + layer, __float_as_int(peak));
+        if (peak > 0.f && peak < 3.0e38f && __float_as_int(peak) > __builtin_nontemporal_load(range_flag + 1 + layer))
+            atomicMax(range_flag + 1 + layer, __float_as_int(peak));
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = rstd * gamma[c];
         ss[n * C + c] = make_float2(sc, beta[c] - (float)mean * sc);

@@ -88,6 +88,13 @@ def run_inference(
     precision = precision or "fp16"
     crop_size = tuple(int(c) for c in crop_size)
     print("using crop size:  ", crop_size)
+    if any(c <= 0 or c % 16 for c in crop_size):
+        # the reference takes any window (inference/inference.py:162-168 -> SlidingWindowInferer): MONAI's UpCat replicate-pads an
+        # up-sampled tensor whose skip tensor has an odd size.  The HIP U-Net has no such padding: four 2 x poolings and transposed
+        # convs return to the skip shapes exactly when every window dimension is a multiple of 16 (DLV_EUNSUP in the library).
+        raise ValueError(f"window_dimensions {crop_size}: every dimension must be a positive multiple of 16 on the MI355X path "
+                         "(the reference builds its windows from window_dim_0..2, inference/inference.py:162-168, and MONAI pads odd "
+                         "levels; the defaults (64, 64, 32) and config.json's (96, 96, 64) qualify)")
     if not torch.cuda.is_available():
         raise RuntimeError("run_inference needs an MI355X: the HIP path has no CPU fallback")
     # one process per GPU (torch.distributed.run): the window list is sharded over the ranks, see parallel.py.
