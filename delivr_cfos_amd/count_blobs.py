@@ -86,7 +86,7 @@ def _count_blobs_sharded(eng, bin_img, dist, path_out, brain):
             mm = np.load(out_path, mmap_mode="r")
             off = int(mm.offset) + lo * Y * X * mm.dtype.itemsize
             del mm
-            hostio.download(eng, _labels_in_file_dtype(labels, N), out_path, offset=off, what="d2h_labels")
+            hostio.download(eng, _labels_in_file_dtype(labels, N), out_path, offset=off, what="d2h_labels", sparse=True)  # (rank 0 created the file just now)
     except Exception as exc:
         mine = f"rank {rank}: {exc!r}"
     _raise_if_any_failed(dist, mine, f"count_blobs: writing the label slabs into {out_path} (path_out must be shared by all ranks)")

@@ -115,10 +115,18 @@ def mask_and_pad(engine, raw_dev, mask_dev, crop_size: Sequence[int], threshold:
     return engine.mask_pad_u16(raw_dev, mask_dev, pad, threshold or 0)
 
 
-def write_masked_nifti_npy(path: str, padded_dev) -> None:
+def write_masked_nifti_npy(path: str, padded_dev, engine=None) -> None:
     """(Zp,Yp,Xp) uint16 tensor -> <path> as NPY v1 (1,1,Zp,Yp,Xp) '<u2' with the 128-byte header the
-    inference step skips with offset=128 (inference/inference.py:234)."""
+    inference step skips with offset=128 (inference/inference.py:234).  With an engine the payload streams out of HBM through
+    pinned staging (hostio.py; the masked-out background stays a hole of the file), else through one host copy."""
     shape = (1, 1) + tuple(int(v) for v in padded_dev.shape)
+    if engine is not None and padded_dev.is_contiguous():
+        from .. import hostio
+
+        if hostio.create_npy(path, np.uint16, shape) != 128:
+            raise RuntimeError("npy header is not the 128 bytes the pipeline expects")
+        hostio.download(engine, padded_dev, path, offset=128, what="d2h_volume", sparse=True)
+        return
     out = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint16, shape=shape)
     if out.offset != 128:
         raise RuntimeError(f"npy header is {out.offset} bytes, the pipeline expects 128")
@@ -188,7 +196,7 @@ def downsample_mask(settings: dict, brain: str, engine=None):
             np.save(os.path.join(results, "downsampled_masked_stack.npy"),
                     (ds_host > int(md["simple_threshold_value"])).astype(ds_host.dtype) * ds_host)  # (:316, :333)
         eng.sync()
-        write_masked_nifti_npy(os.path.join(results, "masked_niftis", "masked_nifti.npy"), padded)
+        write_masked_nifti_npy(os.path.join(results, "masked_niftis", "masked_nifti.npy"), padded, engine=eng)
     finally:
         if own:
             eng.close()

@@ -32,6 +32,10 @@ N_STAGE = 4
 # from the kernel, whatever the host does; the writers exist to keep the copy engine and the coordinator from waiting.
 WRITE_MODE = "pwrite"
 WRITE_THREADS = 8
+# Files written into a FRESH file (create_npy: ftruncate, every byte reads as zero) skip the blocks that are zero in HBM: the file
+# stays sparse there and reads back the same bytes.  A brain fills ~40 % of its box - binaries.npy and the label volume are zero
+# outside it - so ~60 % of the 4.3 + 17 GB never cross PCIe or the kernel's one-file write path (the bottleneck of step 3).
+SPARSE_BLOCK = 1 << 20
 _MAX_IO = 1 << 30  # (one pread / pwrite moves at most 0x7ffff000 bytes on Linux)
 
 last_transfer = {}
@@ -180,11 +184,22 @@ def _copy_bytes(dst_mv: memoryview, src_arr) -> None:
     np.copyto(np.frombuffer(dst_mv, dtype=np.uint8), src_arr, casting="no")
 
 
+def _zero_block_flags(torch, src, nblk: int):
+    """numpy bool (nblk,): block i of SPARSE_BLOCK bytes of the uint8 device tensor `src` holds a non-zero byte"""
+    words = src[: nblk * SPARSE_BLOCK].view(torch.int64).view(nblk, SPARSE_BLOCK // 8)
+    out = torch.empty(nblk, dtype=torch.bool, device=src.device)
+    for b0 in range(0, nblk, 1024):  # (1 GiB at a time: the comparison's temporary stays at 128 MiB)
+        out[b0:b0 + 1024] = words[b0:b0 + 1024].ne(0).any(dim=1)
+    return out.cpu().numpy()
+
+
 def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTES, what: str = "d2h", sync_file: bool = False,
-             synced: bool = False):
+             synced: bool = False, sparse: bool = False):
     """contiguous tensor in HBM -> `dst`: a path (bytes written at `offset`; the file must exist, e.g. from create_npy), an
     open file descriptor (int), or a C-contiguous writeable ndarray of the same byte size.  synced=True: the caller has already
-    synchronised the engine (a download running in a side thread must not touch the context)."""
+    synchronised the engine (a download running in a side thread must not touch the context).  sparse=True (file destinations
+    whose target range is known to read as zeros - a file fresh from create_npy): blocks of SPARSE_BLOCK bytes that are zero in
+    HBM are neither copied nor written."""
     torch = engine.torch
     if not tensor.is_contiguous():
         raise ValueError("download: the tensor must be contiguous")
@@ -225,18 +240,52 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
         evs = [torch.cuda.Event() for _ in range(N_STAGE)]
         writes = [[] for _ in range(N_STAGE)]
         inflight = []  # (buffer, lo, hi) whose D2H copy has been queued
+        flags, nblk, written = None, 0, 0
+        if sparse and fd is not None and chunk_bytes % SPARSE_BLOCK == 0 and nbytes >= 4 * SPARSE_BLOCK:
+            with torch.cuda.device(engine.device):
+                nblk = nbytes // SPARSE_BLOCK
+                flags = _zero_block_flags(torch, src, nblk)  # (the tail beyond the last whole block is always written)
+
+        def runs_of(lo, hi):
+            """byte ranges [s, e) relative to `lo` of the chunk [lo, hi) that have to be written"""
+            if flags is None:
+                return [(0, hi - lo)]
+            b0, b1 = lo // SPARSE_BLOCK, min(hi // SPARSE_BLOCK, nblk)
+            out, start = [], None
+            for k in range(b0, b1):
+                if flags[k] and start is None:
+                    start = k
+                elif not flags[k] and start is not None:
+                    out.append((start * SPARSE_BLOCK - lo, k * SPARSE_BLOCK - lo))
+                    start = None
+            if start is not None:
+                out.append((start * SPARSE_BLOCK - lo, b1 * SPARSE_BLOCK - lo))
+            if hi > b1 * SPARSE_BLOCK:  # the ragged tail of the tensor
+                if out and out[-1][1] == b1 * SPARSE_BLOCK - lo:
+                    out[-1] = (out[-1][0], hi - lo)
+                else:
+                    out.append((b1 * SPARSE_BLOCK - lo, hi - lo))
+            return out
 
         def drain(b, lo, hi):
+            nonlocal written
             evs[b].synchronize()
             mv = st.views[b]
-            if arr is None:
-                writes[b] = [pool.submit(_pwrite_full, fd, mv[s:e], offset + lo + s) for s, e in _split(hi - lo, nthr)]
-            else:
-                writes[b] = [pool.submit(_copy_out, arr[lo + s:lo + e], mv[s:e]) for s, e in _split(hi - lo, nthr)]
+            writes[b] = []
+            for rs, re_ in runs_of(lo, hi):
+                written += re_ - rs
+                if arr is None:
+                    writes[b] += [pool.submit(_pwrite_full, fd, mv[rs + s:rs + e], offset + lo + rs + s) for s, e in _split(re_ - rs, nthr)]
+                else:
+                    writes[b] += [pool.submit(_copy_out, arr[lo + rs + s:lo + rs + e], mv[rs + s:rs + e]) for s, e in _split(re_ - rs, nthr)]
 
         with torch.cuda.device(engine.device):
-            for i, lo in enumerate(range(0, nbytes, chunk_bytes)):
-                hi, b = min(lo + chunk_bytes, nbytes), i % N_STAGE
+            k = 0  # chunks that are copied (a staging buffer is reused every N_STAGE of THEM)
+            for lo in range(0, nbytes, chunk_bytes):
+                hi = min(lo + chunk_bytes, nbytes)
+                if flags is not None and not runs_of(lo, hi):
+                    continue  # the whole chunk is zero: nothing crosses PCIe, the file keeps its hole
+                b, k = k % N_STAGE, k + 1
                 for f in writes[b]:
                     f.result()  # the writers have emptied this buffer
                 writes[b] = []
@@ -266,6 +315,7 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
             os.close(fd)
     dt_s = time.perf_counter() - t0
     last_transfer[what] = {"bytes": nbytes, "s": dt_s, "GBps": nbytes / dt_s / 1e9, "threads": nthr,
+                           "bytes_written": written, "zero_blocks_skipped": (int(nblk - flags.sum()) if flags is not None else None),
                            "sink": ("host array" if fd is None else "file (pwrite from pinned staging)" if fmap is None
                                     else "file (memcpy from pinned staging into a shared mapping)")}
 
@@ -284,7 +334,8 @@ def create_npy(path: str, dtype, shape) -> int:
     return off
 
 
-def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: bool = False, synced: bool = False) -> None:
+def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: bool = False, synced: bool = False,
+             sparse: bool = True) -> None:
     """np.save(path, tensor) without a host copy of the tensor: header by numpy, payload streamed from HBM.  `dtype`: the
     numpy dtype the file declares (same item size as the tensor's: e.g. uint32 for labels held in an int32 tensor).
     partial: write under `<path>.partial` and rename when complete (a killed run leaves no complete-looking file)."""
@@ -293,6 +344,6 @@ def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: 
         raise ValueError("save_npy: dtype must have the tensor's item size")
     target = path + ".partial" if partial else path
     off = create_npy(target, npdt, tuple(tensor.shape))
-    download(engine, tensor, target, offset=off, what=what, synced=synced)
+    download(engine, tensor, target, offset=off, what=what, synced=synced, sparse=sparse)  # (a fresh file: zero blocks stay holes)
     if partial:
         os.replace(target, path)

@@ -216,16 +216,24 @@ def stats_streamed(engine, labels, n_total: int, budget_bytes: int) -> dict:
     run's (parallel.merge_stats with identity renumbering) - counts, boxes and integer coordinate sums add up across slabs."""
     from .parallel import merge_stats
 
+    import itertools
+
     torch = engine.torch
     Z, Y, X = (int(v) for v in labels.shape)
-    planes = max(1, int(budget_bytes // max(1, Y * X * 4 * 2)))  # uint32 slab + headroom
+    # the device-side accumulators of dlv_cc_stats_raw_dev (52 B per label) come out of the same budget as the label slab
+    acc_bytes = (int(n_total) + 1) * 52
+    planes = max(1, int(max(budget_bytes - acc_bytes, 0) // max(1, Y * X * 4 * 2)))  # uint32 slab + headroom
     ident = np.arange(n_total + 1, dtype=np.uint32)
-    luts, raws, offs = [], [], []
-    for lo in range(0, Z, planes):
-        hi = min(Z, lo + planes)
-        lab = torch.from_numpy(np.ascontiguousarray(labels[lo:hi]).astype(np.uint32).view(np.int32)).to(engine.device)
-        raws.append(engine.cc_stats_raw(lab, n_total))
-        luts.append(ident)
-        offs.append(lo)
-        del lab
-    return merge_stats(luts, raws, offs, (Z, Y, X), n_total)
+    starts = list(range(0, Z, planes))
+
+    def raw_of_slabs():
+        # one slab's raw accumulators at a time: merge_stats folds each into its running sums as zip() hands it over (host
+        # memory O(N), not O(slabs x N) - a cached labelling with millions of components over hundreds of slabs)
+        for lo in starts:
+            hi = min(Z, lo + planes)
+            lab = torch.from_numpy(np.ascontiguousarray(labels[lo:hi]).astype(np.uint32).view(np.int32)).to(engine.device)
+            raw = engine.cc_stats_raw(lab, n_total)
+            del lab
+            yield raw
+
+    return merge_stats(itertools.repeat(ident), raw_of_slabs(), starts, (Z, Y, X), n_total)

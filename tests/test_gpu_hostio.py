@@ -91,6 +91,21 @@ def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads, write_mo
     assert np.array_equal(got[10:20], vol[0, 0, 10:20]) and not got[:10].any() and not got[20:].any()
     with pytest.raises(ValueError):
         hostio.download(eng, dev[:, ::2], host)
+    # sparse files: blocks of 1 MiB that are zero in HBM are not written - the fresh file reads back identically and holds holes
+    big = torch.zeros((40, 512, 1024), dtype=torch.int32, device=eng.device)  # 80 MiB of labels, most of it background
+    big[3, 100:140, 17:900] = torch.arange(40 * 883, dtype=torch.int32, device=eng.device).reshape(40, 883) + 1
+    big[25:27] = 7
+    big[-1, -1, -5:] = 9  # the last bytes of the tensor
+    sp = str(tmp_path / "sparse.npy")
+    hostio.save_npy(eng, big, sp, np.uint32, what="d2h_sparse")
+    assert np.array_equal(np.load(sp), big.cpu().numpy().view(np.uint32))
+    tr = hostio.last_transfer["d2h_sparse"]
+    assert tr["bytes"] == big.numel() * 4 and tr["zero_blocks_skipped"] >= 60 and tr["bytes_written"] <= 12 << 20, tr
+    if write_mode == "pwrite":
+        assert os.stat(sp).st_blocks * 512 < big.numel() * 4 // 2, "the zero blocks should have stayed holes"
+    dense = str(tmp_path / "dense.npy")
+    hostio.save_npy(eng, big, dense, np.uint32, sparse=False)
+    assert open(dense, "rb").read() == open(sp, "rb").read()
     if write_mode == "mmap":
         with pytest.raises(ValueError):  # the file must already have its size (create_npy)
             hostio.download(eng, dev, out, offset=off + 1)
