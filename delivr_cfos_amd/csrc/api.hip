@@ -28,7 +28,9 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
         }
-        size_t want = bytes + (bytes >> 3);  // 12.5 % headroom against regrowth
+        // 12.5 % headroom against regrowth - for the small buffers only: device allocation costs ~28 ms per GB on this platform
+        // (the driver clears what it hands out), and the big ones (activations of a lane, CCL scratch) are sized by the geometry
+        size_t want = bytes + (bytes < ((size_t)256 << 20) ? (bytes >> 3) : 0);
         hipError_t e = hipMalloc(&ctx->ws[slot], want);
         if (e != hipSuccess) {
             want = bytes;

@@ -100,7 +100,7 @@ def test_upload_and_download_round_trip(tmp_path, monkeypatch, threads, write_mo
     hostio.save_npy(eng, big, sp, np.uint32, what="d2h_sparse")
     assert np.array_equal(np.load(sp), big.cpu().numpy().view(np.uint32))
     tr = hostio.last_transfer["d2h_sparse"]
-    assert tr["bytes"] == big.numel() * 4 and tr["zero_blocks_skipped"] >= 60 and tr["bytes_written"] <= 12 << 20, tr
+    assert tr["bytes"] == big.numel() * 4 and tr["zero_blocks_skipped"] >= 0.9 * (80 << 20) // hostio.SPARSE_BLOCK and tr["bytes_written"] <= 12 << 20, tr
     if write_mode == "pwrite":
         assert os.stat(sp).st_blocks * 512 < big.numel() * 4 // 2, "the zero blocks should have stayed holes"
     dense = str(tmp_path / "dense.npy")
@@ -171,13 +171,14 @@ def test_reserve_allocates_what_the_pass_asks_for_and_the_shared_engine_is_one_p
         if reserve:
             eng.reserve(p, shape)
             free1 = torch.cuda.mem_get_info()[0]
-            assert free0 - free1 > 3 * 100 * 2**20  # three lanes of 15 windows x 64^3 voxels x ~400 B of activations
+            assert free0 - free1 > 3 * 2**30  # three lanes of (up to) 64 windows x 64^3 voxels x ~400 B of activations
         eng.sw_infer(p, v, acc)
         out = eng.finalize(acc, None, v, shape, 0.5, 30, 0, out=mask)
         eng.sync()
         assert out.data_ptr() == mask.data_ptr()
         if reserve:
-            assert free1 - torch.cuda.mem_get_info()[0] < 64 * 2**20, "the pass allocated what dlv_reserve_dev should have"
+            # (what is left: window lists, the HSA queues of the lanes' streams on their first use - against the GBs reserved)
+            assert free1 - torch.cuda.mem_get_info()[0] < 512 * 2**20, "the pass allocated what dlv_reserve_dev should have"
         outs.append((acc.cpu().numpy(), mask.cpu().numpy()))
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
