@@ -40,6 +40,7 @@ WORKLOADS = {
     "c3": ((1024, 2048, 2048), (128, 128, 128), 2, False),  # BASELINE configs[2]: 2048x2048x1024 synthetic brain
     "c2": ((512, 512, 512), (128, 128, 128), 1, False),     # BASELINE configs[1]: 512^3 volume
     "tiny": ((128, 256, 256), (64, 64, 64), 5, False),      # plumbing check
+    "tiny_default": ((100, 180, 150), (96, 96, 64), 5, True),  # plumbing check of `default`: padding (192, 192, 192) + the TTA schedule
     # what the reference SHIPS (config.json:24-28,63): windows 96 x 96 x 64 and test-time augmentation - the 13 passes of
     # inference/inference.py:261-279 = 3 distinct passes weighted 5:4:4; one step = all of them
     "default": ((1024, 2048, 2048), (96, 96, 64), 2, True),

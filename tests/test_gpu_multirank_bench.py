@@ -52,6 +52,39 @@ def test_two_ranks_through_torch_distributed_run_match_the_single_rank_line():
         assert c2["mask_checksum"] == c1["mask_checksum"]
     assert j2["value"] > 0 and j2["ms_per_step"] > 0
     assert j2["cpu_baseline"] is None  # the CPU leg is reported at N = 1 only
+    # N = 1: the file -> file walls of the two steps ran on this volume and left the files the next step reads
+    w = j1["step_walls"]
+    assert w and w.get("files_ok") is True and w["step2_wall_s"] > 0 and w["step3_wall_next_brain_s"] > 0, w
+    assert w["first_brain"]["components"] == w["next_brain"]["components"] == w["components"]
+    assert j2["step_walls"] is None
+    # N = 2: where each rank's step went
+    ph = c2["per_rank_phases"]
+    assert len(ph) == 2 and all({"windows_ms", "seam_ms", "finalize_ms", "window_max_gather_ms", "slab_planes"} <= set(p) for p in ph), ph
+
+
+def test_padded_volume_with_tta_schedule_sharded_three_ways_matches_the_single_rank_line():
+    """The shape of the `default` workload (the reference's shipped configuration: windows 96 x 96 x 64, TTA as 3 distinct passes,
+    config.json:24-28,63) at plumbing size: a stack of 100 x 180 x 150 zero-padded to 192^3, on one rank and on three."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    args = ["--steps", "1", "--warmup", "0", "--workload", "tiny_default", "--no-cpu-baseline", "--no-extras", "--no-isolated", "--no-step-walls"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *args], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout + one.stderr
+    j1 = _json_line(one.stdout)
+    env["DLV_BENCH_SAME_DEVICE"] = "1"
+    env["DLV_LANES"] = "1"
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "3", *args],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert three.returncode == 0, three.stdout + three.stderr
+    j3 = _json_line(three.stdout)
+    c1, c3 = j1["config"], j3["config"]
+    assert c1["padded_zyx"] == [192, 192, 192] and c1["volume_zyx"] == [100, 180, 150] and c1["passes_per_step"] == 3 and c1["pass_weights"] == [5, 4, 4]
+    assert c1["windows"] == 3 * 3 * 5 and c3["windows"] == c1["windows"] and c3["windows_skipped"] == c1["windows_skipped"]
+    assert j1["value"] == pytest.approx(100 * 180 * 150 / (j1["ms_per_step"] * 1e-3), rel=1e-6)  # the STACK's voxels, not the padding's
+    assert abs(c3["mask_voxels"] - c1["mask_voxels"]) <= 3, (c1["mask_voxels"], c3["mask_voxels"])
+    assert c1["mask_voxels"] > 0
 
 
 def test_eight_ranks_launched_by_bench_itself_match_the_single_rank_line():
