@@ -326,9 +326,13 @@ __global__ void __launch_bounds__(256) ccl_scan_apply_kernel(u32* __restrict__ c
     }
 }
 
+// The union-find runs IN the label volume (round 6: L == labels; the separate parent array was 4 bytes per voxel of scratch -
+// 17 GB for 2^32 voxels, 0.5 s of device allocation on a process's first labelling).  A root's entry becomes its label here; which
+// entries are roots is recorded in a bit mask (one uint16 per 16 voxels, like bm) for the relabel pass: a non-root entry still
+// holds its root's INDEX, and an index cannot be told from a label by its value.
 __global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L,
                                                                u64 n, const u32* __restrict__ offsets,
-                                                               u32* __restrict__ labels) {
+                                                               u32* __restrict__ labels, unsigned short* __restrict__ rb) {
     const u64 base = (u64)blockIdx.x * RCHUNK + (u64)threadIdx.x * RPT;
     int c = 0;
     unsigned roots = 0;
@@ -341,6 +345,7 @@ __global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const unsigned sh
             roots |= 1u << k;
         }
     }
+    if (base < n) rb[base >> 4] = (unsigned short)roots;  // (RPT == 16: a thread's voxels are one word of the bit masks)
     int total;
     u32 rank = offsets[blockIdx.x] + (u32)block_excl_scan(c, &total);
     while (roots) {
@@ -352,19 +357,19 @@ __global__ void __launch_bounds__(256) ccl_assign_roots_kernel(const unsigned sh
 
 // every voxel of the label volume is written exactly once here (16 voxels = four 16-byte stores per thread): 0 for the
 // background, the root's label for the rest (roots already hold theirs)
-__global__ void __launch_bounds__(256) ccl_relabel_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L,
-                                                          u64 n, u32* __restrict__ labels, bool aligned) {
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const unsigned short* __restrict__ bm, const unsigned short* __restrict__ rb,
+                                                          u64 n, u32* labels, bool aligned) {
     const u64 nch = (n + 15) / 16;
     for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (u64)gridDim.x * blockDim.x) {
         const u64 base = c * 16;
-        const unsigned bits = bm[c];
+        const unsigned bits = bm[c], rbits = rb[c];
         u32 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             v[k] = 0;
             if (bits & (1u << k)) {
-                const u32 r = L[base + k];
-                v[k] = labels[r];  // r == base + k for a root: its label was assigned by ccl_assign_roots_kernel
+                const u32 x = labels[base + k];             // a root: its label (ccl_assign_roots_kernel); else: its root's index
+                v[k] = (rbits & (1u << k)) ? x : labels[x];  // (a root's entry never changes again: racing readers see its label)
             }
         }
         if (aligned && base + 16 <= n) {
@@ -378,18 +383,21 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const unsigned short* 
 }
 
 // The label volume was zeroed (hipMemsetAsync: the fill runs at 6.9 TB/s); only the listed chunks are written
-__global__ void __launch_bounds__(256) ccl_relabel_list_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L, u64 n,
-                                                               u32* __restrict__ labels, const u32* __restrict__ list,
+__global__ void __launch_bounds__(256) ccl_relabel_list_kernel(const unsigned short* __restrict__ bm, const unsigned short* __restrict__ rb, u64 n,
+                                                               u32* labels, const u32* __restrict__ list,
                                                                const u32* __restrict__ list_n, bool aligned) {
     const u32 cnt = *list_n;
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += gridDim.x * blockDim.x) {
         const u64 c = list[t], base = c * 16;
-        const unsigned bits = bm[c];
+        const unsigned bits = bm[c], rbits = rb[c];
         u32 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             v[k] = 0;
-            if (bits & (1u << k)) v[k] = labels[L[base + k]];  // (a root reads its own label: assigned by ccl_assign_roots_kernel)
+            if (bits & (1u << k)) {
+                const u32 x = labels[base + k];             // a root: its label; else: its root's index (the volume is its own parent array)
+                v[k] = (rbits & (1u << k)) ? x : labels[x];
+            }
         }
         if (aligned && base + 16 <= n) {
 #pragma unroll
@@ -404,8 +412,8 @@ __global__ void __launch_bounds__(256) ccl_relabel_list_kernel(const unsigned sh
 // The same label volume with whole-line stores: a wave owns 1024 consecutive voxels and writes them with four store
 // instructions of 64 x 16 contiguous bytes (the kernel above gives every lane 64 contiguous bytes, i.e. four instructions that
 // each touch a quarter of 64 lines).  Needs the 16-byte alignment; the last partial block is written voxel by voxel.
-__global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const unsigned short* __restrict__ bm, const u32* __restrict__ L, u64 n,
-                                                                u32* __restrict__ labels) {
+__global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const unsigned short* __restrict__ bm, const unsigned short* __restrict__ rb, u64 n,
+                                                                u32* labels) {
     const int lane = threadIdx.x & 63;
     const u64 nblk = n / 1024;
     const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -415,18 +423,27 @@ __global__ void __launch_bounds__(256) ccl_relabel_lines_kernel(const unsigned s
         for (int q = 0; q < 4; ++q) {
             const u64 o = base + (u64)q * 256 + (u64)lane * 4;
             const unsigned m = ((unsigned)bm[o >> 4] >> (o & 15)) & 15u;  // this lane's four voxels (four lanes share a word)
+            const unsigned rt = ((unsigned)rb[o >> 4] >> (o & 15)) & 15u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (m) {
-                if (m & 1u) v.x = labels[L[o]];  // a root's label was assigned by ccl_assign_roots_kernel (L[r] == r)
-                if (m & 2u) v.y = labels[L[o + 1]];
-                if (m & 4u) v.z = labels[L[o + 2]];
-                if (m & 8u) v.w = labels[L[o + 3]];
+            if (m) {  // (an entry is a root's label, or the index of its root - whose entry is its label and never changes again)
+                const uint4 x = *reinterpret_cast<const uint4*>(labels + o);
+                if (m & 1u) v.x = (rt & 1u) ? x.x : labels[x.x];
+                if (m & 2u) v.y = (rt & 2u) ? x.y : labels[x.y];
+                if (m & 4u) v.z = (rt & 4u) ? x.z : labels[x.z];
+                if (m & 8u) v.w = (rt & 8u) ? x.w : labels[x.w];
             }
             *reinterpret_cast<uint4*>(labels + o) = v;
         }
     }
     if (wave0 == 0)
-        for (u64 i = nblk * 1024 + lane; i < n; i += 64) labels[i] = ((bm[i >> 4] >> (i & 15)) & 1u) ? labels[L[i]] : 0u;
+        for (u64 i = nblk * 1024 + lane; i < n; i += 64) {
+            u32 v = 0u;
+            if ((bm[i >> 4] >> (i & 15)) & 1u) {
+                const u32 x = labels[i];
+                v = ((rb[i >> 4] >> (i & 15)) & 1u) ? x : labels[x];
+            }
+            labels[i] = v;
+        }
 }
 
 // ---- statistics -------------------------------------------------------------------------------------
@@ -638,16 +655,19 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     const u64 nb = (n + RCHUNK - 1) / RCHUNK;
     char* ws;
-    const size_t parent_bytes = (size_t)n * 4;
     const u64 nch = (n + 15) / 16;
-    const size_t counts_off = (parent_bytes + 255) & ~(size_t)255;
+    // scratch: root counts per renumbering block, their group sums, the two bit masks (foreground, roots), the chunk list - 0.5 B per
+    // voxel.  The union-find's parent array IS the label volume (ccl_assign_roots_kernel)
+    const size_t counts_off = 0;
     const size_t gsum_off = (counts_off + (size_t)(nb + 1) * 4 + 255) & ~(size_t)255;
     const size_t bm_off = (gsum_off + (size_t)((nb + SGRP - 1) / SGRP + 1) * 4 + 255) & ~(size_t)255;
-    const size_t list_off = (bm_off + (size_t)(nch + 4) * 2 + 255) & ~(size_t)255;  // [list_n, pad, list[nch]]
+    const size_t rb_off = (bm_off + (size_t)(nch + 4) * 2 + 255) & ~(size_t)255;
+    const size_t list_off = (rb_off + (size_t)(nch + 4) * 2 + 255) & ~(size_t)255;  // [list_n, pad, list[nch]]
     DLV_TRY(dlv_ws_get(ctx, WS_CCL, list_off + 256 + (size_t)nch * 4 + 256, (void**)&ws));
     u32* list_n = (u32*)(ws + list_off);
     u32* list = (u32*)(ws + list_off + 256);
-    u32* L = (u32*)ws;
+    u32* L = labels_dev;
+    unsigned short* rb = (unsigned short*)(ws + rb_off);  // root bits, one word per 16 voxels (written for every chunk by ccl_assign_roots_kernel)
     u32* counts = (u32*)(ws + counts_off);
     u32* gsum = (u32*)(ws + gsum_off);
     unsigned short* bm = (unsigned short*)(ws + bm_off);  // bit mask of the volume, one word per 16 voxels (ccl_init_kernel)
@@ -677,15 +697,15 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
     hipLaunchKernelGGL(ccl_scan_groups_kernel, dim3(1), dim3(1024), 0, ctx->stream, gsum, ng, counts + nb);
     hipLaunchKernelGGL(ccl_scan_apply_kernel, dim3((unsigned)ng), dim3(256), 0, ctx->stream, counts, nb, gsum);
     DLV_LAUNCH_CHECK(ctx, "ccl_scan_counts_kernel");
-    hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, bm, L, n, counts, labels_dev);
+    hipLaunchKernelGGL(ccl_assign_roots_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, bm, L, n, counts, labels_dev, rb);
     DLV_LAUNCH_CHECK(ctx, "ccl_assign_roots_kernel");
     if (!simple)
-        hipLaunchKernelGGL(ccl_relabel_list_kernel, dim3(gl), dim3(256), 0, ctx->stream, bm, L, n, labels_dev, list, list_n, aligned);
+        hipLaunchKernelGGL(ccl_relabel_list_kernel, dim3(gl), dim3(256), 0, ctx->stream, bm, rb, n, labels_dev, list, list_n, aligned);
     else if (aligned)
         hipLaunchKernelGGL(ccl_relabel_lines_kernel, dim3((unsigned)std::min<u64>((n / 1024 + 3) / 4 + 1, (u64)256 * 32)), dim3(256), 0,
-                           ctx->stream, bm, L, n, labels_dev);
+                           ctx->stream, bm, rb, n, labels_dev);
     else
-        hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, bm, L, n, labels_dev, aligned);
+        hipLaunchKernelGGL(ccl_relabel_kernel, dim3(gs), dim3(256), 0, ctx->stream, bm, rb, n, labels_dev, aligned);
     DLV_LAUNCH_CHECK(ctx, "ccl_relabel_kernel");
     pr.end();
     u32 total = 0;

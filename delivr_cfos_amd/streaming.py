@@ -151,8 +151,9 @@ def run_inference_streamed(engine, dataset_host, pad, stack_zyx, crop_size, over
 
 
 def ccl_bytes_per_voxel() -> int:
-    """uint8 mask + uint32 labels + the union-find / renumbering scratch of dlv_ccl26_dev + statistics"""
-    return 1 + 4 + 8
+    """uint8 mask + uint32 labels (the union-find runs in the label volume itself) + the bit masks, chunk list and renumbering
+    scratch of dlv_ccl26_dev (0.5 B) + the statistics accumulators and slack"""
+    return 1 + 4 + 2
 
 
 def even_slabs(Z: int, n: int):
