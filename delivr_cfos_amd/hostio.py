@@ -53,11 +53,57 @@ def io_threads() -> int:
     return max(2, min(16, (os.cpu_count() or 2)))
 
 
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
+def io_cpus(device_index: int = 0):
+    """CPUs the I/O threads are bound to: those of the NUMA node the GPU hangs on (the pinned staging buffers live there, and a
+    tmpfs / page-cache page is allocated on the node of the CPU that writes it: writers on the other socket read the staging
+    buffer over the socket link and bounce the file's inode lock between sockets - the same write ran at 2.5 or 4.4 GB/s
+    depending on where the scheduler had put the threads).  DLV_IO_NUMA=off disables the binding, =<n> picks the node; None when the
+    node is unknown or the binding is off."""
+    mode = os.environ.get("DLV_IO_NUMA", "auto")
+    if mode == "off":
+        return None
+    try:
+        if mode == "auto":
+            import torch
+
+            pr = torch.cuda.get_device_properties(device_index)
+            with open(f"/sys/bus/pci/devices/{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0/numa_node") as f:
+                node = int(f.read().strip())
+        else:
+            node = int(mode)
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = _parse_cpulist(f.read()) & set(os.sched_getaffinity(0))
+        return cpus or None
+    except Exception:
+        return None
+
+
+def _bind_io_thread(cpus):
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)  # (0: the calling thread)
+        except OSError:
+            pass
+
+
 def _executor() -> ThreadPoolExecutor:
     global _pool
     with _pool_lock:
         if _pool is None or _pool._max_workers != io_threads():
-            _pool = ThreadPoolExecutor(max_workers=io_threads(), thread_name_prefix="dlv-io")
+            _pool = ThreadPoolExecutor(max_workers=io_threads(), thread_name_prefix="dlv-io", initializer=_bind_io_thread, initargs=(io_cpus(),))
         return _pool
 
 

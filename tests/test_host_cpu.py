@@ -599,6 +599,62 @@ def test_range_guard_maps_the_named_layer_to_the_blocks_feeding_it():
     assert next_shifts(0, [0.0] * 18, shifts) is None
 
 
+def test_range_recovery_spares_small_blocks_stops_after_a_futile_blind_step_and_takes_it_back():
+    """range_guard.run_with_range_recovery on a fake engine: (i) a block whose recorded |mean| + 8 sigma would fall below 1 is not
+    moved on no evidence; (ii) a blind step that leaves the same layer overflowing is not repeated - the format falls back to
+    bf16_all with the futile shift taken back; (iii) a hinted step cures the overflow in the format asked for."""
+    from delivr_cfos_amd._lib import DLV_ERANGE, DelivrHipError
+    from delivr_cfos_amd.range_guard import next_shifts, run_with_range_recovery
+
+    peaks = [0.0] * 18
+    peaks[3], peaks[13] = 20.0, 300.0   # both small: 20 * 2^-6 < 1 (spared), 300 * 2^-6 = 4.7 (may move)
+    assert next_shifts(14, peaks, [0] * 18) == {13: 6}
+    peaks[13] = 30.0
+    assert next_shifts(14, peaks, [0] * 18) is None
+
+    class FakeEngine:
+        def __init__(self, layer, peaks, cured_by):
+            self.layer, self.peaks, self.cured_by = layer, peaks, cured_by
+            self.shifts, self.log = [0] * 18, []
+
+        def range_report(self):
+            return self.layer, list(self.peaks)
+
+        def conv_shifts(self):
+            return list(self.shifts)
+
+        def set_conv_shift(self, p, k):
+            self.log.append((p, k))
+            self.shifts[p] = k
+
+    def runner(eng, ran):
+        def run(prec):
+            ran.append((prec, list(eng.shifts)))
+            if prec != "bf16_all" and not eng.cured_by(eng.shifts):
+                raise DelivrHipError(DLV_ERANGE, "fp16 range exceeded")
+        return run
+
+    # (ii) nothing recorded for the producers of layer 18 -> one blind step of 6 bits on block 17, still overflowing -> stop
+    eng, ran, resets = FakeEngine(18, [0.0] * 18, lambda s: False), [], []
+    out = run_with_range_recovery(eng, "fp16", runner(eng, ran), lambda: resets.append(1), log=lambda m: None)
+    assert out == "bf16_all" and [p for p, _ in ran] == ["fp16", "fp16", "bf16_all"]
+    assert eng.log == [(17, 6), (17, 0)] and ran[-1][1] == [0] * 18  # the futile shift is taken back before the last resort
+    # (iii) a hint: block 15 reported 3e6 -> 12 bits, cured, the mixed format stays the mixed format
+    pk = [0.0] * 18
+    pk[15] = 3.0e6
+    eng, ran = FakeEngine(16, pk, lambda s: s[15] >= 12), []
+    out = run_with_range_recovery(eng, "bf16", runner(eng, ran), lambda: None, log=lambda m: None)
+    assert out == "bf16" and eng.log == [(15, 12)] and [p for p, _ in ran] == ["bf16", "bf16"]
+    # bf16_all never recovers: its range errors are raised
+    eng = FakeEngine(5, [0.0] * 18, lambda s: False)
+    import pytest
+
+    with pytest.raises(DelivrHipError):
+        def always(prec):
+            raise DelivrHipError(DLV_ERANGE, "x")
+        run_with_range_recovery(eng, "bf16_all", always, lambda: None, log=lambda m: None)
+
+
 def test_c_abi_range_policy_equals_the_python_one():
     """dlv_range_next_shifts (api.hip; what dlv_range_recover / dlv_comm_range_recover apply for hosts without run_inference) against
     range_guard.next_shifts on every layer x a set of peak / shift patterns (pure host logic: no GPU)."""
