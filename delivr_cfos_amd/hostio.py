@@ -65,11 +65,10 @@ def _parse_cpulist(text: str):
 
 
 def io_cpus(device_index: int = 0):
-    """CPUs the I/O threads are bound to: those of the NUMA node the GPU hangs on (the pinned staging buffers live there, and a
-    tmpfs / page-cache page is allocated on the node of the CPU that writes it: writers on the other socket read the staging
-    buffer over the socket link and bounce the file's inode lock between sockets - the same write ran at 2.5 or 4.4 GB/s
-    depending on where the scheduler had put the threads).  DLV_IO_NUMA=off disables the binding, =<n> picks the node; None when the
-    node is unknown or the binding is off."""
+    """CPUs the I/O threads are bound to: those of the NUMA node the GPU hangs on (a two-socket host: the pinned staging buffers
+    and the copy engine's DMA target live there).  Measured (profiles/r06k_io_numa_probe.json, 8 GB from / to tmpfs, four rounds
+    interleaved): reads 22.5-24.7 GB/s unbound, 27.5-34.8 bound; writes 3.5-6.6 unbound, 4.3-6.7 bound - the one-file write rate is
+    the kernel's and stays noisy.  DLV_IO_NUMA=off disables the binding, =<n> picks the node; None when the node is unknown."""
     mode = os.environ.get("DLV_IO_NUMA", "auto")
     if mode == "off":
         return None

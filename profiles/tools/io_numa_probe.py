@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does binding hostio's reader / writer threads to the GPU's NUMA node steady the one-file write rate?  8 GB from HBM into a
-fresh file on /dev/shm and back, three times per setting, settings interleaved (DLV_IO_NUMA=off | auto)."""
+fresh file on /dev/shm and back, four times per setting, settings interleaved (DLV_IO_NUMA=off | auto | 0 | 1)."""
 import json
 import os
 import sys
@@ -25,9 +25,9 @@ cp = hostio.io_cpus()
 out["gpu_node_cpus"] = None if cp is None else f"{min(cp)}-{max(cp)} ({len(cp)} cpus)"
 t = torch.randint(1, 2**31 - 1, (2048, 1024, 1024), dtype=torch.int32, device="cuda")  # 8 GiB, no zero block
 path = "/dev/shm/dlv_io_numa_probe.npy"
-res = {"off": [], "auto": []}
-for rep in range(3):
-    for mode in ("off", "auto"):
+res = {"off": [], "auto": [], "0": [], "1": []}
+for rep in range(4):
+    for mode in ("off", "auto", "0", "1"):
         os.environ["DLV_IO_NUMA"] = mode
         hostio._pool = None  # the next transfer builds its pool under this setting
         if os.path.exists(path):
