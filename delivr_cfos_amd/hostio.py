@@ -102,6 +102,8 @@ def _executor() -> ThreadPoolExecutor:
     global _pool
     with _pool_lock:
         if _pool is None or _pool._max_workers != io_threads():
+            if _pool is not None:
+                _pool.shutdown(wait=False)
             _pool = ThreadPoolExecutor(max_workers=io_threads(), thread_name_prefix="dlv-io", initializer=_bind_io_thread, initargs=(io_cpus(),))
         return _pool
 
@@ -113,6 +115,25 @@ class _Stage:
         self.bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(n)]
         self.views = [memoryview(b.numpy()) for b in self.bufs]
         self.nbytes = nbytes
+
+
+def _transfer_lock(engine):
+    """one transfer at a time per engine: its staging ring is shared (a label volume streaming out from a side thread must not
+    meet an upload of the next step in the same buffers)"""
+    lock = getattr(engine, "_io_lock", None)
+    if lock is None:
+        lock = engine._io_lock = threading.Lock()
+    return lock
+
+
+def _settle(futures) -> None:
+    """wait for reader / writer tasks that are still running when a transfer ends in an error: the file descriptor and the staging
+    buffers they use are about to go"""
+    for f in futures:
+        try:
+            f.result()
+        except Exception:
+            pass
 
 
 def _stage_of(engine, chunk_bytes: int) -> _Stage:
@@ -184,15 +205,17 @@ def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk
     if nbytes == 0:
         return out
     dst = out.reshape(-1).view(torch.uint8)
-    st = _stage_of(engine, chunk_bytes)
     pool, nthr = _executor(), io_threads()
     t0 = time.perf_counter()
     if path is not None:
         fd = os.open(path, os.O_RDONLY)
+    pending = []  # (buffer index, byte range, futures) whose reads are in flight
+    lock = _transfer_lock(engine)
+    lock.acquire()
     try:
+        st = _stage_of(engine, chunk_bytes)
         copy_stream = torch.cuda.Stream(device=engine.device)
         evs = [torch.cuda.Event() for _ in range(N_STAGE)]
-        pending = []  # (buffer index, byte range, futures) whose reads are in flight
 
         def fill(b, lo, hi):
             mv = st.views[b]
@@ -219,6 +242,9 @@ def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk
                 finish(*pending.pop(0))
             copy_stream.synchronize()
     finally:
+        for item in pending:
+            _settle(item[3])
+        lock.release()
         if fd is not None:
             os.close(fd)
     dt_s = time.perf_counter() - t0
@@ -266,11 +292,13 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
         if own_fd:
             os.close(fd)
         return
-    st = _stage_of(engine, chunk_bytes)
     pool, nthr = _executor(), (io_threads() if isinstance(dst, np.ndarray) else min(io_threads(), WRITE_THREADS))
     writes = None
     t0 = time.perf_counter()
+    lock = _transfer_lock(engine)
+    lock.acquire()
     try:
+        st = _stage_of(engine, chunk_bytes)
         if fd is not None and WRITE_MODE == "mmap":
             import mmap
 
@@ -353,6 +381,9 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
                 fmap.flush()
             os.fsync(fd)
     finally:
+        for w in (writes or []):
+            _settle(w)
+        lock.release()
         if fmap is not None:
             arr = writes = None  # (the futures hold slices of the mapping)
             try:
@@ -391,6 +422,12 @@ def save_npy(engine, tensor, path: str, dtype=None, what: str = "d2h", partial: 
     if npdt.itemsize != tensor.element_size():
         raise ValueError("save_npy: dtype must have the tensor's item size")
     target = path + ".partial" if partial else path
+    if tensor.numel() == 0:  # (nothing to map or stream: numpy writes the header of the empty array)
+        with open(target, "wb") as fh:
+            np.save(fh, np.empty(tuple(tensor.shape), dtype=npdt))
+        if partial:
+            os.replace(target, path)
+        return
     off = create_npy(target, npdt, tuple(tensor.shape))
     download(engine, tensor, target, offset=off, what=what, synced=synced, sparse=sparse)  # (a fresh file: zero blocks stay holes)
     if partial:
