@@ -64,7 +64,7 @@ def _parse_cpulist(text: str):
     return cpus
 
 
-def io_cpus(device_index: int = 0):
+def io_cpus(device_index: Optional[int] = None):
     """CPUs the I/O threads are bound to: those of the NUMA node the GPU hangs on (a two-socket host: the pinned staging buffers
     and the copy engine's DMA target live there).  Measured (profiles/r06k_io_numa_probe.json, 8 GB from / to tmpfs, four rounds
     interleaved): reads 22.5-24.7 GB/s unbound, 27.5-34.8 bound; writes 3.5-6.6 unbound, 4.3-6.7 bound - the one-file write rate is
@@ -76,7 +76,7 @@ def io_cpus(device_index: int = 0):
         if mode == "auto":
             import torch
 
-            pr = torch.cuda.get_device_properties(device_index)
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device() if device_index is None else device_index)  # (one process = one device)
             with open(f"/sys/bus/pci/devices/{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0/numa_node") as f:
                 node = int(f.read().strip())
         else:
