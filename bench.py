@@ -761,6 +761,36 @@ def main():
             fence()
             extras["gaussian_blend_pass_ms"] = 1e3 * (time.perf_counter() - t0)
             del wsum, acc_g
+        # the configuration the reference SHIPS on the same brain (config.json:24-28,63: windows 96 x 96 x 64, test-time
+        # augmentation = 13 passes = 3 distinct ones weighted 5:4:4; `--workload default` is the full bench of it): one warm-up
+        # pass (the shapes' workspaces), then one timed inference of the volume = 3 passes + finalize
+        if args.workload == "c3" and not args.dense and params is not None:
+            d_roi = (96, 96, 64)
+            d_pad = padded_shape(stack, d_roi)
+            vol_d = torch.zeros(d_pad, dtype=torch.uint16, device=eng.device)
+            vol_d[:Z, :Y, :X] = vol
+            acc_d = torch.zeros(d_pad, dtype=torch.float32, device=eng.device)
+            qs = [eng.make_sw_params(d_pad, d_roi, 0.5, flip, 0, args.precision, repeat=rep_n) for flip, rep_n in pass_schedule(True)]
+            eng.sw_infer(qs[0], vol_d, acc_d)
+            fence()
+            acc_d.zero_()
+            fence()
+            t0 = time.perf_counter()
+            for q in qs:
+                st_d = eng.sw_infer(q, vol_d, acc_d)
+            mask_d = eng.finalize(acc_d, None, vol_d, stack, 0.5, 30, zb)
+            fence()
+            dt_d = time.perf_counter() - t0
+            act_d = st_d["n_windows"] - st_d["n_skipped"]
+            pv_d = float(d_roi[0] * d_roi[1] * d_roi[2]) * act_d * len(qs) / dt_d
+            pv_here = tile_vox * n_active * n_passes / (elapsed / args.steps)
+            extras["default_config"] = {
+                "what": "the reference's shipped configuration on this brain: windows 96x96x64, TTA (13 passes = 3 distinct passes weighted "
+                        f"5:4:4), volume zero-padded to {d_pad[0]}x{d_pad[1]}x{d_pad[2]}; one inference = 3 passes + finalize",
+                "ms_per_inference": 1e3 * dt_d, "voxels_per_s": vox / dt_d, "windows": st_d["n_windows"], "windows_skipped": st_d["n_skipped"],
+                "patch_voxels_per_s": pv_d, "patch_voxels_per_s_over_this_line": pv_d / pv_here,
+                "mask_voxels": int(mask_d.sum(dtype=torch.int64))}
+            del vol_d, acc_d, mask_d
 
     walls = None
     if not args.no_step_walls and world == 1 and not dist_mode:
