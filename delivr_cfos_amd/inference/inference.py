@@ -174,6 +174,7 @@ def run_inference(
                   f"{budget / 2**30:.1f} GiB: streaming {n_slabs} Z-slabs through the device")
     resident = not sharded and stream_plan is None
     output_image = count_map = mask_buf = None
+    prealloc_t = {}
     if resident:
         # Device allocation is not free here (~28 ms per GB: the driver clears what it hands out) and this step needs ~70 GB for a
         # 1024 x 2048 x 2048 brain - sums, the pass's activation workspaces, the finalize maps.  A second thread allocates them
@@ -186,12 +187,16 @@ def run_inference(
         def preallocate():
             try:
                 with torch.cuda.device(eng.device):
+                    t_a = time.perf_counter()
                     side["acc"] = torch.zeros(pad[2:], dtype=torch.float32, device=eng.device)
                     if need_count:
                         side["cnt"] = torch.zeros(pad[2:], dtype=cm_dtype, device=eng.device)
                     side["mask"] = torch.empty(tuple(stack_shape[2:]), dtype=torch.uint8, device=eng.device)
+                    torch.cuda.current_stream(eng.device).synchronize()
+                    t_b = time.perf_counter()
                     eng.reserve(eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision), stack_shape[2:])
                     torch.cuda.current_stream(eng.device).synchronize()
+                    side["t"] = {"prealloc_torch_s": t_b - t_a, "prealloc_reserve_s": time.perf_counter() - t_b}
             except Exception as exc:  # re-raised on the main thread
                 side_err.append(exc)
 
@@ -204,6 +209,7 @@ def run_inference(
         if side_err:
             raise side_err[0]
         output_image, count_map, mask_buf = side["acc"], side.get("cnt"), side["mask"]
+        prealloc_t = side.get("t", {})
         mark("upload+alloc")
     if need_count and cm_dtype == torch.uint8:
         # uint8 like the reference's LOAD_ALL_RAM map (:241): refuse geometries whose multiplicity cannot be held
@@ -359,6 +365,6 @@ def run_inference(
         dist.barrier()
     mark("finalize+write")
     run_inference.last_timings = {"total_s": marks[-1][1] - marks[0][1],
-                                  **{f"{b[0]}_s": b[1] - a[1] for a, b in zip(marks, marks[1:])}}
+                                  **{f"{b[0]}_s": b[1] - a[1] for a, b in zip(marks, marks[1:])}, **prealloc_t}
     print(f"{datetime.datetime.now()} : Blob Detection finished")
     return testing_session_path
