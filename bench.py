@@ -296,7 +296,8 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels):
         log = io.StringIO()
         settings = {"postprocessing": {"output_location": post_dir}}
         runs = []
-        # twice: the FIRST brain of a process (fresh context: every workspace is allocated - ~28 ms per GB on this platform) and the
+        # twice: the FIRST brain of this process (fresh context: every workspace is allocated - slow in a process that has released
+        # device memory before, as this one has; free in a fresh process: profiles/r06s_first_brain_probe.json) and the
         # NEXT one (python -m delivr_cfos_amd loops over brains: the shared engine and torch's allocator keep what they allocated)
         for which in ("first_brain", "next_brain"):
             shutil.rmtree(out_dir, ignore_errors=True)

@@ -28,8 +28,8 @@ int dlv_ws_get(dlv_ctx* ctx, int slot, size_t bytes, void** out) {
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
         }
-        // 12.5 % headroom against regrowth - for the small buffers only: device allocation costs ~28 ms per GB on this platform
-        // (the driver clears what it hands out), and the big ones (activations of a lane, CCL scratch) are sized by the geometry
+        // 12.5 % headroom against regrowth - for the small buffers only: the big ones (activations of a lane, CCL scratch) are sized
+        // by the geometry, and a regrowth (hipFree + hipMalloc) is what makes later allocations slow (profiles/r06r_alloc_probe2.json)
         size_t want = bytes + (bytes < ((size_t)256 << 20) ? (bytes >> 3) : 0);
         hipError_t e = hipMalloc(&ctx->ws[slot], want);
         if (e != hipSuccess) {

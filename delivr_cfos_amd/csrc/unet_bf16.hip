@@ -1811,8 +1811,8 @@ int dlv_pack_weights_bf16(dlv_ctx* ctx) {
     return pack_weights_16<PF16>(ctx);
 }
 
-// the workspaces `lanes` pipeline lanes of a 16-bit forward of B windows of d x h x w will ask for (dlv_reserve_dev): hipMalloc
-// costs ~28 ms per GB on this platform (the driver clears what it hands out) and a pass needs ~10 GB per lane
+// the workspaces `lanes` pipeline lanes of a 16-bit forward of B windows of d x h x w will ask for (dlv_reserve_dev): a pass needs
+// ~10 GB per lane, and a large hipMalloc that follows a release of device memory can take seconds (profiles/r06r_alloc_probe2.json)
 int dlv_unet_reserve_16(dlv_ctx* ctx, int B, int d, int h, int w, int lanes) {
     if (!ctx->weights_loaded && ctx->features[1] == 0) return DLV_OK;  // (channel counts unknown before dlv_unet_load / alloc_blob)
     const Ws16 wsz = ws16_bytes(ctx->features, B, d, h, w, nullptr);

@@ -133,8 +133,8 @@ _shared_engines: Dict[int, "HipEngine"] = {}
 def shared_engine(device: int = 0) -> "HipEngine":
     """The process-wide engine of a device.  run_inference and count_blobs use it by default, so that one `python -m
     delivr_cfos_amd` run keeps its context between steps and brains: the workspaces of a pass (~35 GB) and of the labelling
-    (~20 GB) and the pinned staging ring are allocated once (device allocation costs ~28 ms per GB here - 1-2 s per step
-    otherwise).  The reference's counterpart is PyTorch's caching allocator living as long as the process."""
+    (~2 GB) and the pinned staging ring are allocated once and never handed back to the driver in between (large allocations
+    that follow a release took up to seconds on this platform: profiles/r06r_alloc_probe2.json).  The reference's counterpart is PyTorch's caching allocator living as long as the process."""
     eng = _shared_engines.get(int(device))
     if eng is None or eng.ctx is None:
         eng = HipEngine(int(device))

@@ -176,10 +176,12 @@ def run_inference(
     output_image = count_map = mask_buf = None
     prealloc_t = {}
     if resident:
-        # Device allocation is not free here (~28 ms per GB: the driver clears what it hands out) and this step needs ~70 GB for a
-        # 1024 x 2048 x 2048 brain - sums, the pass's activation workspaces, the finalize maps.  A second thread allocates them
-        # while this one reads the volume (preads -> pinned staging -> HBM, hostio.py); a process that has already served a brain
-        # of this size finds all of it in the shared engine and in torch's caching allocator.
+        # This step needs ~65 GB of device memory for a 1024 x 2048 x 2048 brain - sums, the pass's activation workspaces, the
+        # finalize maps.  Fresh memory costs nothing (16 GiB: 0.3 ms), but in a long-lived process whose allocators have handed
+        # memory back to the driver large allocations took up to seconds (profiles/r06r_alloc_probe2.json: 2.25 s for the first
+        # 16 GiB after a release; 1.2-1.8 s for this step's buffers inside the bench process).  A second thread allocates them while
+        # this one reads the volume (preads -> pinned staging -> HBM, hostio.py), and nothing is handed back between brains: the
+        # shared engine keeps its workspaces, torch's caching allocator its blocks.
         import threading
 
         side, side_err = {}, []

@@ -396,9 +396,10 @@ int dlv_prof_reset(dlv_ctx* ctx);
 int dlv_prof_report(dlv_ctx* ctx, dlv_prof_entry* entries, int capacity, int* n_out); /* synchronous */
 
 /* Allocates now what a pass with these parameters (window shape, precision, batch; dlv_set_lanes) and the finalize of a Z x Y x X
- * stack (0s: none) will ask for later - ~10 GB of activations per pipeline lane, the erosion's distance map.  Device allocation
- * costs ~28 ms per GB on this platform (the driver clears what it hands out): a host calls this from a second thread while it
- * reads the volume (inference/inference.py does), and a context that is kept between brains pays it once.  Optional: the pass
+ * stack (0s: none) will ask for later - ~10 GB of activations per pipeline lane, the erosion's distance map.  Fresh device memory
+ * is free to allocate, memory that went back to the driver is not (up to seconds for tens of GB in a long-lived process:
+ * profiles/r06r_alloc_probe2.json): a host calls this from a second thread while it reads the volume (inference/inference.py
+ * does), and keeps one context per device for all its volumes so that nothing is released in between.  Optional: the pass
  * allocates on demand otherwise.  The ctx must not be used by another thread meanwhile.  No reference counterpart (PyTorch's
  * caching allocator plays this role there, inference/inference.py:240-247). */
 int dlv_reserve_dev(dlv_ctx* ctx, const dlv_sw_params* p, int Z, int Y, int X);
