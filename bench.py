@@ -251,7 +251,53 @@ def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, cro
     }
 
 
-def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels):
+def step_walls_pair(spec, sd):
+    """run_inference + count_blobs on the file spec["nifti"], twice (first brain of the process, next brain): wall clock,
+    breakdown and transfer rates of each call"""
+    import contextlib
+    import io
+    import shutil
+
+    from delivr_cfos_amd import hostio
+    from delivr_cfos_amd.count_blobs import count_blobs
+    from delivr_cfos_amd.inference.inference import run_inference
+
+    Z, Y, X = spec["stack"]
+    log = io.StringIO()
+    settings = {"postprocessing": {"output_location": spec["post_dir"]}}
+    runs = []
+    for which in ("first_brain", "next_brain"):
+        shutil.rmtree(spec["out_dir"], ignore_errors=True)
+        shutil.rmtree(spec["post_dir"], ignore_errors=True)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(log):  # (the step's own progress lines: bench.py prints ONE line)
+            run_inference([spec["nifti"]], spec["out_dir"], (1, 1, Z, Y, X), comment="brain", tta=bool(spec["tta"]),
+                          crop_size=tuple(spec["roi"]), state_dict={"state_dict": sd}, precision=spec["precision"])
+        step2 = time.perf_counter() - t0
+        t2 = dict(getattr(run_inference, "last_timings", {}))
+        xfer = {k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_volume", "d2h_mask")}
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(log):
+            n_comp = count_blobs(settings, spec["out_dir"], 0, "brain", (1, 1, Z, Y, X))
+        step3 = time.perf_counter() - t0
+        t3 = dict(getattr(count_blobs, "last_timings", {}))
+        xfer.update({k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_mask", "d2h_labels")})
+        runs.append({"which": which, "step2_wall_s": step2, "step3_wall_s": step3, "step2_breakdown": t2, "step3_breakdown": t3,
+                     "transfers": xfer, "components": int(n_comp)})
+    return runs
+
+
+def step_walls_child(spec_json):
+    """`python bench.py --step-walls-child <spec>`: the two steps on two brains in a process that has done nothing else"""
+    spec = json.loads(spec_json)
+    from delivr_cfos_amd.weights import random_state_dict, trained_like_state_dict
+
+    sd = trained_like_state_dict() if spec["weights"] == "trained-like" else random_state_dict(seed=0)
+    runs = step_walls_pair(spec, sd)
+    print(json.dumps({"step_walls_child": runs}))
+
+
+def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels, weights_name):
     """File -> file wall-clock of the two steps the reference's caller sees (__main__.py:133-140,166): `run_inference`
     (masked_nifti.npy -> binaries.npy) and `count_blobs` (binaries.npy -> <brain>-<N>-cc3d.npy + statistics + CSV) on THIS
     volume, files on tmpfs (/dev/shm; $DLV_BENCH_TMP overrides), so that what is timed is the step's own host work - reads,
@@ -290,33 +336,26 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels):
         write_volume_s = time.perf_counter() - t0
         if os.path.getsize(nifti) != 128 + int(vol.numel()) * 2:
             return {"skipped": "masked_nifti.npy: numpy's header is not the 128 bytes the reference assumes (inference.py:234)"}
-        import contextlib
-        import io
+        # Two brains in a row (python -m delivr_cfos_amd loops over brains: the shared engine and torch's allocator keep what they
+        # allocated), in a FRESH child process - what the CLI is: this process has run a benchmark, holds ~100 GB in caches, and
+        # its late allocations are slow (profiles/r06r_alloc_probe2.json), which is not what a user's first brain meets.  The child is
+        # started before it touches the GPU (bench.py --step-walls-child); $DLV_BENCH_WALLS_INPROC=1 runs the pair in this process.
+        spec = {"nifti": nifti, "out_dir": out_dir, "post_dir": post_dir, "stack": [Z, Y, X], "roi": list(roi), "tta": bool(tta),
+                "precision": precision, "weights": weights_name}
+        if os.environ.get("DLV_BENCH_WALLS_INPROC") == "1":
+            runs = step_walls_pair(spec, sd)
+            where = "this process (after the benchmark)"
+        else:
+            import subprocess
 
-        log = io.StringIO()
-        settings = {"postprocessing": {"output_location": post_dir}}
-        runs = []
-        # twice: the FIRST brain of this process (fresh context: every workspace is allocated - slow in a process that has released
-        # device memory before, as this one has; free in a fresh process: profiles/r06s_first_brain_probe.json) and the
-        # NEXT one (python -m delivr_cfos_amd loops over brains: the shared engine and torch's allocator keep what they allocated)
-        for which in ("first_brain", "next_brain"):
-            shutil.rmtree(out_dir, ignore_errors=True)
-            shutil.rmtree(post_dir, ignore_errors=True)
-            t0 = time.perf_counter()
-            with contextlib.redirect_stdout(log):  # (the step's own progress lines: bench.py prints ONE line)
-                run_inference([nifti], out_dir, (1, 1, Z, Y, X), comment="brain", tta=bool(tta), crop_size=tuple(roi),
-                              state_dict={"state_dict": sd}, precision=precision)
-            step2 = time.perf_counter() - t0
-            t2 = dict(getattr(run_inference, "last_timings", {}))
-            xfer = {k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_volume", "d2h_mask")}
-            t0 = time.perf_counter()
-            with contextlib.redirect_stdout(log):
-                n_comp = count_blobs(settings, out_dir, 0, "brain", (1, 1, Z, Y, X))
-            step3 = time.perf_counter() - t0
-            t3 = dict(getattr(count_blobs, "last_timings", {}))
-            xfer.update({k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_mask", "d2h_labels")})
-            runs.append({"which": which, "step2_wall_s": step2, "step3_wall_s": step3, "step2_breakdown": t2, "step3_breakdown": t3,
-                         "transfers": xfer, "components": int(n_comp)})
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--step-walls-child", json.dumps(spec)], capture_output=True,
+                               text=True, timeout=1800)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"step_walls_child"')]
+            if r.returncode != 0 or not lines:
+                return {"skipped": f"child process failed (rc {r.returncode}): {r.stderr[-600:]}"}
+            runs = json.loads(lines[-1])["step_walls_child"]
+            where = "a fresh child process (python bench.py --step-walls-child)"
+        n_comp = runs[-1]["components"]
         # the files the next step / the reference's consumers read
         binaries = np.load(os.path.join(out_dir, "brain", "binary_segmentations", "binaries.npy"), mmap_mode="r")
         lab_path = os.path.join(post_dir, f"brain-{n_comp}-cc3d.npy")
@@ -338,6 +377,7 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels):
                 "d2h_labels": tr.get("d2h_labels"), "write_input_volume_s": write_volume_s, "components": int(n_comp),
                 "label_dtype": str(labels.dtype), "mask_voxels_in_file": fg, "files_ok": files_ok, "files_on": base,
                 "io_threads": {"read": hostio.io_threads(), "write": hostio.WRITE_THREADS},
+                "process": where,
                 "what": "run_inference(masked_nifti.npy -> binaries.npy) and count_blobs(binaries.npy -> labels .npy, stats pickle, CSV) "
                         "called as python -m delivr_cfos_amd calls them, files on tmpfs; wall clock of each call - for the first brain of "
                         "a process (fresh context: workspaces allocated) and for the next one (context, workspaces and pinned staging kept)"}
@@ -369,9 +409,14 @@ def main():
     ap.add_argument("--diag", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B runs: a kernel-selection switch of include/delivr_hip_diag.h (dlv_diag_set) for the benchmark's engine, e.g. "
                          "--diag fuse_levels=1; recorded in config.diag")
+    ap.add_argument("--step-walls-child", default=None, help=argparse.SUPPRESS)  # (internal: the fresh process of `step_walls`)
     ap.add_argument("--no-step-walls", action="store_true", help="skip the file -> file wall-clock of run_inference and count_blobs "
                     "on this volume (N = 1; ~30 GiB of files on /dev/shm for c3)")
     args = ap.parse_args()
+
+    if args.step_walls_child:
+        step_walls_child(args.step_walls_child)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the contract's launch line as a CHILD process - before this
@@ -796,7 +841,7 @@ def main():
     walls = None
     if not args.no_step_walls and world == 1 and not dist_mode:
         try:
-            walls = step_walls(eng, vol, stack, shape, roi, tta, args.precision, sd, mask_voxels)
+            walls = step_walls(eng, vol, stack, shape, roi, tta, args.precision, sd, mask_voxels, weights_name)
         except Exception as exc:  # reported, never fatal for the metric
             walls = {"skipped": f"failed: {exc!r}"}
 
