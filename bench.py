@@ -284,6 +284,36 @@ def step_walls_pair(spec, sd):
         xfer.update({k: dict(v) for k, v in hostio.last_transfer.items() if k in ("h2d_mask", "d2h_labels")})
         runs.append({"which": which, "step2_wall_s": step2, "step3_wall_s": step3, "step2_breakdown": t2, "step3_breakdown": t3,
                      "transfers": xfer, "components": int(n_comp)})
+    # ... and three brains the way python -m delivr_cfos_amd runs a batch: while one brain's passes run, the next volume is read into
+    # HBM and the previous binaries.npy streams out (run_inference prefetch / defer_write); the label files stream out behind the
+    # next brain's labelling (count_blobs defer_write).  Per-brain wall = total / 3, every file complete (wait_deferred) inside it.
+    nb = int(spec.get("pipelined_brains", 3))
+    if nb > 0:
+        names = [f"pipe{k}" for k in range(nb)]
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(log):
+            for k, name in enumerate(names):
+                run_inference([spec["nifti"]], spec["out_dir"], (1, 1, Z, Y, X), comment=name, tta=bool(spec["tta"]), crop_size=tuple(spec["roi"]),
+                              state_dict={"state_dict": sd}, precision=spec["precision"], prefetch=spec["nifti"] if k + 1 < nb else None,
+                              defer_write=True)
+            hostio.wait_deferred()
+        p2 = (time.perf_counter() - t0) / nb
+        t0 = time.perf_counter()
+        comps = []
+        with contextlib.redirect_stdout(log):
+            for k, name in enumerate(names):
+                comps.append(int(count_blobs(settings, spec["out_dir"], k, name, (1, 1, Z, Y, X), defer_write=True)))
+            hostio.wait_deferred()
+        p3 = (time.perf_counter() - t0) / nb
+        same = all(c == runs[-1]["components"] for c in comps) and all(
+            os.path.isfile(os.path.join(spec["post_dir"], f"{name}-{c}-cc3d.npy")) for name, c in zip(names, comps))
+        for name in names:  # (the sequential brain's files stay for the caller's check)
+            shutil.rmtree(os.path.join(spec["out_dir"], name), ignore_errors=True)
+        for f in os.listdir(spec["post_dir"]):
+            if f.startswith("pipe") or "_pipe" in f:
+                os.remove(os.path.join(spec["post_dir"], f))
+        runs.append({"which": "pipelined", "brains": nb, "step2_per_brain_s": p2, "step3_per_brain_s": p3, "files_ok": bool(same),
+                     "components": comps[-1]})
     return runs
 
 
@@ -310,7 +340,7 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels, wei
     from delivr_cfos_amd.inference.inference import run_inference
 
     Z, Y, X = stack
-    need = int(vol.numel()) * 2 + Z * Y * X * (1 + 4) + (1 << 30)
+    need = int(vol.numel()) * 2 + 4 * Z * Y * X * (1 + 4) + (1 << 30)  # (input + the outputs of the sequential brain and of three pipelined ones)
     base = os.environ.get("DLV_BENCH_TMP") or "/dev/shm"
     try:
         free = shutil.disk_usage(base).free
@@ -355,6 +385,7 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels, wei
                 return {"skipped": f"child process failed (rc {r.returncode}): {r.stderr[-600:]}"}
             runs = json.loads(lines[-1])["step_walls_child"]
             where = "a fresh child process (python bench.py --step-walls-child)"
+        pipe = runs.pop() if runs and runs[-1].get("which") == "pipelined" else None
         n_comp = runs[-1]["components"]
         # the files the next step / the reference's consumers read
         binaries = np.load(os.path.join(out_dir, "brain", "binary_segmentations", "binaries.npy"), mmap_mode="r")
@@ -367,12 +398,15 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels, wei
         files_ok = bool(binaries.shape == (Z, Y, X) and binaries.dtype == np.uint8 and fg == int(mask_voxels) and labels.shape == (Z, Y, X)
                         and n_lab == int(n_comp) and runs[0]["components"] == runs[1]["components"]
                         and os.path.isfile(os.path.join(post_dir, "brain-stats.pickle"))
-                        and os.path.isfile(post_dir + f"({Z}, {Y}, {X})_brain.csv"))
+                        and os.path.isfile(post_dir + f"({Z}, {Y}, {X})_brain.csv") and (pipe is None or pipe["files_ok"]))
         first, nxt = runs
         tr = nxt["transfers"]
         return {"step2_wall_s": first["step2_wall_s"], "step3_wall_s": first["step3_wall_s"],
                 "step2_wall_next_brain_s": nxt["step2_wall_s"], "step3_wall_next_brain_s": nxt["step3_wall_s"],
                 "first_brain": first, "next_brain": nxt,
+                # a batch of brains as the CLI runs it (next volume read and previous files written behind the passes / the labelling)
+                "pipelined": pipe, "step2_wall_pipelined_per_brain_s": pipe["step2_per_brain_s"] if pipe else None,
+                "step3_wall_pipelined_per_brain_s": pipe["step3_per_brain_s"] if pipe else None,
                 "h2d_volume": tr.get("h2d_volume"), "d2h_mask": tr.get("d2h_mask"), "h2d_mask": tr.get("h2d_mask"),
                 "d2h_labels": tr.get("d2h_labels"), "write_input_volume_s": write_volume_s, "components": int(n_comp),
                 "label_dtype": str(labels.dtype), "mask_voxels_in_file": fg, "files_ok": files_ok, "files_on": base,

@@ -69,28 +69,44 @@ def main(argv=None) -> int:
         step_no += 1
         from .inference.inference import run_inference
 
+        from . import hostio
+
         mask_out = settings["blob_detection"]["input_location"]
         brains = sorted(os.listdir(mask_out))
-        for i, brain in enumerate(brains):
-            print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
-            stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
+
+        def niftis_of(brain):
             nifti_dir = os.path.join(mask_out, brain, "masked_niftis")
-            niftis = sorted(os.path.join(nifti_dir, f) for f in os.listdir(nifti_dir) if f.endswith(".npy"))
-            run_inference(niftis=niftis, output_folder=settings["blob_detection"]["output_location"],
-                          stack_shape=stack_shape, model_weights=settings["blob_detection"]["model_location"],
-                          tta=flags["TEST_TIME_AUGMENTATION"], comment=brain, load_all_ram=flags["LOAD_ALL_RAM"],
-                          settings=settings)
+            return sorted(os.path.join(nifti_dir, f) for f in os.listdir(nifti_dir) if f.endswith(".npy"))
+
+        # the brains are pipelined: while one runs its passes the next one's volume is read into HBM and the previous one's
+        # binaries.npy streams out (run_inference: prefetch / defer_write) - per brain the step costs its passes
+        try:
+            for i, brain in enumerate(brains):
+                print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
+                stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
+                nxt = niftis_of(brains[i + 1])[:1] if i + 1 < len(brains) else []
+                run_inference(niftis=niftis_of(brain), output_folder=settings["blob_detection"]["output_location"],
+                              stack_shape=stack_shape, model_weights=settings["blob_detection"]["model_location"],
+                              tta=flags["TEST_TIME_AUGMENTATION"], comment=brain, load_all_ram=flags["LOAD_ALL_RAM"],
+                              settings=settings, prefetch=nxt[0] if nxt else None, defer_write=True)
+        finally:
+            hostio.wait_deferred()  # every binaries.npy is complete before the next step reads it
     if flags.get("POSTPROCESSING"):
         step_no += 1
         from .count_blobs import count_blobs
 
+        from . import hostio
+
         path_in = settings["postprocessing"]["input_location"]
         brains = sorted(os.listdir(path_in))
-        for i, brain in enumerate(brains):
-            print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
-            stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
-            count_blobs(settings, path_in, i, brain, stack_shape, settings["postprocessing"]["min_size"],
-                        settings["postprocessing"]["max_size"])
+        try:
+            for i, brain in enumerate(brains):
+                print(f"HOOK:{step_no}:{len(steps)}:{i}:{len(brains)}")
+                stack_shape = (1, 1, *get_real_size(os.path.join(settings["raw_location"], brain)))
+                count_blobs(settings, path_in, i, brain, stack_shape, settings["postprocessing"]["min_size"],
+                            settings["postprocessing"]["max_size"], defer_write=True)  # (the label file streams out behind the next brain)
+        finally:
+            hostio.wait_deferred()
     for k in ("ATLAS_ALIGNMENT", "REGION_ASSIGNMENT"):
         if flags.get(k):
             step_no += 1

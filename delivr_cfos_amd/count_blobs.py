@@ -102,9 +102,11 @@ def _raise_if_any_failed(dist, mine, what: str):
         raise RuntimeError(f"{what} failed: " + "; ".join(bad))
 
 
-def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max_size=-1, engine=None):  # noqa: C901
+def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max_size=-1, engine=None, defer_write=False):  # noqa: C901
     """Same positional parameters as the reference.  ``engine``: a HipEngine to use (default: the process-wide engine of the
-    device, engine.shared_engine - the one run_inference used, with its workspaces).  Under torch.distributed (one process per GPU) the labelling is sharded over the
+    device, engine.shared_engine - the one run_inference used, with its workspaces).  ``defer_write``: return when the statistics
+    and the CSV are written - the label volume keeps streaming into its file on a background worker (hostio.wait_deferred() joins;
+    the file appears under its name only when complete), so that the next brain's labelling does not wait for 17 GB of writes.  Under torch.distributed (one process per GPU) the labelling is sharded over the
     ranks along z; rank 0 writes the statistics and the CSV, every rank writes its slab of the labels and returns N.
     Rank 0 alone looks for a cached labelling and tells the others which branch to take, so the ranks cannot disagree
     about the collectives that follow (different cache views on a shared file system); a failure on rank 0 reaches the
@@ -179,7 +181,10 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
             fh.write(cells_csv_text(stats, N))
         count_blobs.last_timings["csv_s"] = time.perf_counter() - t_csv
         t_join = time.perf_counter()
-        labels_written()  # the label volume has been streaming into its file since the labelling finished
+        if defer_write:
+            hostio.submit_deferred(eng, labels_written)
+        else:
+            labels_written()  # the label volume has been streaming into its file since the labelling finished
         count_blobs.last_timings["wait_for_labels_s"] = time.perf_counter() - t_join
         result = [N]
     except Exception as exc:

@@ -117,13 +117,46 @@ class _Stage:
         self.nbytes = nbytes
 
 
-def _transfer_lock(engine):
-    """one transfer at a time per engine: its staging ring is shared (a label volume streaming out from a side thread must not
-    meet an upload of the next step in the same buffers)"""
-    lock = getattr(engine, "_io_lock", None)
-    if lock is None:
-        lock = engine._io_lock = threading.Lock()
-    return lock
+def _transfer_lock(engine, kind: str):
+    """one transfer at a time per engine and DIRECTION ("up" / "down": each has its own staging ring, so the next brain's volume
+    can be read while the previous brain's mask or labels are still streaming out)"""
+    locks = engine.__dict__.setdefault("_io_locks", {})
+    with _pool_lock:
+        if kind not in locks:
+            locks[kind] = threading.Lock()
+    return locks[kind]
+
+
+# ---- deferred transfers: a step may return while its output file is still streaming out of HBM (the next brain's passes run
+# meanwhile); one background worker per engine keeps the files in order, wait_deferred() joins and re-raises -------------------
+_deferred = {}
+
+
+def submit_deferred(engine, fn, *args, **kwargs):
+    """run fn(*args, **kwargs) on the engine's background worker (one at a time, in submission order) -> Future"""
+    with _pool_lock:
+        ent = _deferred.get(id(engine))
+        if ent is None:
+            ent = _deferred[id(engine)] = {"pool": ThreadPoolExecutor(max_workers=1, thread_name_prefix="dlv-deferred"), "futs": []}
+    fut = ent["pool"].submit(fn, *args, **kwargs)
+    ent["futs"].append(fut)
+    return fut
+
+
+def wait_deferred(engine=None) -> None:
+    """join every deferred transfer (of one engine, or of all); the first exception any of them ran into is raised here"""
+    with _pool_lock:
+        ents = [e for k, e in _deferred.items() if engine is None or k == id(engine)]
+    first = None
+    for ent in ents:
+        futs, ent["futs"] = ent["futs"], []
+        for f in futs:
+            try:
+                f.result()
+            except BaseException as exc:  # noqa: BLE001 (collected, raised below)
+                first = first or exc
+    if first is not None:
+        raise first
 
 
 def _settle(futures) -> None:
@@ -136,11 +169,11 @@ def _settle(futures) -> None:
             pass
 
 
-def _stage_of(engine, chunk_bytes: int) -> _Stage:
-    st = getattr(engine, "_io_stage", None)
+def _stage_of(engine, chunk_bytes: int, kind: str) -> _Stage:
+    stages = engine.__dict__.setdefault("_io_stages", {})
+    st = stages.get(kind)
     if st is None or st.nbytes < chunk_bytes:
-        st = _Stage(engine.torch, N_STAGE, chunk_bytes)
-        engine._io_stage = st
+        st = stages[kind] = _Stage(engine.torch, N_STAGE, chunk_bytes)
     return st
 
 
@@ -210,10 +243,10 @@ def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk
     if path is not None:
         fd = os.open(path, os.O_RDONLY)
     pending = []  # (buffer index, byte range, futures) whose reads are in flight
-    lock = _transfer_lock(engine)
+    lock = _transfer_lock(engine, "up")
     lock.acquire()
     try:
-        st = _stage_of(engine, chunk_bytes)
+        st = _stage_of(engine, chunk_bytes, "up")
         copy_stream = torch.cuda.Stream(device=engine.device)
         evs = [torch.cuda.Event() for _ in range(N_STAGE)]
 
@@ -295,10 +328,10 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
     pool, nthr = _executor(), (io_threads() if isinstance(dst, np.ndarray) else min(io_threads(), WRITE_THREADS))
     writes = None
     t0 = time.perf_counter()
-    lock = _transfer_lock(engine)
+    lock = _transfer_lock(engine, "down")
     lock.acquire()
     try:
-        st = _stage_of(engine, chunk_bytes)
+        st = _stage_of(engine, chunk_bytes, "down")
         if fd is not None and WRITE_MODE == "mmap":
             import mmap
 

@@ -21,12 +21,23 @@ from ..model import HipBasicUNet
 from .sliding_window_inferer import SlidingWindowInferer
 
 
+# volumes read ahead for the NEXT call of run_inference (pipelined runs over several brains): key -> (thread, box)
+_prefetched = {}
+
+
+def _prefetch_key(path):
+    st = os.stat(path)
+    return (os.path.abspath(path), int(st.st_size), int(st.st_mtime_ns))
+
+
 def create_nifti_seg(threshold, model_output, output_file, network_output_file, dataset, original_stack_shape,
-                     count_map=None, engine=None, erode_iters: int = 30, mask_out=None):
+                     count_map=None, engine=None, erode_iters: int = 30, mask_out=None, defer_write: bool = False):
     """sigmoid >= threshold, eroded re-mask, crop to the original stack, write binaries.npy
     (reference :31-95).  ``model_output``: (1,1,Zp,Yp,Xp) or (Zp,Yp,Xp) fp32 tensor in HBM holding the
     blended logits (sum; pass ``count_map`` to divide, or the mean already); ``dataset``: the uint16
-    volume in HBM; ``mask_out``: a uint8 (Z,Y,X) tensor in HBM to hold the mask (allocated ahead of the passes)."""
+    volume in HBM; ``mask_out``: a uint8 (Z,Y,X) tensor in HBM to hold the mask (allocated ahead of the passes);
+    ``defer_write``: return as soon as the mask exists in HBM - the file(s) stream out on the engine's background worker
+    (hostio.wait_deferred() joins; a file appears under its name only when complete)."""
     Z, Y, X = (int(v) for v in original_stack_shape[-3:])
     if count_map is None and float(threshold) != 0.5:
         # sigmoid(sum of the window logits) >= t equals the reference's sigmoid(sum / count) >= t (:295) only at t = 0.5
@@ -42,6 +53,13 @@ def create_nifti_seg(threshold, model_output, output_file, network_output_file, 
     engine.sync()
     # the reference creates binaries.npy with open_memmap (:312) and fills it block by block; here numpy writes the same
     # header and the payload streams out of HBM through pinned staging with parallel writers (hostio.py)
+    if defer_write:
+        from ..hostio import submit_deferred
+
+        submit_deferred(engine, save_npy, engine, mask, output_file, np.uint8, "d2h_mask", True, True)  # (partial=True, synced=True)
+        if network_output_file is not None:
+            submit_deferred(engine, save_npy, engine, prob, network_output_file, np.float32, "d2h_prob", True, True)
+        return mask
     save_npy(engine, mask, output_file, np.uint8, what="d2h_mask")
     if network_output_file is not None:
         save_npy(engine, prob, network_output_file, np.float32, what="d2h_prob")
@@ -66,10 +84,17 @@ def run_inference(
     settings: Optional[dict] = None,
     precision: Optional[str] = None,
     state_dict=None,
+    prefetch: Optional[str] = None,
+    defer_write: bool = False,
 ):
     """Same parameters as the reference (:113-129) plus ``precision`` ("fp16" default / "bf16" / "bf16_all" / "fp32",
     also settings["mi355x"]["precision"]) and ``state_dict`` (use instead of reading
-    ``model_weights``).  Returns "<abs output_folder>/<comment>"."""
+    ``model_weights``).  Returns "<abs output_folder>/<comment>".
+
+    Pipelining over several brains (python -m delivr_cfos_amd does it; single device, resident volumes): ``prefetch`` = the
+    masked_nifti.npy of the NEXT brain - it is read into HBM by a side thread while this brain's passes run, and the next call
+    finds it there; ``defer_write`` = return when the mask exists in HBM, binaries.npy streams out in the background
+    (hostio.wait_deferred() before anything reads the file).  Per brain the step then costs its passes."""
     import time
 
     import torch
@@ -205,11 +230,33 @@ def run_inference(
         th = threading.Thread(target=preallocate, name="dlv-prealloc")
         th.start()
         try:
-            dataset = eng.upload_volume(dataset_host[0, 0])  # parallel preads -> pinned staging ring -> HBM (hostio.py)
+            ahead = _prefetched.pop(_prefetch_key(niftis[0]), None)
+            dataset = None
+            if ahead is not None:  # the previous call read this volume while its passes ran
+                ahead[0].join()
+                if "err" not in ahead[1] and int(ahead[1]["vol"].numel()) == int(pad[2]) * int(pad[3]) * int(pad[4]):
+                    dataset = ahead[1]["vol"].reshape(tuple(pad[2:]))
+            if dataset is None:
+                dataset = eng.upload_volume(dataset_host[0, 0])  # parallel preads -> pinned staging ring -> HBM (hostio.py)
         finally:
             th.join()
         if side_err:
             raise side_err[0]
+        _prefetched.clear()  # (a volume read ahead for a call that never came is dropped)
+        if prefetch is not None and os.path.isfile(prefetch):
+            nxt_shape = (os.path.getsize(prefetch) - 128) // 2
+            box = {}
+
+            def read_ahead(path=prefetch, n=nxt_shape):
+                try:
+                    host = np.memmap(path, dtype=np.uint16, mode="r", shape=(n,), offset=128)
+                    box["vol"] = eng.upload_volume(host.reshape(1, 1, n))[0, 0].reshape(-1)  # (flat: the next call knows the shape)
+                except Exception as exc:  # the next call simply reads the file itself
+                    box["err"] = exc
+
+            ra = threading.Thread(target=read_ahead, name="dlv-prefetch")
+            _prefetched[_prefetch_key(prefetch)] = (ra, box)
+            ra.start()
         output_image, count_map, mask_buf = side["acc"], side.get("cnt"), side["mask"]
         prealloc_t = side.get("t", {})
         mark("upload+alloc")
@@ -281,7 +328,7 @@ def run_inference(
             os.makedirs(testing_session_path + "/network_outputs/", exist_ok=True)
         create_nifti_seg(threshold=threshold, model_output=output_image, output_file=output_file,
                          network_output_file=network_output_file, dataset=dataset, original_stack_shape=stack_shape,
-                         count_map=count_map, engine=eng, mask_out=mask_buf)
+                         count_map=count_map, engine=eng, mask_out=mask_buf, defer_write=defer_write)
     else:
         from ..parallel import balanced_plan, exchange_seams, finalize_owned, gather_slabs
 

@@ -185,3 +185,53 @@ def test_reserve_allocates_what_the_pass_asks_for_and_the_shared_engine_is_one_p
     with pytest.raises(ValueError):
         eng2 = HipEngine(0)
         eng2.finalize(torch.zeros(shape, device="cuda"), None, torch.zeros(shape, dtype=torch.uint16, device="cuda"), shape, out=torch.empty((1, 2, 3), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_pipelined_brains_write_the_files_of_the_sequential_run(tmp_path):
+    """python -m delivr_cfos_amd runs a batch of brains pipelined: run_inference(prefetch=<next masked_nifti.npy>, defer_write=True) reads
+    the next volume into HBM while this brain's passes run and lets binaries.npy stream out behind the next brain; count_blobs(
+    defer_write=True) lets the label file stream out behind the next labelling.  Same files, byte for byte, as one brain at a time."""
+    from delivr_cfos_amd import hostio
+    from delivr_cfos_amd.count_blobs import count_blobs
+    from delivr_cfos_amd.hostlogic import padded_shape
+    from delivr_cfos_amd.inference.inference import run_inference
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+
+    crop = (32, 32, 32)
+    sd = {"state_dict": random_state_dict(4)}
+    shapes = [(40, 70, 64), (40, 70, 64), (33, 64, 96)]  # (the third brain has another shape: the read-ahead is sized by its file)
+    niftis = []
+    for k, shp in enumerate(shapes):
+        vol = synth_volume_np(shp, seed=20 + k)
+        pad = padded_shape(shp, crop)
+        d = tmp_path / "mask" / f"b{k}" / "masked_niftis"
+        os.makedirs(d)
+        out = np.lib.format.open_memmap(str(d / "masked_nifti.npy"), mode="w+", dtype=np.uint16, shape=(1, 1) + pad)
+        out[0, 0, : shp[0], : shp[1], : shp[2]] = vol
+        out.flush()
+        del out
+        niftis.append(str(d / "masked_nifti.npy"))
+
+    def run(tag, pipelined):
+        blob, post = str(tmp_path / tag / "blob"), str(tmp_path / tag / "post") + "/"
+        settings = {"postprocessing": {"output_location": post}}
+        for k, shp in enumerate(shapes):
+            kw = dict(prefetch=niftis[k + 1] if k + 1 < len(shapes) else None, defer_write=True) if pipelined else {}
+            run_inference([niftis[k]], blob, (1, 1) + shp, comment=f"b{k}", crop_size=crop, state_dict=sd, precision="fp32", **kw)
+        hostio.wait_deferred()
+        ns = [count_blobs(settings, blob, k, f"b{k}", (1, 1) + shp, **({"defer_write": True} if pipelined else {})) for k, shp in enumerate(shapes)]
+        hostio.wait_deferred()
+        files = {}
+        for root, _dirs, names in os.walk(str(tmp_path / tag)):
+            for n in names:
+                files[os.path.relpath(os.path.join(root, n), str(tmp_path / tag))] = open(os.path.join(root, n), "rb").read()
+        return ns, files
+
+    n_seq, f_seq = run("seq", False)
+    n_pipe, f_pipe = run("pipe", True)
+    assert n_seq == n_pipe and sorted(f_seq) == sorted(f_pipe) and not any(k.endswith(".partial") for k in f_pipe)
+    for k in f_seq:
+        assert f_seq[k] == f_pipe[k], k
+    assert any("cc3d.npy" in k for k in f_seq) and any(k.endswith("binaries.npy") for k in f_seq)
