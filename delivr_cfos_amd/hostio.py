@@ -117,14 +117,39 @@ class _Stage:
         self.nbytes = nbytes
 
 
-def _transfer_lock(engine, kind: str):
-    """one transfer at a time per engine and DIRECTION ("up" / "down": each has its own staging ring, so the next brain's volume
-    can be read while the previous brain's mask or labels are still streaming out)"""
-    locks = engine.__dict__.setdefault("_io_locks", {})
+class _Slots:
+    """the staging rings of one direction of one engine: acquire() -> index of a free ring (blocks while all are in use)"""
+
+    def __init__(self, n: int):
+        self.free = list(range(n))
+        self.cv = threading.Condition()
+
+    def acquire(self) -> int:
+        with self.cv:
+            while not self.free:
+                self.cv.wait()
+            return self.free.pop(0)
+
+    def release(self, i: int) -> None:
+        with self.cv:
+            self.free.append(i)
+            self.free.sort()
+            self.cv.notify()
+
+
+# rings per direction.  "up": one (the next brain's volume is read while the previous brain's files stream out of the "down" rings).
+# "down": two - buffered writes of ONE file serialise on its inode lock, two files do not: two 8 GB files written at once took
+# 6.9-8.7 GB/s together against 3.8-5.7 one after the other (profiles/r06w_two_files_probe.json), so two deferred outputs (the label
+# volumes of consecutive brains) may be in flight together.
+_RINGS = {"up": 1, "down": 2}
+
+
+def _slots(engine, kind: str) -> _Slots:
+    table = engine.__dict__.setdefault("_io_slots", {})
     with _pool_lock:
-        if kind not in locks:
-            locks[kind] = threading.Lock()
-    return locks[kind]
+        if kind not in table:
+            table[kind] = _Slots(_RINGS[kind])
+    return table[kind]
 
 
 # ---- deferred transfers: a step may return while its output file is still streaming out of HBM (the next brain's passes run
@@ -133,11 +158,12 @@ _deferred = {}
 
 
 def submit_deferred(engine, fn, *args, **kwargs):
-    """run fn(*args, **kwargs) on the engine's background worker (one at a time, in submission order) -> Future"""
+    """run fn(*args, **kwargs) on one of the engine's background workers (as many as there are "down" rings; the outputs are
+    independent files, so their order does not matter) -> Future"""
     with _pool_lock:
         ent = _deferred.get(id(engine))
         if ent is None:
-            ent = _deferred[id(engine)] = {"pool": ThreadPoolExecutor(max_workers=1, thread_name_prefix="dlv-deferred"), "futs": []}
+            ent = _deferred[id(engine)] = {"pool": ThreadPoolExecutor(max_workers=_RINGS["down"], thread_name_prefix="dlv-deferred"), "futs": []}
     fut = ent["pool"].submit(fn, *args, **kwargs)
     ent["futs"].append(fut)
     return fut
@@ -243,10 +269,10 @@ def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk
     if path is not None:
         fd = os.open(path, os.O_RDONLY)
     pending = []  # (buffer index, byte range, futures) whose reads are in flight
-    lock = _transfer_lock(engine, "up")
-    lock.acquire()
+    slots = _slots(engine, "up")
+    slot = slots.acquire()
     try:
-        st = _stage_of(engine, chunk_bytes, "up")
+        st = _stage_of(engine, chunk_bytes, f"up{slot}")
         copy_stream = torch.cuda.Stream(device=engine.device)
         evs = [torch.cuda.Event() for _ in range(N_STAGE)]
 
@@ -277,7 +303,7 @@ def upload(engine, src, dtype=None, shape=None, offset: int = 0, out=None, chunk
     finally:
         for item in pending:
             _settle(item[3])
-        lock.release()
+        slots.release(slot)
         if fd is not None:
             os.close(fd)
     dt_s = time.perf_counter() - t0
@@ -328,10 +354,10 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
     pool, nthr = _executor(), (io_threads() if isinstance(dst, np.ndarray) else min(io_threads(), WRITE_THREADS))
     writes = None
     t0 = time.perf_counter()
-    lock = _transfer_lock(engine, "down")
-    lock.acquire()
+    slots = _slots(engine, "down")
+    slot = slots.acquire()
     try:
-        st = _stage_of(engine, chunk_bytes, "down")
+        st = _stage_of(engine, chunk_bytes, f"down{slot}")
         if fd is not None and WRITE_MODE == "mmap":
             import mmap
 
@@ -416,7 +442,7 @@ def download(engine, tensor, dst, offset: int = 0, chunk_bytes: int = CHUNK_BYTE
     finally:
         for w in (writes or []):
             _settle(w)
-        lock.release()
+        slots.release(slot)
         if fmap is not None:
             arr = writes = None  # (the futures hold slices of the mapping)
             try:
