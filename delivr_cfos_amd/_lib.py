@@ -179,6 +179,7 @@ SIGNATURES = {
     "dlv_tiff_stack_to_device": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, _P, C.c_longlong,
                                             C.c_longlong, C.c_int]),
     "dlv_diag_set": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "dlv_cells_csv": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dlv_reserve_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "dlv_debug_stamps": (C.c_int, [_P, _P]),
     "dlv_debug_set_zm_variant": (C.c_int, [_P, C.c_int]),

@@ -14,7 +14,7 @@ import pickle
 import numpy as np
 
 from . import hostio
-from .hostlogic import cells_csv_text, csv_name
+from .hostlogic import cells_csv_bytes, csv_name
 
 
 def _find_cached(path: str, suffix: str, brain: str):
@@ -153,8 +153,8 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
                 try:
                     with open(os.path.join(path_out, f"{brain}-stats.pickle"), "wb") as fh:
                         pickle.dump(stats, fh, protocol=pickle.HIGHEST_PROTOCOL)
-                    with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
-                        fh.write(cells_csv_text(stats, N))
+                    with open(path_out + csv_name(bin_img.shape, brain), "wb") as fh:
+                        fh.write(cells_csv_bytes(stats, N))
                     end = datetime.datetime.now()
                     print(f"{end} {brain} {brain_i} / {len_b} Done ({dist.get_world_size()} ranks); Took {end - start}")
                 except Exception as exc:
@@ -177,8 +177,8 @@ def count_blobs(settings, path_in, brain_i, brain, stack_shape, min_size=-1, max
 
         N, stats, labels_written = _count_blobs_single(settings, brain, bin_img, eng, own, path_out, start)
         t_csv = time.perf_counter()
-        with open(path_out + csv_name(bin_img.shape, brain), "w") as fh:
-            fh.write(cells_csv_text(stats, N))
+        with open(path_out + csv_name(bin_img.shape, brain), "wb") as fh:
+            fh.write(cells_csv_bytes(stats, N))  # (the text pandas writes for the reference, formatted by the library: dlv_cells_csv)
         count_blobs.last_timings["csv_s"] = time.perf_counter() - t_csv
         t_join = time.perf_counter()
         if defer_write:

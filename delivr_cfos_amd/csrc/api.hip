@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -621,6 +622,52 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
     if (precision == DLV_PREC_BF16 || precision == DLV_PREC_F16 || precision == DLV_PREC_BF16_ALL)
         return dlv_unet_forward_bf16(ctx, x_dev, logits_dev, B, d, h, w, dlv_fmt16(precision));
     return dlv_fail(ctx, DLV_EINVAL, "unknown precision %d", precision);
+}
+
+// ---- the cell table's text (count_blobs.py:98-114) -----------------------------------------------------------------------------
+// one float as Python's repr writes it: shortest round-trip digits (std::to_chars without a precision gives exactly those),
+// fixed notation with ".0" on integral values for 1e-4 <= |v| < 1e16, exponent form outside (float_repr_style 'short')
+static char* py_float_repr(char* p, char* end, double v) {
+    if (std::isnan(v)) return p + snprintf(p, (size_t)(end - p), "nan");
+    if (std::isinf(v)) return p + snprintf(p, (size_t)(end - p), v < 0 ? "-inf" : "inf");
+    const double a = std::fabs(v);
+    if (a != 0.0 && (a < 1e-4 || a >= 1e16)) {
+        const auto r = std::to_chars(p, end, v, std::chars_format::scientific);
+        return r.ptr;
+    }
+    const auto r = std::to_chars(p, end, v, std::chars_format::fixed);
+    char* q = r.ptr;
+    bool dot = false;
+    for (char* c = p; c < q; ++c) dot |= (*c == '.');
+    if (!dot && q + 2 <= end) {
+        *q++ = '.';
+        *q++ = '0';
+    }
+    return q;
+}
+
+int dlv_cells_csv(const uint32_t* voxel_counts, const double* centroids, uint64_t n, char* out, size_t cap, size_t* len_out) {
+    if (!voxel_counts || !centroids || !out || !len_out) return DLV_EINVAL;
+    static const char header[] = ",Blob,Coords,Size\n";
+    if (cap < sizeof(header)) return DLV_EINVAL;
+    char* p = out;
+    char* const end = out + cap;
+    memcpy(p, header, sizeof(header) - 1);
+    p += sizeof(header) - 1;
+    for (uint64_t i = 1; i < n; ++i) {  // (range(1, N): the reference drops the last label)
+        if ((size_t)(end - p) < 128) return DLV_EINVAL;
+        p += snprintf(p, (size_t)(end - p), "0,%llu,\"[", (unsigned long long)i);
+        for (int k = 0; k < 3; ++k) {
+            p = py_float_repr(p, end, centroids[3 * i + k]);
+            if (k < 2) {
+                *p++ = ',';
+                *p++ = ' ';
+            }
+        }
+        p += snprintf(p, (size_t)(end - p), "]\",%u\n", voxel_counts[i]);
+    }
+    *len_out = (size_t)(p - out);
+    return DLV_OK;
 }
 
 // test / A-B switches (include/delivr_hip_diag.h): kernel selection per context, never from the environment

@@ -46,6 +46,27 @@ def cells_csv_text(stats: dict, n: int) -> str:
     return "\n".join(lines) + "\n"
 
 
+def cells_csv_bytes(stats: dict, n: int) -> bytes:
+    """cells_csv_text through the library's host-side writer (dlv_cells_csv: C, ~0.1 s for 540 k cells instead of 0.8 s of Python
+    string formatting - the same text, compared case by case in tests/test_host_cpu.py)"""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    counts = np.ascontiguousarray(stats["voxel_counts"], dtype=np.uint32)
+    cent = np.ascontiguousarray(stats["centroids"], dtype=np.float64)
+    n = int(n)
+    if len(counts) < n or cent.shape[0] < n or cent.shape[1:] != (3,):
+        raise ValueError("statistics shorter than the label count")
+    buf = C.create_string_buffer(64 + 128 * max(n, 1))
+    ln = C.c_size_t()
+    rc = lib.dlv_cells_csv(counts.ctypes.data_as(C.c_void_p), cent.ctypes.data_as(C.c_void_p), n, buf, len(buf), C.byref(ln))
+    if rc != 0:
+        raise _lib.DelivrHipError(rc, "dlv_cells_csv failed")
+    return buf.raw[: ln.value]
+
+
 def csv_name(shape_zyx: Sequence[int], brain: str) -> str:
     """f"{bin_img.shape}_{brain}.csv" (count_blobs.py:113): "(Z, Y, X)_<brain>.csv"."""
     return f"{tuple(int(v) for v in shape_zyx)}_{brain.replace('.nii.gz', '')}.csv"

@@ -252,6 +252,15 @@ int dlv_ccl26_dev(dlv_ctx* ctx, const uint8_t* mask_dev, int Z, int Y, int X, ui
 int dlv_cc_stats_dev(dlv_ctx* ctx, const uint32_t* labels_dev, int Z, int Y, int X, uint64_t n,
                      uint32_t* voxel_counts, uint16_t* bounding_boxes, double* centroids);
 
+/* The cell table as the reference writes it (count_blobs.py:98-114: a pandas frame of Blob / Coords / Size rows for labels 1..N-1 -
+ * `range(1, N)` drops the last label - through DataFrame.to_csv): header ",Blob,Coords,Size", then per label
+ * `0,<label>,"[z, y, x]",<voxel count>` with the centroid as Python writes a list of floats (repr: the shortest digits that
+ * round-trip, ".0" on integral values, exponent form below 1e-4 and from 1e16).  Host-only (no context, no GPU): 540 k rows take
+ * ~0.1 s instead of 0.8 s of Python string formatting.  voxel_counts / centroids: the outputs of dlv_cc_stats_dev.  out / cap:
+ * caller-owned text buffer (128 bytes per label are enough); *len_out = bytes written (no terminator); DLV_EINVAL when the buffer
+ * is too small. */
+int dlv_cells_csv(const uint32_t* voxel_counts, const double* centroids, uint64_t n, char* out, size_t cap, size_t* len_out);
+
 /* Multi-GPU CCL (one process per GPU, every rank labels its own Z-slab with dlv_ccl26_dev): the pieces of the seam
  * merge that run on the device.  The reference has no counterpart - cc3d labels the whole volume on one core
  * (count_blobs.py:61); the contract is that the merged result is identical to that single-volume labelling.

@@ -599,6 +599,32 @@ def test_range_guard_maps_the_named_layer_to_the_blocks_feeding_it():
     assert next_shifts(0, [0.0] * 18, shifts) is None
 
 
+def test_native_cell_table_writer_writes_pythons_text(golden_dir):
+    """dlv_cells_csv (host-only C: the reference's count_blobs.py:98-114 text without 0.8 s of Python formatting per brain) against
+    hostlogic.cells_csv_text - which the golden ref_csv.npz pins to the text the reference's own count_blobs() wrote - on centroids
+    that exercise every branch of Python's float repr: integral values, quarters, long fractions, < 1e-4, >= 1e16, zero."""
+    from delivr_cfos_amd.hostlogic import cells_csv_bytes, cells_csv_text
+
+    rng = np.random.default_rng(0)
+    n = 5000
+    cent = rng.random((n + 1, 3)) * 2048
+    cent[5] = [12.0, 0.0, 2047.0]
+    cent[6] = [5e-5, 1e-4, 9.999e-5]
+    cent[7] = [1 / 3, 2 / 3, 1e16]
+    cent[8] = [1e15, 123456789.125, 0.1]
+    cent[9] = [1e22, 1.5e-7, 3.0e-300]
+    cent[10:1000] = np.round(cent[10:1000] * 4) / 4
+    cent[1000:2000] = rng.integers(0, 100000, (1000, 3)) / rng.integers(1, 5000, (1000, 3))
+    stats = {"centroids": cent, "voxel_counts": rng.integers(1, 2**32 - 1, n + 1).astype(np.uint32)}
+    for k in (n, 2, 1, 0):
+        assert cells_csv_bytes(stats, k) == cells_csv_text(stats, k).encode(), k
+    # ... and the golden itself: the text the reference's own count_blobs() wrote for the statistics of a gt patch
+    g = np.load(os.path.join(golden_dir, "ref_csv.npz"))
+    c = np.load(os.path.join(golden_dir, "orc_ccl.npz"))
+    st = {"voxel_counts": c["gt0_counts"], "centroids": c["gt0_centroids"]}
+    assert cells_csv_bytes(st, int(c["gt0_n"])) == str(g["csv_text"]).encode()
+
+
 def test_range_recovery_spares_small_blocks_stops_after_a_futile_blind_step_and_takes_it_back():
     """range_guard.run_with_range_recovery on a fake engine: (i) a block whose recorded |mean| + 8 sigma would fall below 1 is not
     moved on no evidence; (ii) a blind step that leaves the same layer overflowing is not repeated - the format falls back to
