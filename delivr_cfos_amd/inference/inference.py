@@ -202,9 +202,9 @@ def run_inference(
     prealloc_t = {}
     if resident:
         # This step needs ~65 GB of device memory for a 1024 x 2048 x 2048 brain - sums, the pass's activation workspaces, the
-        # finalize maps.  Fresh memory costs nothing (16 GiB: 0.3 ms), but in a long-lived process whose allocators have handed
-        # memory back to the driver large allocations took up to seconds (profiles/r06r_alloc_probe2.json: 2.25 s for the first
-        # 16 GiB after a release; 1.2-1.8 s for this step's buffers inside the bench process).  A second thread allocates them while
+        # finalize maps.  Memory nobody has used since the driver's last clear costs nothing (16 GiB: 0.3 ms); memory that was used
+        # before - by this process or an earlier one - is cleared when it is handed out again, at 28-140 ms per GB
+        # (profiles/r06r_alloc_probe2.json, r06y_*: 1.8 s for this step's buffers).  A second thread allocates them while
         # this one reads the volume (preads -> pinned staging -> HBM, hostio.py), and nothing is handed back between brains: the
         # shared engine keeps its workspaces, torch's caching allocator its blocks.
         import threading
