@@ -370,6 +370,9 @@ def step_walls(eng, vol, stack, shape, roi, tta, precision, sd, mask_voxels, wei
         # allocated), in a FRESH child process - what the CLI is: this process has run a benchmark, holds ~100 GB in caches, and
         # its late allocations are slow (profiles/r06r_alloc_probe2.json), which is not what a user's first brain meets.  The child is
         # started before it touches the GPU (bench.py --step-walls-child); $DLV_BENCH_WALLS_INPROC=1 runs the pair in this process.
+        import torch
+
+        torch.cuda.empty_cache()  # (this process's caches - tens of GB after the extras - would push the child towards the slab-streamed path)
         spec = {"nifti": nifti, "out_dir": out_dir, "post_dir": post_dir, "stack": [Z, Y, X], "roi": list(roi), "tta": bool(tta),
                 "precision": precision, "weights": weights_name}
         if os.environ.get("DLV_BENCH_WALLS_INPROC") == "1":

@@ -182,7 +182,9 @@ def run_inference(
 
         budget = hbm_budget_bytes(eng, settings)
         bpv = inference_bytes_per_voxel(need_count, gaussian, save_activated)
-        fixed = forward_workspace_bytes(crop_size, precision)
+        # (the pass's workspaces: already in the shared engine when it has served a brain with these windows and this format)
+        ws_key = (tuple(crop_size), precision)
+        fixed = 0 if ws_key in eng.__dict__.setdefault("_ws_reserved", set()) else forward_workspace_bytes(crop_size, precision)
         pad_vox = int(pad[2]) * int(pad[3]) * int(pad[4])
         forced = int((settings or {}).get("mi355x", {}).get("stream_slabs", 0) or 0)  # explicit: exactly this many slabs
         if forced > 0:
@@ -222,6 +224,7 @@ def run_inference(
                     torch.cuda.current_stream(eng.device).synchronize()
                     t_b = time.perf_counter()
                     eng.reserve(eng.make_sw_params(pad[2:], crop_size, overlap, None, 0, precision), stack_shape[2:])
+                    eng.__dict__.setdefault("_ws_reserved", set()).add((tuple(crop_size), precision))
                     torch.cuda.current_stream(eng.device).synchronize()
                     side["t"] = {"prealloc_torch_s": t_b - t_a, "prealloc_reserve_s": time.perf_counter() - t_b}
             except Exception as exc:  # re-raised on the main thread

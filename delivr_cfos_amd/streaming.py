@@ -34,12 +34,17 @@ ACT_BYTES_PER_PATCH_VOXEL = 340
 
 
 def hbm_budget_bytes(engine, settings: Optional[dict]) -> int:
-    """settings["mi355x"]["hbm_budget_gb"] when given, else 92 % of what the device reports free right now."""
+    """settings["mi355x"]["hbm_budget_gb"] when given, else 92 % of what this process can use right now: what the device reports
+    free plus what torch's caching allocator holds without using it (the previous brain's volume, sums and mask: the next brain's
+    tensors come out of those blocks - counting them as "used" sent the second brain of a process down the slab-streamed path
+    when another process held most of the device)."""
     gb = (settings or {}).get("mi355x", {}).get("hbm_budget_gb") if settings else None
     if gb:
         return int(float(gb) * (1 << 30))
-    free, _total = engine.torch.cuda.mem_get_info(engine.device)
-    return int(free * 0.92)
+    torch = engine.torch
+    free, _total = torch.cuda.mem_get_info(engine.device)
+    reusable = max(int(torch.cuda.memory_reserved(engine.device)) - int(torch.cuda.memory_allocated(engine.device)), 0)
+    return int((free + reusable) * 0.92)
 
 
 def forward_workspace_bytes(roi: Sequence[int], precision: str, lanes: int = 3) -> int:
