@@ -47,6 +47,8 @@ WORKLOADS = {
     # run_inference's own defaults (inference/inference.py:113-129): crop_size (64, 64, 32), tta False
     "legacy": ((1024, 2048, 2048), (64, 64, 32), 2, False),
 }
+# the benchmark's checkpoint is test data of this repository (tests/golden/; the product package does not look there)
+TRAINED_LIKE_FIXTURE = os.environ.get("DLV_TRAINED_LIKE_FIXTURE") or os.path.join(ROOT, "tests", "golden", "trained_like_weights.npz")
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PATCH_VOXEL = 285104.0
@@ -322,7 +324,7 @@ def step_walls_child(spec_json):
     spec = json.loads(spec_json)
     from delivr_cfos_amd.weights import random_state_dict, trained_like_state_dict
 
-    sd = trained_like_state_dict() if spec["weights"] == "trained-like" else random_state_dict(seed=0)
+    sd = trained_like_state_dict(TRAINED_LIKE_FIXTURE) if spec["weights"] == "trained-like" else random_state_dict(seed=0)
     runs = step_walls_pair(spec, sd)
     print(json.dumps({"step_walls_child": runs}))
 
@@ -507,7 +509,7 @@ def main():
     from delivr_cfos_amd.hostlogic import arrayterator_zblock, padded_shape, pass_schedule
     from delivr_cfos_amd.parallel import balanced_plan, broadcast_weights, exchange_seams, finalize_owned, p2p_selftest, plan_from_params
     from delivr_cfos_amd.synth import synth_planes_torch, synth_volume_torch
-    from delivr_cfos_amd.weights import TRAINED_LIKE_FIXTURE, random_state_dict, trained_like_state_dict
+    from delivr_cfos_amd.weights import random_state_dict, trained_like_state_dict
 
     stack, roi, seed, tta = WORKLOADS[args.workload]
     Z, Y, X = stack
@@ -533,7 +535,7 @@ def main():
         raise SystemExit(f"bench.py: the trained-like checkpoint {TRAINED_LIKE_FIXTURE} is missing; pass --weights random to "
                          "benchmark on seeded random weights instead")
     weights_name = "trained-like" if args.weights == "trained" else "seeded random"
-    sd = trained_like_state_dict() if weights_name == "trained-like" else random_state_dict(seed=0)
+    sd = trained_like_state_dict(TRAINED_LIKE_FIXTURE) if weights_name == "trained-like" else random_state_dict(seed=0)
     if rank == 0:
         eng.load_state_dict({"state_dict": sd})
     if dist_mode:

@@ -54,20 +54,16 @@ def random_state_dict(seed: int = 0, features: Sequence[int] = FEATURES, module_
     return sd
 
 
-def _find_trained_like_fixture() -> str:
-    """The trained-like checkpoint is TEST DATA (tests/golden/, regenerable with oracle/train_weights.py), not part of the
-    product; an installed package finds it through DLV_TRAINED_LIKE_FIXTURE or a copy under delivr_cfos_amd/data/.  Callers
-    that need it (bench.py --weights trained, tests) fail when it is absent - nothing falls back to other weights."""
+def _default_trained_like_fixture() -> Optional[str]:
+    """The trained-like checkpoint is TEST DATA (the repository keeps it under tests/golden/, regenerable with
+    oracle/train_weights.py), not part of the product: the package does not look into tests/.  Callers name the file
+    (bench.py, the tests and the profiling tools pass tests/golden/trained_like_weights.npz); $DLV_TRAINED_LIKE_FIXTURE or a copy
+    under delivr_cfos_amd/data/ serve an installed package."""
     here = os.path.dirname(os.path.abspath(__file__))
-    cands = [os.environ.get("DLV_TRAINED_LIKE_FIXTURE"), os.path.join(here, "data", "trained_like_weights.npz"),
-             os.path.join(os.path.dirname(here), "tests", "golden", "trained_like_weights.npz")]
-    for c in cands:
+    for c in (os.environ.get("DLV_TRAINED_LIKE_FIXTURE"), os.path.join(here, "data", "trained_like_weights.npz")):
         if c and os.path.isfile(c):
             return c
-    return cands[-1]
-
-
-TRAINED_LIKE_FIXTURE = _find_trained_like_fixture()
+    return None
 
 
 def trained_like_state_dict(fixture: Optional[str] = None, module_prefix: bool = True) -> Dict[str, "object"]:
@@ -79,7 +75,11 @@ def trained_like_state_dict(fixture: Optional[str] = None, module_prefix: bool =
     import torch
 
     sd = random_state_dict(seed=0, module_prefix=module_prefix)
-    z = np.load(fixture or TRAINED_LIKE_FIXTURE)
+    fixture = fixture or _default_trained_like_fixture()
+    if fixture is None or not os.path.isfile(fixture):
+        raise FileNotFoundError("trained_like_state_dict: name the fixture file (the repository's copy is tests/golden/trained_like_weights.npz; "
+                                "regenerable with oracle/train_weights.py) or set DLV_TRAINED_LIKE_FIXTURE - nothing falls back to other weights")
+    z = np.load(fixture)
     pre = "module." if module_prefix else ""
     for k in z.files:
         if k.startswith("w:"):

@@ -177,7 +177,7 @@ def main():
         from delivr_cfos_amd.weights import trained_like_state_dict
 
         net = orc.build_unet(seed=0)
-        net.load_state_dict(trained_like_state_dict())
+        net.load_state_dict(trained_like_state_dict(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_like_weights.npz")))
     vol = synth_volume_np(CROP, seed=21)
     os.makedirs(a.cache, exist_ok=True)
 

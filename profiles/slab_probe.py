@@ -19,7 +19,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ranks = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,3").split(",")]
 shape, roi = (1024, 2048, 2048), (128, 128, 128)
 eng = HipEngine(0)
-eng.load_state_dict({"state_dict": trained_like_state_dict()})
+eng.load_state_dict({"state_dict": trained_like_state_dict(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_like_weights.npz"))})
 vol = synth_volume_torch(shape, 2, eng.device)
 p_all = eng.make_sw_params(shape, roi, 0.5, None, 0, "fp16")
 wmax = eng.window_max(p_all, vol)

@@ -36,7 +36,7 @@ try:
     del gen
     torch.cuda.empty_cache()
     time.sleep(3.0)
-    sd = trained_like_state_dict()
+    sd = trained_like_state_dict(os.path.join(ROOT, "tests", "golden", "trained_like_weights.npz"))
     settings = {"postprocessing": {"output_location": os.path.join(d, "post") + "/"}}
     for which in ("first", "second"):
         shutil.rmtree(os.path.join(d, "blob"), ignore_errors=True)

@@ -71,7 +71,7 @@ def main():
     t0 = time.perf_counter()
     eng = HipEngine(0)
     out["ctx_create_s"] = time.perf_counter() - t0
-    sd = trained_like_state_dict()
+    sd = trained_like_state_dict(os.path.join(ROOT, "tests", "golden", "trained_like_weights.npz"))
     t0 = time.perf_counter()
     eng.load_state_dict({"state_dict": sd})
     eng.sync()

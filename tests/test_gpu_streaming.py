@@ -79,7 +79,7 @@ def test_streamed_pipeline_is_bit_identical_on_the_trained_like_checkpoint(tmp_p
 
     crop = (64, 64, 64)
     vol = synth_volume_np((256, 128, 128), seed=23)  # with the ellipsoid background: skipped windows, a brain surface
-    sd = {"state_dict": trained_like_state_dict()}
+    sd = {"state_dict": trained_like_state_dict(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_like_weights.npz"))}
     fixed_gb = forward_workspace_bytes(crop, "fp16") / 2**30
     outs = {}
     for tag, mi in (("resident", {}), ("streamed", {"hbm_budget_gb": fixed_gb + 0.028})):  # 28.7 MiB beside the workspace: the resident run needs 36 MiB

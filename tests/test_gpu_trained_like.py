@@ -39,7 +39,7 @@ def eng():
     from delivr_cfos_amd.weights import trained_like_state_dict
 
     e = HipEngine(0)
-    e.load_state_dict({"state_dict": trained_like_state_dict()})
+    e.load_state_dict({"state_dict": trained_like_state_dict(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_like_weights.npz"))})
     yield e
     e.close()
 
