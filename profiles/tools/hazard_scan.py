@@ -149,6 +149,30 @@ def _kernel_metadata(elf):
     return meta
 
 
+def scan_m0(raw_lines):
+    """Uses of m0 in a kernel's listing.  The LDS-DMA asm of conv_deep.hip writes m0 (`s_mov_b32 m0, sN` + `buffer_load ... lds`);
+    hipcc treats m0 as reserved - a clobber on it is not honoured (-Winline-asm) - so the kernel is only correct while NOTHING
+    ELSE in it depends on m0: no compiler-generated reader (s_movrel / v_movrel / s_sendmsg with m0 / ds_gws / LDS-DMA builtin)
+    between our writes.  -> {"writes": n, "dma_reads": n, "other": [instruction text of every other line that mentions m0]}"""
+    writes = dma = 0
+    other = []
+    for l in raw_lines:
+        t = l.split("//")[0].strip()
+        if not t:
+            continue
+        toks = re.split(r"[\s,]+", t)
+        if re.search(r"\bm0\b", t):
+            if toks[0] == "s_mov_b32" and toks[1] == "m0":
+                writes += 1
+            else:
+                other.append(t)
+        elif toks[0].startswith("buffer_load") and toks[-1] == "lds":
+            dma += 1  # (reads m0 implicitly)
+        elif toks[0].startswith(("s_movrel", "v_movrel", "ds_gws", "s_sendmsg")):
+            other.append(t)
+    return {"writes": writes, "dma_reads": dma, "other": other}
+
+
 def library_report(lib_path, name_filter=("conv3_zreg_kernel", "conv3_zwino_kernel")):
     if isinstance(name_filter, str):
         name_filter = (name_filter,)
@@ -174,7 +198,7 @@ def library_report(lib_path, name_filter=("conv3_zreg_kernel", "conv3_zwino_kern
                 findings, n_mfma = scan(body.get(nm, []))
                 back = scan_readback(body.get(nm, []))
                 rep[nm] = {"hazards": len(findings), "first": findings[:3], "mfma": n_mfma, "readback_hazards": len(back),
-                           "first_readback": back[:3], **meta.get(nm, {})}
+                           "first_readback": back[:3], "m0": scan_m0(body.get(nm, [])), **meta.get(nm, {})}
     return rep
 
 

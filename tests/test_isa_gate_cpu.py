@@ -107,3 +107,10 @@ def test_deep_level_kernels_fit_two_waves_per_simd_without_scratch():
         assert r["vgpr_count"] <= 256 and r["agpr_count"] == 0, (name, r["vgpr_count"], r["agpr_count"])
     for name, r in conv.items():
         assert r["mfma"] == (144 if "ELi4EEE" in name else 72), (name, r["mfma"])
+    # the LDS-DMA asm writes m0, which hipcc treats as reserved (a clobber on it is not honoured: -Winline-asm).  The kernels are
+    # correct as long as m0 has no other user: every mention of m0 is one of our `s_mov_b32 m0, sN`, each LDS-DMA load follows one,
+    # and no instruction that reads m0 implicitly (movrel, gws, sendmsg) exists in them
+    for name, r in rep.items():
+        m0 = r["m0"]
+        assert m0["other"] == [], (name, m0["other"][:3])
+        assert m0["writes"] >= 1 and m0["dma_reads"] == m0["writes"], (name, m0)
