@@ -161,6 +161,7 @@ int main(int argc, char** argv) {
     uint64_t ncomp = 0;
     size_t fg = 0;
     int gpus = 1, same_device = 0, plan_only = 0, use_comm = 0, hot_block = -1, attempt, recoveries = 0;
+    const char* csv_path = NULL;
 
     for (i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
@@ -168,6 +169,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--same-device")) same_device = 1;
         else if (!strcmp(argv[i], "--hot-block") && i + 1 < argc) hot_block = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--comm")) use_comm = 1; /* the communicator path also for ONE rank (with DLV_FORCE_RCCL=1: real RCCL) */
+        else if (!strcmp(argv[i], "--csv") && i + 1 < argc) csv_path = argv[++i]; /* the cell table as count_blobs.py:98-114 writes it */
     }
     if (gpus < 1 || gpus > DLV_MAX_RANKS) return 3;
     if (plan_only) { /* pure host logic: no device is touched */
@@ -225,6 +227,7 @@ int main(int argc, char** argv) {
     CHECK(dlv_memset_dev(ctx, acc_dev, 0, nvox * 4));
 
     set_params(&p, Z, Y, X, roi);
+    CHECK(dlv_reserve_dev(ctx, &p, Z, Y, X)); /* (optional) the pass's workspaces and the finalize scratch now, not inside the pass */
     for (attempt = 0;; ++attempt) { /* the fp16 range guard: DLV_ERANGE -> next block shifts -> repeat */
         int changed = 0;
         const int rc = dlv_sw_infer_dev(ctx, &p, (const uint16_t*)vol_dev, (float*)acc_dev, NULL, &st);
@@ -241,6 +244,22 @@ int main(int argc, char** argv) {
     CHECK(dlv_finalize_dev(ctx, (const float*)acc_dev, NULL, (const uint16_t*)vol_dev, Y, X, Z, Y, X, 0.5f, 3, 0,
                            (uint8_t*)mask_dev, NULL));
     CHECK(dlv_ccl26_dev(ctx, (const uint8_t*)mask_dev, Z, Y, X, (uint32_t*)lab_dev, &ncomp));
+    if (csv_path) { /* cc3d.statistics + the cell table (count_blobs.py:85, :98-114): statistics on the device, text by the library */
+        uint32_t* counts = (uint32_t*)calloc((size_t)ncomp + 1, sizeof(uint32_t));
+        uint16_t* boxes = (uint16_t*)calloc(((size_t)ncomp + 1) * 6, sizeof(uint16_t));
+        double* cents = (double*)calloc(((size_t)ncomp + 1) * 3, sizeof(double));
+        const size_t cap = 64 + 128 * ((size_t)ncomp + 1);
+        char* text = (char*)malloc(cap);
+        size_t len = 0;
+        FILE* fh;
+        if (!counts || !boxes || !cents || !text) return 1;
+        CHECK(dlv_cc_stats_dev(ctx, (const uint32_t*)lab_dev, Z, Y, X, ncomp, counts, boxes, cents));
+        if (dlv_cells_csv(counts, cents, ncomp, text, cap, &len) != DLV_OK) return 1;
+        fh = fopen(csv_path, "wb");
+        if (!fh || fwrite(text, 1, len, fh) != len || fclose(fh) != 0) return 1;
+        printf("cell table: %llu rows, %zu bytes -> %s\n", (unsigned long long)(ncomp ? ncomp - 1 : 0), len, csv_path);
+        free(counts); free(boxes); free(cents); free(text);
+    }
     CHECK(dlv_copy_d2h(ctx, mask, mask_dev, nvox));
     for (i = 0; i < (int)nvox; ++i) fg += mask[i] != 0;
     printf("windows %lld (skipped %lld), mask voxels %zu of %zu, components %llu\n", (long long)st.n_windows,

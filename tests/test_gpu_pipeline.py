@@ -794,10 +794,19 @@ def test_plain_c_host_runs_the_pass_single_and_sharded(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "examples", "c_host.c"), "-o", exe, "-L" + lib_dir, "-ldelivr_hip",
                            "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-lm"])
-    single = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    csv = str(tmp_path / "cells.csv")
+    single = subprocess.run([exe, "--csv", csv], capture_output=True, text=True, timeout=600)
     assert single.returncode == 0, single.stdout + single.stderr
     fg1 = int(re.search(r"mask voxels (\d+)", single.stdout).group(1))
     assert fg1 > 0
+    # the cell table written from C (dlv_cc_stats_dev + dlv_cells_csv): header, one row per label 1..N-1, Python's list-of-floats text
+    ncomp = int(re.search(r"components (\d+)", single.stdout).group(1))
+    rows = open(csv).read().splitlines()
+    assert rows[0] == ",Blob,Coords,Size" and len(rows) == max(ncomp - 1, 0) + 1, (ncomp, len(rows))
+    for k, row in enumerate(rows[1:], 1):
+        m = re.fullmatch(r'0,(\d+),"\[([^\]]+)\]",(\d+)', row)
+        assert m and int(m.group(1)) == k and int(m.group(3)) > 0, row
+        assert all(repr(float(c)) == c for c in m.group(2).split(", ")), row  # every coordinate is its own Python repr
     for n in (2, 3):
         r = subprocess.run([exe, "--gpus", str(n), "--same-device"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
