@@ -1203,6 +1203,20 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const uint4* __restrict
 // ---------------------------------------------------------------------------------------------------
 // debug / test conversions: fp32 NCDHW <-> bf16 chunk-planar
 // ---------------------------------------------------------------------------------------------------
+// MONAI UpCat's replicate padding (monai/networks/nets/basic_unet.py, UpCat.forward, is_pad=True; call site
+// inference/inference.py:190-197): a level whose skip tensor has an ODD size gets an up-sampled tensor that is one voxel short in
+// that dimension (2 * floor(n / 2) = n - 1); it is padded by one at the far end with the edge value.  Windows whose dimensions
+// are multiples of 16 never come here.  Chunk-planar tensors: [n][C/8][D][H][W] of uint4.
+__global__ void __launch_bounds__(256) replicate_pad_cp_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int Di, int Hi, int Wi,
+                                                               int Do, int Ho, int Wo) {
+    const long long vo = (long long)Do * Ho * Wo, vi = (long long)Di * Hi * Wi;
+    const long long plane = blockIdx.y;  // (n, chunk)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vo; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((long long)Wo * Ho));
+        out[plane * vo + i] = in[plane * vi + ((long long)min(z, Di - 1) * Hi + min(y, Hi - 1)) * Wi + min(x, Wi - 1)];
+    }
+}
+
 template <class P>
 __global__ void f32_to_cp_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C, long long vox) {
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -1489,6 +1503,24 @@ struct Net16 {
         return DLV_OK;
     }
 
+    // the transposed conv of an UpCat block into `out` with the SKIP tensor's dimensions `dskip`: where they are 2 x the input's,
+    // straight into it; where the skip tensor is odd (windows that are not multiples of 16), into `tmp` and from there
+    // replicate-padded by one voxel at the far end (MONAI's UpCat)
+    int deconv_to(int j, Act& a, uint4* out, uint4* tmp, Dims din, Dims dskip) {
+        const Dims du{2 * din.D, 2 * din.H, 2 * din.W};
+        if (du.D == dskip.D && du.H == dskip.H && du.W == dskip.W) return deconv(j, a, out, din);
+        if (dskip.D - du.D > 1 || dskip.H - du.H > 1 || dskip.W - du.W > 1 || dskip.D < du.D || dskip.H < du.H || dskip.W < du.W)
+            return dlv_fail(ctx, DLV_ESTATE, "deconv %d: skip tensor %dx%dx%d against an up-sampled %dx%dx%d", j, dskip.D, dskip.H, dskip.W, du.D, du.H, du.W);
+        DLV_TRY(deconv(j, a, tmp, din));
+        const int cout = ctx->deconv[j].cout;
+        DlvProf pr(ctx, P::IS_F16 ? "replicate_pad_f16" : "replicate_pad_bf16", 0.0, 16.0 * B * (cout / 8) * ((double)du.vox() + (double)dskip.vox()));
+        hipLaunchKernelGGL(replicate_pad_cp_kernel, dim3(std::max(1, std::min(grid1d(dskip.vox()), 1024)), B * (cout / 8)), dim3(256), 0, ctx->stream,
+                           tmp, out, du.D, du.H, du.W, dskip.D, dskip.H, dskip.W);
+        pr.end();
+        DLV_LAUNCH_CHECK(ctx, "replicate_pad_cp_kernel");
+        return DLV_OK;
+    }
+
     int deconv(int j, Act& a, uint4* out, Dims din) {
         const DlvDeconvLayer& L = ctx->deconv[j];
         const uint4* w = reinterpret_cast<const uint4*>(wpack<P>(L));
@@ -1655,8 +1687,17 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         const int li_cat = 18 - 2 * l;  // upcat conv that takes skip[l-1]: 16, 14, 12, 10
         const int c_up = ctx->deconv[4 - l].cout;
         const bool keep_raw = net.fuses_first_input(li_cat, up.C, c_up, dm[l - 1]);
-        if (l == 1) DLV_TRY((net.template norm_mish<P0, PD>(up.p, up.C, dm[0], buf(1, A), up.ss, !keep_raw)));  // (level 0 stays P0, pooled: PD)
-        else DLV_TRY(netd.norm_mish(up.p, up.C, dm[l - 1], buf(l, A), up.ss, !keep_raw));
+        const bool odd = ((dm[l - 1].D | dm[l - 1].H | dm[l - 1].W) & 1) != 0;
+        // a level with an odd size (windows that are not multiples of 16): MaxPool3d(2) drops its last plane / row / column, so the
+        // pooling pass - which writes back only what it pools - cannot be the pass that makes the tensor final: pool only, then a
+        // full normalisation pass (unless every consumer activates on load)
+        if (l == 1) {  // (level 0 stays P0, pooled: PD)
+            DLV_TRY((net.template norm_mish<P0, PD>(up.p, up.C, dm[0], buf(1, A), up.ss, !keep_raw && !odd)));
+            if (odd && !keep_raw) DLV_TRY(net.norm_mish(up.p, up.C, dm[0], nullptr, up.ss, true));
+        } else {
+            DLV_TRY(netd.norm_mish(up.p, up.C, dm[l - 1], buf(l, A), up.ss, !keep_raw && !odd));
+            if (odd && !keep_raw) DLV_TRY(netd.norm_mish(up.p, up.C, dm[l - 1], nullptr, up.ss, true));
+        }
         if (!keep_raw) up.ss = nullptr;
         Act a{buf(l, A), encC[l - 1], nullptr};
         Act b{buf(l, Bf), encC[l], nullptr};
@@ -1674,7 +1715,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
         const int li = 10 + 2 * j;
         Act b{buf(l, Bf), ctx->conv[li].cout, nullptr};
         if (l >= 1) {
-            DLV_TRY(netd.deconv(j, cur, buf(l, U), dm[l + 1]));
+            DLV_TRY(netd.deconv_to(j, cur, buf(l, U), buf(l, A), dm[l + 1], dm[l]));  // (buf(l, A): free until this block's second conv writes it)
             Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
             DLV_TRY(netd.conv(li, skip[l], &u, b.p, dm[l]));
             b.ss = net.ss_of(li);
@@ -1692,7 +1733,7 @@ int forward_16(dlv_ctx* ctx, const float* xf, const uint16_t* vol, int Yp, int X
             // 32-channel conv of the skip half with P as its addend - no up-sampled tensor, 8 coarse taps instead of 27 fine ones
             DLV_TRY(net.conv_folded(li, skip[l], cur, buf(l, U), b.p, dm[l], dm[l + 1]));
         } else {
-            DLV_TRY(net.deconv(j, cur, buf(l, U), dm[l + 1]));
+            DLV_TRY(net.deconv_to(j, cur, buf(l, U), buf(l, A), dm[l + 1], dm[l]));  // (buf(0, A): the stem's output, consumed)
             Act u{buf(l, U), ctx->deconv[j].cout, nullptr};
             DLV_TRY(net.conv(li, skip[l], &u, b.p, dm[l]));
         }

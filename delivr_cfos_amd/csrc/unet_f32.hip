@@ -128,6 +128,18 @@ __global__ void __launch_bounds__(256) maxpool2_f32_kernel(const float* __restri
 }
 
 // ConvTranspose3d k2 s2: out[n,co,2z+a,2y+b,2x+c] = bias[co] + sum_ci in[n,ci,z,y,x] * W[ci,co,a,b,c]
+// UpCat's replicate padding of an up-sampled tensor whose skip tensor has an odd size (MONAI basic_unet.py UpCat.forward; windows
+// that are not multiples of 16 reach it): one voxel at the far end of each short dimension, edge value
+__global__ void __launch_bounds__(256) replicate_pad_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int Di, int Hi, int Wi,
+                                                                int Do, int Ho, int Wo) {
+    const long long vo = (long long)Do * Ho * Wo, vi = (long long)Di * Hi * Wi;
+    const long long plane = blockIdx.y;  // (n, c)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vo; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((long long)Wo * Ho));
+        out[plane * vo + i] = in[plane * vi + ((long long)min(z, Di - 1) * Hi + min(y, Hi - 1)) * Wi + min(x, Wi - 1)];
+    }
+}
+
 __global__ void __launch_bounds__(256) deconv2_f32_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int cin, int cout, int D, int H, int W) {
@@ -194,6 +206,14 @@ struct F32Net {
         DLV_LAUNCH_CHECK(ctx, "maxpool2_f32_kernel");
         return DLV_OK;
     }
+    // MONAI UpCat's replicate padding: `in` (B, C, Di, Hi, Wi) -> `out` (B, C, Do, Ho, Wo), Do - Di etc. in {0, 1}, edge values repeated
+    int pad(const float* in, float* out, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+        hipLaunchKernelGGL(replicate_pad_f32_kernel, dim3(std::max(1, std::min(dlv_cdiv((long long)Do * Ho * Wo, 256), 1024)), B * C), dim3(256), 0,
+                           ctx->stream, in, out, Di, Hi, Wi, Do, Ho, Wo);
+        DLV_LAUNCH_CHECK(ctx, "replicate_pad_f32_kernel");
+        return DLV_OK;
+    }
+
     int deconv(int j, const float* in, float* out, int D, int H, int W) {
         const DlvDeconvLayer& L = ctx->deconv[j];
         dim3 grid(dlv_cdiv((long long)D * H * W * 8, 256), L.cout / COB, B);
@@ -245,7 +265,12 @@ int dlv_unet_forward_f32(dlv_ctx* ctx, const float* x, float* logits, int B, int
     const float* cur = buf(4, S);
     for (int j = 0; j < 4; ++j) {
         const int l = 3 - j;  // output level
-        DLV_TRY(net.deconv(j, cur, buf(l, U), D[l + 1], H[l + 1], W[l + 1]));
+        if (2 * D[l + 1] == D[l] && 2 * H[l + 1] == H[l] && 2 * W[l + 1] == W[l]) {
+            DLV_TRY(net.deconv(j, cur, buf(l, U), D[l + 1], H[l + 1], W[l + 1]));
+        } else {  // an odd level: up-sample into the free buffer of the level, replicate-pad into U (MONAI's UpCat)
+            DLV_TRY(net.deconv(j, cur, buf(l, A), D[l + 1], H[l + 1], W[l + 1]));
+            DLV_TRY(net.pad(buf(l, A), buf(l, U), ctx->deconv[j].cout, 2 * D[l + 1], 2 * H[l + 1], 2 * W[l + 1], D[l], H[l], W[l]));
+        }
         const int li = 10 + 2 * j;
         DLV_TRY(net.conv(li, buf(l, S), encC[l], buf(l, U), ctx->deconv[j].cout, buf(l, Bf), D[l], H[l], W[l]));
         DLV_TRY(net.conv(li + 1, buf(l, Bf), ctx->conv[li].cout, nullptr, 0, buf(l, A), D[l], H[l], W[l]));

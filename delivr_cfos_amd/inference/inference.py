@@ -113,13 +113,12 @@ def run_inference(
     precision = precision or "fp16"
     crop_size = tuple(int(c) for c in crop_size)
     print("using crop size:  ", crop_size)
-    if any(c <= 0 or c % 16 for c in crop_size):
-        # the reference takes any window (inference/inference.py:162-168 -> SlidingWindowInferer): MONAI's UpCat replicate-pads an
-        # up-sampled tensor whose skip tensor has an odd size.  The HIP U-Net has no such padding: four 2 x poolings and transposed
-        # convs return to the skip shapes exactly when every window dimension is a multiple of 16 (DLV_EUNSUP in the library).
-        raise ValueError(f"window_dimensions {crop_size}: every dimension must be a positive multiple of 16 on the MI355X path "
-                         "(the reference builds its windows from window_dim_0..2, inference/inference.py:162-168, and MONAI pads odd "
-                         "levels; the defaults (64, 64, 32) and config.json's (96, 96, 64) qualify)")
+    if any(c < 16 for c in crop_size):
+        # the reference takes any window (inference/inference.py:162-168 -> SlidingWindowInferer), and so does the HIP U-Net: a
+        # level with an odd size is pooled (last plane dropped) and its up-sampled partner replicate-padded like MONAI's UpCat.
+        # Below 16 the fourth pooling has nothing left - torch raises there too ("Output size is too small").
+        raise ValueError(f"window_dimensions {crop_size}: every dimension must be at least 16 (four 2 x poolings; the reference builds "
+                         "its windows from window_dim_0..2, inference/inference.py:162-168)")
     if not torch.cuda.is_available():
         raise RuntimeError("run_inference needs an MI355X: the HIP path has no CPU fallback")
     # one process per GPU (torch.distributed.run): the window list is sharded over the ranks, see parallel.py.
@@ -182,9 +181,13 @@ def run_inference(
 
         budget = hbm_budget_bytes(eng, settings)
         bpv = inference_bytes_per_voxel(need_count, gaussian, save_activated)
-        # (the pass's workspaces: already in the shared engine when it has served a brain with these windows and this format)
+        # (the pass's workspaces: already in the shared engine when it has served a brain with these windows and this format - then
+        # the device's free memory, which the default budget is derived from, no longer contains them.  An explicit
+        # hbm_budget_gb is a TOTAL: the workspaces always count against it)
         ws_key = (tuple(crop_size), precision)
-        fixed = 0 if ws_key in eng.__dict__.setdefault("_ws_reserved", set()) else forward_workspace_bytes(crop_size, precision)
+        explicit_budget = bool((settings or {}).get("mi355x", {}).get("hbm_budget_gb"))
+        held = not explicit_budget and ws_key in eng.__dict__.setdefault("_ws_reserved", set())
+        fixed = 0 if held else forward_workspace_bytes(crop_size, precision)
         pad_vox = int(pad[2]) * int(pad[3]) * int(pad[4])
         forced = int((settings or {}).get("mi355x", {}).get("stream_slabs", 0) or 0)  # explicit: exactly this many slabs
         if forced > 0:

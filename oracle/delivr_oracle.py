@@ -127,6 +127,14 @@ def build_unet(seed: Optional[int] = 0, features: Sequence[int] = FEATURES):
 
         def forward(self, x, x_e):
             x0 = self.upsample(x)
+            # MONAI 1.2.0 UpCat.forward (is_pad=True, the default) [3P-recall]: where the skip tensor has an odd size the
+            # up-sampled one is a voxel short - it is replicate-padded by one at the FAR end of that dimension
+            sp = [0] * 6
+            for i in range(3):
+                if x_e.shape[-i - 1] != x0.shape[-i - 1]:
+                    sp[i * 2 + 1] = 1
+            if any(sp):
+                x0 = torch.nn.functional.pad(x0, sp, "replicate")
             return self.convs(torch.cat([x_e, x0], dim=1))
 
     class BasicUNet(nn.Module):

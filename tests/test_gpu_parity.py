@@ -302,11 +302,13 @@ def test_errors_are_reported_not_crashed(eng):
 
 
 @pytest.mark.parametrize("shape,roi,overlap", [((48, 40, 40), (32, 32, 16), 0.25), ((40, 48, 56), (32, 32, 32), 0.5),
-                                               ((32, 32, 48), (32, 32, 16), 0.6)])
+                                               ((32, 32, 48), (32, 32, 16), 0.6), ((50, 61, 70), (24, 40, 20), 0.5),
+                                               ((40, 70, 45), (19, 35, 21), 0.3)])
 def test_sw_pass_clamped_windows_and_other_overlaps(eng_w, net, shape, roi, overlap):
     """Volumes that are NOT a multiple of the scan interval: the last window of a dimension is clamped back
     (MONAI dense_patch_slices), so windows of equal parity may overlap - the colour classes must still be
-    race-free and the sums equal the oracle's."""
+    race-free and the sums equal the oracle's.  The last two: windows that are not multiples of 16 (odd levels inside the
+    U-Net: MaxPool3d's dropped plane, UpCat's replicate padding), one of them odd itself with an odd scan interval."""
     import torch
     from delivr_cfos_amd.synth import synth_volume_np
     from oracle import delivr_oracle as orc

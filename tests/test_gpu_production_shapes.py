@@ -159,6 +159,47 @@ def test_uneven_windows_through_the_deep_level_kernels_vs_oracle(eng, net, prec,
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("roi,batch", [((72, 88, 104), 2), ((40, 64, 24), 3), ((120, 128, 128), 1), ((100, 100, 52), 2), ((67, 93, 45), 2),
+                                       ((36, 20, 28), 3), ((97, 64, 129), 1)])
+def test_windows_with_odd_levels_pool_and_pad_like_monai_vs_oracle(eng, net, prec, roi, batch):
+    """MONAI's BasicUNet takes any window: MaxPool3d(2) drops the last plane of an odd level and UpCat replicate-pads the
+    up-sampled tensor back to the skip tensor's size (basic_unet.py UpCat.forward, is_pad=True); the reference passes
+    settings' window_dim_0..2 straight through (inference/inference.py:162-168).  Multiples of 16 keep every level even.
+    (72,88,104): level 3 of 9x11x13, odd in every dimension (the transposed conv of 4x5x6 gives 8x10x12); (40,64,24): 5x8x3
+    there, level 4 of 2x4x1; (120,128,128): a production-size window, odd in z only; (100,100,52): level 2 of 25x25x13;
+    (67,93,45): odd at level 0 - the folded up-conv of upcat_1 does not apply, the stem / final conv / blend see odd rows - and
+    again at levels 1-3 in some dimension; (36,20,28): small, levels 2-4 of 9x5x7, 4x2x3, 2x1x1; (97,64,129): full-size rows of an
+    odd length in z and x.  Several windows per launch; every precision against the oracle (oracle/delivr_oracle.py UpCat pads
+    with torch's F.pad(mode="replicate") as MONAI does)."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    shape = (roi[0], roi[1], roi[2] * batch)
+    vol = synth_volume_np(shape, seed=11, dense=True)
+    acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    st = eng.sw_infer(eng.make_sw_params(shape, roi, 0.0, None, 0, prec), eng.to_device(vol), acc)
+    eng.sync()
+    assert st["n_windows"] == batch and st["n_skipped"] == 0
+    out = acc.cpu().numpy()
+    for b in range(batch):
+        sl = slice(b * roi[2], (b + 1) * roi[2])
+        ref = orc.unet_forward(net, vol[:, :, sl].astype(np.float32)[None, None])[0, 0]
+        _check(f"{roi} window {b}", prec, out[:, :, sl], ref)
+
+
+def test_window_below_16_is_refused(eng):
+    """four 2 x poolings need 16 voxels (torch: "Output size is too small")"""
+    import torch
+    from delivr_cfos_amd._lib import DelivrHipError
+
+    with pytest.raises(DelivrHipError, match="at least 16"):
+        eng.sw_infer(eng.make_sw_params((12, 64, 64), (12, 64, 64), 0.0, None, 0, "fp16"),
+                     torch.zeros((12, 64, 64), dtype=torch.int16, device="cuda").view(torch.uint16),
+                     torch.zeros((12, 64, 64), dtype=torch.float32, device="cuda"))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
 def test_window_128cube_forward_vs_oracle(eng, crop, prec):
     """dlv_unet_forward_dev on the centre window of the crop (fp32 patch input) vs the oracle's logits of that window."""
     import torch
