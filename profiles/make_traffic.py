@@ -75,7 +75,7 @@ from delivr_cfos_amd._lib import build_fingerprint  # noqa: E402  (hashes only: 
 # what the figures belong to: the library that ran (sha256 of the .so and of its sources) and the commit it was built from
 # (DLV_GIT_HEAD: .git does not travel to the GPU box, the caller passes `git rev-parse --short HEAD`); bench.py reports a
 # traffic figure only when the library it has loaded matches
-out = {"workload": wl, "precision": precision, "round": os.environ.get("DLV_BUILD_TAG", "r05"), "git_head": os.environ.get("DLV_GIT_HEAD"),
+out = {"workload": wl, "precision": precision, "round": os.environ.get("DLV_BUILD_TAG", "r06"), "git_head": os.environ.get("DLV_GIT_HEAD"),
        "fingerprint": build_fingerprint(),
        "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged over the launches of one label; "
                "algorithmic_bytes = the figure the library's DlvProf bracket declares for that launch (DESIGN.md)",
