@@ -432,7 +432,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dense", action="store_true", help="no background: every window runs the network")
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
-                    help="fp16 (default): IEEE-half MFMA operands, mask IoU 0.9997 vs the fp32 path; bf16: 2.7 %% faster, IoU 0.998")
+                    help="fp16 (default): IEEE-half MFMA operands and storage, mask IoU 0.9998 vs the oracle; bf16: bf16 at levels 1-4 of the "
+                         "U-Net, fp16 at level 0 (DLV_PREC_BF16), IoU 0.9994, the same speed; fp32: the VALU parity path")
     ap.add_argument("--sw-batch", type=int, default=0)
     ap.add_argument("--weights", default="trained", choices=["trained", "random"],
                     help="trained (default): the trained-like checkpoint (tests/golden/trained_like_weights.npz: top levels trained on the "

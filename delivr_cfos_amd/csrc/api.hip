@@ -615,9 +615,10 @@ int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, in
     if (!ctx || !x_dev || !logits_dev) return DLV_EINVAL;
     if (!ctx->weights_loaded) return dlv_fail(ctx, DLV_ESTATE, "dlv_unet_forward_dev before dlv_unet_load");
     if (B <= 0 || d <= 0 || h <= 0 || w <= 0) return dlv_fail(ctx, DLV_EINVAL, "empty batch/patch");
-    if (d < 16 || h < 16 || w < 16)
-        return dlv_fail(ctx, DLV_EUNSUP, "patch %dx%dx%d: every dimension must be at least 16 (four 2 x poolings; any size from there on: levels with an odd size are "
-                        "pooled and padded like MONAI's MaxPool3d / UpCat)", d, h, w);
+    if (d < 16 || h < 16 || w < 16 || (long long)(d >> 4) * (h >> 4) * (w >> 4) < 2)
+        return dlv_fail(ctx, DLV_EUNSUP, "patch %dx%dx%d: every dimension must be at least 16 and level 4 (each dimension / 16, rounded down) must hold more "
+                        "than one voxel - InstanceNorm3d has no statistics of a single value and torch raises there; any size from there on: "
+                        "levels with an odd size are pooled and padded like MONAI's MaxPool3d / UpCat", d, h, w);
     DLV_HIP(ctx, hipSetDevice(ctx->device));
     if (precision == DLV_PREC_F32) return dlv_unet_forward_f32(ctx, x_dev, logits_dev, B, d, h, w);
     if (precision == DLV_PREC_BF16 || precision == DLV_PREC_F16 || precision == DLV_PREC_BF16_ALL)

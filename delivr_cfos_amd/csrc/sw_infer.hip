@@ -395,9 +395,10 @@ int dlv_sw_infer_dev(dlv_ctx* ctx, const dlv_sw_params* p, const uint16_t* vol_d
     Tiler t;
     DLV_TRY(build_tiler(ctx, p, t));
     const int d = t.roi[0], h = t.roi[1], w = t.roi[2];
-    if (d < 16 || h < 16 || w < 16)
-        return dlv_fail(ctx, DLV_EUNSUP, "window %dx%dx%d: every dimension must be at least 16 (four 2 x poolings; any size from there on: levels with an odd size are "
-                        "pooled and padded like MONAI's MaxPool3d / UpCat)", d, h, w);
+    if (d < 16 || h < 16 || w < 16 || (long long)(d >> 4) * (h >> 4) * (w >> 4) < 2)
+        return dlv_fail(ctx, DLV_EUNSUP, "window %dx%dx%d: every dimension must be at least 16 and level 4 (each dimension / 16, rounded down) must hold more "
+                        "than one voxel - InstanceNorm3d has no statistics of a single value and torch raises there; any size from there on: "
+                        "levels with an odd size are pooled and padded like MONAI's MaxPool3d / UpCat", d, h, w);
     const int64_t total = t.count();
     const int64_t wb = std::max<int64_t>(p->win_begin, 0);
     const int64_t we = p->win_end > 0 ? std::min<int64_t>(p->win_end, total) : total;

@@ -113,12 +113,14 @@ def run_inference(
     precision = precision or "fp16"
     crop_size = tuple(int(c) for c in crop_size)
     print("using crop size:  ", crop_size)
-    if any(c < 16 for c in crop_size):
+    if any(c < 16 for c in crop_size) or (crop_size[0] // 16) * (crop_size[1] // 16) * (crop_size[2] // 16) < 2:
         # the reference takes any window (inference/inference.py:162-168 -> SlidingWindowInferer), and so does the HIP U-Net: a
         # level with an odd size is pooled (last plane dropped) and its up-sampled partner replicate-padded like MONAI's UpCat.
-        # Below 16 the fourth pooling has nothing left - torch raises there too ("Output size is too small").
-        raise ValueError(f"window_dimensions {crop_size}: every dimension must be at least 16 (four 2 x poolings; the reference builds "
-                         "its windows from window_dim_0..2, inference/inference.py:162-168)")
+        # Where torch raises, this raises: below 16 the fourth pooling has nothing left ("Output size is too small"), and a level 4
+        # of ONE voxel has no InstanceNorm statistics (ValueError "Expected more than 1 spatial element", e.g. 16 x 16 x 16).
+        raise ValueError(f"window_dimensions {crop_size}: every dimension must be at least 16 and level 4 of the U-Net (each dimension "
+                         "// 16) must hold more than one voxel (torch's InstanceNorm3d raises on a single spatial element; the reference "
+                         "builds its windows from window_dim_0..2, inference/inference.py:162-168)")
     if not torch.cuda.is_available():
         raise RuntimeError("run_inference needs an MI355X: the HIP path has no CPU fallback")
     # one process per GPU (torch.distributed.run): the window list is sharded over the ranks, see parallel.py.

@@ -104,9 +104,9 @@ int dlv_unet_blob_dev(dlv_ctx* ctx, void** blob_dev); /* device pointer owned by
 int dlv_unet_alloc_blob(dlv_ctx* ctx, const int features[6]); /* non-root ranks: allocate only */
 
 /* ---- U-Net forward (one batch of patches) -------------------------------------------------- */
-/* logits = BasicUNet(x): x_dev (B,1,d,h,w) fp32 -> logits_dev (B,1,d,h,w) fp32; d,h,w >= 16 (multiples
- * of 16 keep every level even; elsewhere MaxPool3d's dropped plane and UpCat's replicate padding as in
- * MONAI; DLV_EUNSUP below 16).  Replaces predictor(window_data) at inference/sliding_window_inferer.py:222. */
+/* logits = BasicUNet(x): x_dev (B,1,d,h,w) fp32 -> logits_dev (B,1,d,h,w) fp32; d,h,w >= 16 and
+ * (d/16)*(h/16)*(w/16) > 1 (DLV_EUNSUP otherwise: torch raises there too); multiples of 16 keep every level
+ * even, elsewhere MaxPool3d's dropped plane and UpCat's replicate padding as in MONAI.  Replaces predictor(window_data) at inference/sliding_window_inferer.py:222. */
 int dlv_unet_forward_dev(dlv_ctx* ctx, const float* x_dev, float* logits_dev, int B, int d, int h, int w,
                          int precision);
 

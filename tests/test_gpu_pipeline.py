@@ -650,6 +650,55 @@ def test_run_inference_with_gaussian_blend_option(tmp_path):
     assert np.abs(prob - want).max() < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_run_inference_with_windows_that_are_not_multiples_of_16(tmp_path, precision):
+    """window_dim_0..2 = (24, 40, 20) - as the reference passes any window to MONAI (inference/inference.py:162-168): the padded
+    shape rule, the window list with an odd scan interval (12, 20, 10), the 13-pass schedule and the mask against the oracle's
+    pipeline.  Level 3 of these windows is 3 x 5 x 2 (odd: MaxPool3d's dropped plane, UpCat's replicate padding)."""
+    import torch
+    from delivr_cfos_amd.inference.inference import run_inference
+    from delivr_cfos_amd.hostlogic import pass_schedule
+    from delivr_cfos_amd.synth import synth_volume_np
+    from delivr_cfos_amd.weights import random_state_dict
+    from oracle import delivr_oracle as orc
+
+    sd = random_state_dict(6)
+    wfile = str(tmp_path / "weights.tar")
+    torch.save({"state_dict": sd}, wfile)
+    crop = (24, 40, 20)
+    vol = synth_volume_np((50, 61, 70), seed=8, dense=True)
+    vol[:, :, :12] = 0
+    mask_dir = tmp_path / "01" / "b" / "masked_niftis"
+    os.makedirs(mask_dir)
+    pad = _write_padded_npy(str(mask_dir / "masked_nifti.npy"), vol, crop)
+    settings = {"blob_detection": {"window_dimensions": {"window_dim_0": 24, "window_dim_1": 40, "window_dim_2": 20}},
+                "mi355x": {"precision": precision}, "FLAGS": {"SAVE_ACTIVATED_OUTPUT": False}}
+    out = run_inference(niftis=[str(mask_dir / "masked_nifti.npy")], output_folder=str(tmp_path / "02") + "/",
+                        stack_shape=(1, 1, *vol.shape), model_weights=wfile, tta=True, comment="b", load_all_ram=True,
+                        settings=settings)
+    binaries = np.load(os.path.join(str(out), "binary_segmentations", "binaries.npy"))
+    assert binaries.shape == vol.shape and binaries.dtype == np.uint8
+    net = orc.build_unet(seed=None)
+    net.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+    padded = np.zeros(pad, dtype=np.uint16)
+    padded[: vol.shape[0], : vol.shape[1], : vol.shape[2]] = vol
+    acc = np.zeros(pad, dtype=np.float32)
+    cnt = np.zeros(pad, dtype=np.float32)
+    for flip, rep in pass_schedule(True):
+        a1 = np.zeros(pad, dtype=np.float32)
+        c1 = np.zeros(pad, dtype=np.float32)
+        orc.sliding_window_pass(padded, crop, lambda x: orc.unet_forward(net, x), a1, c1, 0.5, flip, 1, fp16=False)
+        acc += rep * a1
+        cnt += rep * c1
+    mean = acc / np.maximum(cnt, 1)
+    ref = orc.finalize(mean, None, padded, vol.shape, 0.5, 30)
+    Z, Y, X = vol.shape
+    margin = np.abs(mean[:Z, :Y, :X]) < (1e-3 if precision == "fp32" else 3e-2)
+    assert margin.mean() < 0.2
+    assert np.array_equal(binaries[~margin], ref[~margin])
+    assert binaries.any() and not binaries.all()
+
+
 @pytest.mark.parametrize("threshold", [0.3, 0.7])
 def test_run_inference_threshold_other_than_half_divides_by_the_count_map(tmp_path, threshold):
     """The reference divides the logit sum by the count map BEFORE the sigmoid (inference.py:295), so a threshold other

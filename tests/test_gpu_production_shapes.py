@@ -188,15 +188,46 @@ def test_windows_with_odd_levels_pool_and_pad_like_monai_vs_oracle(eng, net, pre
         _check(f"{roi} window {b}", prec, out[:, :, sl], ref)
 
 
-def test_window_below_16_is_refused(eng):
-    """four 2 x poolings need 16 voxels (torch: "Output size is too small")"""
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_random_window_shapes_vs_oracle(eng, net, prec):
+    """A seeded sweep of window shapes nobody picked by hand: every dimension uniform in [16, 90], plus three that put odd rows
+    on the kernels of levels 0 and 1 that take rows of 32 / 64 voxels (z-reg conv: W >= 32; the pooling pass by full lines:
+    W % 64 == 0) and the smallest window there is (level 4 of 1 x 1 x 2).  Two windows per launch."""
+    import torch
+    from delivr_cfos_amd.synth import synth_volume_np
+    from oracle import delivr_oracle as orc
+
+    rng = np.random.default_rng(20260603)
+    shapes = [tuple(int(v) for v in rng.integers(16, 91, size=3)) for _ in range(6)] + [(16, 16, 32), (18, 130, 35), (33, 21, 128), (50, 33, 70)]
+    for roi in shapes:
+        shape = (roi[0], roi[1], roi[2] * 2)
+        vol = synth_volume_np(shape, seed=13, dense=True)
+        acc = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        st = eng.sw_infer(eng.make_sw_params(shape, roi, 0.0, None, 0, prec), eng.to_device(vol), acc)
+        eng.sync()
+        assert st["n_windows"] == 2 and st["n_skipped"] == 0
+        out = acc.cpu().numpy()
+        for b in range(2):
+            sl = slice(b * roi[2], (b + 1) * roi[2])
+            ref = orc.unet_forward(net, vol[:, :, sl].astype(np.float32)[None, None])[0, 0]
+            _check(f"{roi} window {b}", prec, out[:, :, sl], ref)
+
+
+@pytest.mark.parametrize("roi", [(12, 64, 64), (16, 16, 16), (31, 16, 20)])
+def test_windows_torch_refuses_are_refused(eng, net, roi):
+    """four 2 x poolings need 16 voxels (torch: "Output size is too small"), and a level 4 of one voxel has no InstanceNorm
+    statistics (torch: ValueError "Expected more than 1 spatial element") - the oracle raises, the library returns DLV_EUNSUP"""
     import torch
     from delivr_cfos_amd._lib import DelivrHipError
+    from oracle import delivr_oracle as orc
 
+    with pytest.raises((ValueError, RuntimeError)):
+        orc.unet_forward(net, np.zeros((1, 1) + roi, dtype=np.float32))
     with pytest.raises(DelivrHipError, match="at least 16"):
-        eng.sw_infer(eng.make_sw_params((12, 64, 64), (12, 64, 64), 0.0, None, 0, "fp16"),
-                     torch.zeros((12, 64, 64), dtype=torch.int16, device="cuda").view(torch.uint16),
-                     torch.zeros((12, 64, 64), dtype=torch.float32, device="cuda"))
+        eng.sw_infer(eng.make_sw_params(roi, roi, 0.0, None, 0, "fp16"), torch.zeros(roi, dtype=torch.int16, device="cuda").view(torch.uint16),
+                     torch.zeros(roi, dtype=torch.float32, device="cuda"))
+    with pytest.raises(DelivrHipError, match="at least 16"):
+        eng.unet_forward(torch.zeros((1, 1) + roi, dtype=torch.float32, device="cuda"), "fp32")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
