@@ -325,7 +325,7 @@ def test_zmarch_variants(eng, net, variant, li, c1, c2, prec):
     assert (out - base).abs().max() < 2 * tol_max
 
 
-def _pass_with_switches(prec, switches, lanes=None, big=False):
+def _pass_with_switches(prec, switches, lanes=None, big=False, odd=None):
     """one sliding-window pass on a fresh engine whose kernel-selection switches were set through dlv_diag_set
     (include/delivr_hip_diag.h): 64^3 windows of a 64x96x128 volume (6 windows, z-reg convs at levels 0/1), or two 128^3 windows"""
     import torch
@@ -340,9 +340,9 @@ def _pass_with_switches(prec, switches, lanes=None, big=False):
         if lanes:
             eng.set_lanes(lanes)
         eng.load_state_dict({"state_dict": random_state_dict(0)})
-        vol = synth_volume_np((128, 128, 256) if big else (64, 96, 128), seed=9, dense=True)
+        vol = synth_volume_np((odd[0], odd[1], 3 * odd[2]) if odd else (128, 128, 256) if big else (64, 96, 128), seed=9, dense=True)
         acc = torch.zeros(vol.shape, dtype=torch.float32, device="cuda")
-        eng.sw_infer(eng.make_sw_params(vol.shape, (128, 128, 128) if big else (64, 64, 64), 0.5, None, 0, prec), eng.to_device(vol), acc)
+        eng.sw_infer(eng.make_sw_params(vol.shape, odd or ((128, 128, 128) if big else (64, 64, 64)), 0.5, None, 0, prec), eng.to_device(vol), acc)
         eng.sync()
         return acc.cpu().numpy()
     finally:
@@ -374,6 +374,25 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(prec):
         assert rel < tol, (sw, rel)
     with pytest.raises(Exception):
         _pass_with_switches(prec, {"no_such_switch": 1})
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_library_switches_on_windows_with_odd_levels(prec):
+    """The same on (67, 93, 70) windows (odd at levels 0, 1 and 3: 33 x 46 x 35, 16 x 23 x 17, 8 x 11 x 8, 4 x 5 x 4): the pooling
+    pass of an odd level does not write back (MaxPool3d drops the last plane), a second pass - or the consumers' activation on
+    load ("fuse_levels") - makes the skip tensor final, the up-sampled tensor is replicate-padded."""
+    odd = (67, 93, 70)
+    base = _pass_with_switches(prec, {}, odd=odd)
+    std = float(base.std())
+    np.testing.assert_array_equal(_pass_with_switches(prec, {}, lanes=1, odd=odd), base, err_msg="lanes")
+    for sw in ({"zreg_dbg": 1}, {"generic_ncb": 1}, {"pool_rows_off": 1}):
+        np.testing.assert_array_equal(_pass_with_switches(prec, sw, odd=odd), base, err_msg=str(sw))
+    tol = 2e-3 if prec == "fp16" else 2e-2
+    for sw in ({"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"deep_mask": 0}, {"no_zmarch": 1}):
+        a = _pass_with_switches(prec, sw, odd=odd)
+        rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
+        print(sw, "rel rms vs default:", rel)
+        assert rel < tol, (sw, rel)
 
 
 # ---------------------------------------------------------------------------------------------------
