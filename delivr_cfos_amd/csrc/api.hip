@@ -691,6 +691,7 @@ int dlv_diag_set(dlv_ctx* ctx, const char* name, int value) {
     else if (n == "ccl_simple") ctx->ccl_simple = value != 0;
     else if (n == "resample_simple") ctx->resample_simple = value != 0;
     else if (n == "resample_run16") ctx->resample_run16 = value != 0;
+    else if (n == "tiff_chunk") ctx->tiff_chunk = value > 0 ? value : 0;
     else return dlv_fail(ctx, DLV_EINVAL, "dlv_diag_set: unknown switch '%s'", name);
     return DLV_OK;
 }

@@ -131,6 +131,7 @@ struct dlv_ctx {
     int deep_small = 1;      // 0 = levels smaller than a tile of conv_deep.hip and its 32-output-channel layers take the generic conv (A/B)
     bool pool_rows_off = false, erode_xy_split = false, erode_z_two_sweeps = false, ccl_simple = false;
     bool resample_simple = false, resample_run16 = false;
+    int tiff_chunk = 0;      // planes per staging chunk of dlv_tiff_stack_to_device (0: ~256 MB; tests: the double-buffer hand-over on small planes)
     bool prof_on = false;
     std::vector<DlvProfSlot> prof_slots;
     std::vector<DlvProfPending> prof_pending;

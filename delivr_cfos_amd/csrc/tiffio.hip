@@ -13,6 +13,8 @@
 #include "common.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <zlib.h>
 
 #include <cstdio>
@@ -145,9 +147,16 @@ const char* parse_ifd(const uint8_t* data, size_t n, TiffInfo& t) {
 // early ("early change").  Every table string is a substring of the output written so far - entry `next` is the
 // previous string plus the byte that follows it in the output - so the table holds (offset, length) pairs and a code
 // is decoded with one forward copy inside the output buffer.  Returns the number of bytes written (<= cap).
+// Camera noise compresses to strings of ~1.4 bytes, so what is paid is the work per CODE: a string of up to 8 bytes is copied as
+// ONE unaligned 8-byte load + store whatever its length (what lands behind it is overwritten by the next code; `dst` must have
+// LZW_SLACK writable bytes behind `cap`), the bit buffer is refilled four bytes at a time, an entry's offset and length share a
+// word.  A 2048 x 2048 uint16 plane of dense synthetic tissue on one core of the build container: 100 -> 58 ms (uniform random
+// 16-bit values 44 ms, brain with background 24 ms).  Tried and slower: the 256 literals as table entries pointing into a prefix
+// of the buffer, which makes literal-or-string no branch but every literal an 8-byte store - the overlapping wide stores defeat
+// store-to-load forwarding for the strings that follow (random values 44 -> 77 ms).
+constexpr size_t LZW_SLACK = 16;
 size_t lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
-    uint32_t off[4096];
-    uint32_t len[4096];
+    uint64_t ent[4096];  // offset << 16 | length (a string is at most 4096 - 258 + 1 bytes long)
     int width = 9, next = 258;
     long long prev_pos = -1;  // where the previous code's string starts in dst
     uint32_t prev_len = 0;
@@ -155,35 +164,60 @@ size_t lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
     int nbits = 0;
     size_t ip = 0, op = 0;
     for (;;) {
-        while (nbits <= 56 && ip < n) {
-            acc = (acc << 8) | src[ip++];
-            nbits += 8;
+        if (nbits <= 32) {
+            if (ip + 4 <= n) {
+                uint32_t w;
+                memcpy(&w, src + ip, 4);
+                acc = (acc << 32) | __builtin_bswap32(w);
+                ip += 4;
+                nbits += 32;
+            } else {
+                while (nbits <= 56 && ip < n) {
+                    acc = (acc << 8) | src[ip++];
+                    nbits += 8;
+                }
+            }
         }
         if (nbits < width) break;
         const int code = (int)((acc >> (nbits - width)) & ((1u << width) - 1));
         nbits -= width;
-        if (code == 257) break;
-        if (code == 256) {
-            width = 9;
-            next = 258;
-            prev_pos = -1;
-            continue;
-        }
         const size_t start = op;
         uint32_t l;
         if (code < 256) {
             if (op >= cap) break;
             dst[op++] = (uint8_t)code;
             l = 1;
-        } else if (code < next) {
-            l = len[code];
+        } else if (code >= 258 && code < next) {
+            const uint64_t e = ent[code];
+            l = (uint32_t)(e & 0xffffu);
+            const size_t o = (size_t)(e >> 16);
             if (op + l > cap) break;
-            const uint8_t* from = dst + off[code];
+            const uint8_t* from = dst + o;
             uint8_t* to = dst + op;
-            if (off[code] + l <= op && l >= 16) memcpy(to, from, l);
-            else for (uint32_t k = 0; k < l; ++k) to[k] = from[k];
+            // (the string ends at or before op: its l bytes are final; what an 8-byte load reads behind them is not, and lands
+            // behind the string in the output, where the next code writes)
+            if (l <= 8) {
+                uint64_t v;
+                memcpy(&v, from, 8);
+                memcpy(to, &v, 8);
+            } else if (o + l + 8 <= op) {  // far enough back for 8-byte steps that never read what this copy writes
+                for (uint32_t k = 0; k < l; k += 8) {
+                    uint64_t v;
+                    memcpy(&v, from + k, 8);
+                    memcpy(to + k, &v, 8);
+                }
+            } else {
+                for (uint32_t k = 0; k < l; ++k) to[k] = from[k];
+            }
             op += l;
-        } else if (code == next && prev_pos >= 0) {  // KwKwK: previous string + its own first byte (overlapping copy)
+        } else if (code == 256) {
+            width = 9;
+            next = 258;
+            prev_pos = -1;
+            continue;
+        } else if (code == 257) {
+            break;
+        } else if (code == next && prev_pos >= 0) {  // KwKwK: previous string + its own first byte (the source ends where the copy starts)
             l = prev_len + 1;
             if (op + l > cap) break;
             const uint8_t* from = dst + prev_pos;
@@ -194,8 +228,7 @@ size_t lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
             break;  // corrupt stream
         }
         if (prev_pos >= 0 && next < 4096) {
-            off[next] = (uint32_t)prev_pos;
-            len[next] = prev_len + 1;
+            ent[next] = ((uint64_t)prev_pos << 16) | (prev_len + 1);
             ++next;
         }
         prev_pos = (long long)start;
@@ -216,7 +249,7 @@ const char* decode_plane(const uint8_t* data, size_t n, const TiffInfo& t, uint1
     const size_t nx = ((size_t)t.width + seg_w - 1) / seg_w, ny = ((size_t)t.height + seg_h - 1) / seg_h;
     if (t.strip_off.size() < nx * ny) return t.tiled ? "fewer tiles than the image needs" : "fewer strips than the image needs";
     const size_t seg_row_bytes = (size_t)seg_w * bps;
-    scratch.resize((size_t)seg_h * seg_row_bytes);
+    scratch.resize((size_t)seg_h * seg_row_bytes + LZW_SLACK);  // (the LZW decoder's 8-byte copies run past the end of a string)
     for (size_t sy = 0; sy < ny; ++sy)
         for (size_t sx = 0; sx < nx; ++sx) {
             const size_t s = sy * nx + sx;
@@ -505,7 +538,10 @@ int dlv_tiff_write_plane(const char* path, const void* data_host, int height, in
 }
 
 // planes paths[0..n_planes) -> vol_dev[(z0 + i) * plane_stride + y * row_stride + x], decoded by n_threads host threads
-// into two pinned staging chunks that alternate between "being filled" and "being copied"
+// into two pinned staging chunks that alternate between "being filled" and "being copied".  The threads live for the whole
+// call and take planes from one queue (their file / scratch buffers keep their capacity: a thread per chunk paid an mmap, the
+// page faults and a munmap of ~13 MB for every plane - profiles/README.md, r06final_tiff_threads); a plane of chunk c may be
+// decoded once the copy that read the staging buffer of chunk c - 2 has finished.
 int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_planes, int height, int width, uint16_t* vol_dev,
                              long long plane_stride, long long row_stride, int n_threads) {
     if (!ctx || !paths || !vol_dev) return DLV_EINVAL;
@@ -515,10 +551,12 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
     // no exception crosses the C ABI: allocation failures of the vectors / strings / threads below are reported as codes
     try {
     if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    n_threads = std::min(n_threads, n_planes);
     const size_t plane_elems = (size_t)height * width;
     // planes per staging chunk: at least one per thread, about 256 MB
     const int by_size = (int)std::max<size_t>(1, ((size_t)256 << 20) / (plane_elems * 2));
-    const int chunk = std::max(1, std::min(n_planes, std::max(n_threads, by_size)));
+    const int chunk = ctx->tiff_chunk > 0 ? std::min(n_planes, ctx->tiff_chunk) : std::max(1, std::min(n_planes, std::max(n_threads, by_size)));
+    const int n_chunks = (n_planes + chunk - 1) / chunk;
     // staging buffers and events are released on every exit path
     struct Staging {
         uint16_t* buf[2] = {nullptr, nullptr};
@@ -530,7 +568,7 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
             }
         }
     } stg;
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < std::min(2, n_chunks); ++b) {
         DLV_HIP(ctx, hipHostMalloc((void**)&stg.buf[b], (size_t)chunk * plane_elems * 2, hipHostMallocDefault));
         DLV_HIP(ctx, hipEventCreateWithFlags(&stg.ev[b], hipEventDisableTiming));
     }
@@ -538,57 +576,80 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
     hipEvent_t* done = stg.ev;
     std::string err;
     std::atomic<bool> failed{false}, oom{false};
-    int rc = DLV_OK;
-    for (int c0 = 0, it = 0; c0 < n_planes && !failed; c0 += chunk, ++it) {
-        const int b = it & 1;
-        const int cn = std::min(chunk, n_planes - c0);
-        if (it >= 2) (void)hipEventSynchronize(done[b]);  // the copy that read this staging chunk has finished
-        std::atomic<int> next{0};
-        std::vector<std::string> errs(n_threads);
-        std::vector<std::thread> pool;
-        pool.reserve(n_threads);
-        struct Joiner {  // a failed thread start (std::system_error) must find no joinable thread in the dying vector
-            std::vector<std::thread>& p;
-            std::atomic<bool>& stop;
-            ~Joiner() {
-                for (auto& th : p)
-                    if (th.joinable()) {
-                        stop = true;
-                        th.join();
-                    }
+    std::atomic<int> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    int writable = std::min(2, n_chunks);          // chunks [0, writable) may be decoded into their staging buffer (guarded by mu)
+    std::vector<int> decoded(n_chunks, 0);          // planes of a chunk that are in the staging buffer (guarded by mu)
+    std::vector<std::string> errs(n_threads);
+    std::vector<std::thread> pool;
+    pool.reserve(n_threads);
+    struct Joiner {  // every exit path (also a failed thread start: std::system_error) stops and joins what is running
+        std::vector<std::thread>& p;
+        std::atomic<bool>& stop;
+        std::mutex& mu;
+        std::condition_variable& cv;
+        ~Joiner() {
+            bool any = false;
+            for (auto& th : p) any = any || th.joinable();
+            if (!any) return;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
             }
-        } joiner{pool, failed};
-        for (int t = 0; t < std::min(n_threads, cn); ++t)
-            pool.emplace_back([&, t]() {
-                try {  // an exception escaping a thread function would call std::terminate
-                std::vector<uint8_t> buf, scratch;
-                for (;;) {
-                    const int i = next.fetch_add(1);
-                    if (i >= cn || failed) break;
-                    const char* path = paths[c0 + i];
-                    const char* e = nullptr;
-                    TiffInfo ti;
-                    if (!read_file(path, buf)) e = "cannot read the file";
-                    if (!e) e = parse_ifd(buf.data(), buf.size(), ti);
-                    if (!e && ((int)ti.height != height || (int)ti.width != width)) e = "plane size differs from the first plane";
-                    if (!e) e = decode_plane(buf.data(), buf.size(), ti, stage[b] + (size_t)i * plane_elems, scratch);
-                    if (e) {
-                        errs[t] = std::string(path) + ": " + e;
-                        failed = true;
-                    }
+            cv.notify_all();
+            for (auto& th : p)
+                if (th.joinable()) th.join();
+        }
+    };
+    std::atomic<bool> stop{false};
+    Joiner joiner{pool, stop, mu, cv};
+    for (int t = 0; t < n_threads; ++t)
+        pool.emplace_back([&, t]() {
+            try {  // an exception escaping a thread function would call std::terminate
+            std::vector<uint8_t> buf, scratch;
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n_planes || failed || stop) break;
+                const int c = i / chunk;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return c < writable || failed || stop; });
                 }
-                } catch (...) {
+                if (failed || stop) break;
+                const char* path = paths[i];
+                const char* e = nullptr;
+                TiffInfo ti;
+                if (!read_file(path, buf)) e = "cannot read the file";
+                if (!e) e = parse_ifd(buf.data(), buf.size(), ti);
+                if (!e && ((int)ti.height != height || (int)ti.width != width)) e = "plane size differs from the first plane";
+                if (!e) e = decode_plane(buf.data(), buf.size(), ti, stage[c & 1] + (size_t)(i - c * chunk) * plane_elems, scratch);
+                if (e) errs[t] = std::string(path) + ": " + e;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (e) failed = true;
+                    ++decoded[c];
+                }
+                cv.notify_all();
+            }
+            } catch (...) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
                     failed = true;  // (no allocation here: the message is set by the caller)
                     oom = true;
                 }
-            });
-        for (auto& th : pool) th.join();
-        if (failed) {
-            for (auto& e : errs)
-                if (!e.empty()) err = e;
-            if (err.empty() && oom) err = "out of host memory while decoding";
-            break;
+                cv.notify_all();
+            }
+        });
+    int rc = DLV_OK;
+    for (int c = 0; c < n_chunks && !failed; ++c) {
+        const int b = c & 1, c0 = c * chunk;
+        const int cn = std::min(chunk, n_planes - c0);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return decoded[c] == cn || failed; });
         }
+        if (failed) break;
         hipError_t he = hipSuccess;
         if (plane_stride == (long long)height * row_stride) {  // planes back to back: one 2-D copy for the chunk
             he = hipMemcpy2DAsync(vol_dev + (long long)c0 * plane_stride, (size_t)row_stride * 2, stage[b], (size_t)width * 2,
@@ -601,13 +662,29 @@ int dlv_tiff_stack_to_device(dlv_ctx* ctx, const char* const* paths, int n_plane
         }
         if (he != hipSuccess) {
             err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(he);
+            std::lock_guard<std::mutex> lk(mu);
             failed = true;
             break;
         }
         (void)hipEventRecord(done[b], ctx->stream);
+        if (c + 2 < n_chunks) {  // chunk c + 2 shares this staging buffer: writable once the copy has read it (chunk c + 1 decodes meanwhile)
+            (void)hipEventSynchronize(done[b]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                writable = c + 3;
+            }
+            cv.notify_all();
+        }
     }
+    if (failed) cv.notify_all();
+    for (auto& th : pool) th.join();
     (void)hipStreamSynchronize(ctx->stream);  // before the staging buffers go away
-    if (failed) rc = dlv_fail(ctx, oom ? DLV_ENOMEM : DLV_EUNSUP, "%s", err.c_str());
+    if (failed) {
+        for (auto& e : errs)
+            if (!e.empty()) err = e;
+        if (err.empty() && oom) err = "out of host memory while decoding";
+        rc = dlv_fail(ctx, oom ? DLV_ENOMEM : DLV_EUNSUP, "%s", err.c_str());
+    }
     return rc;
     } catch (const std::bad_alloc&) {
         (void)hipStreamSynchronize(ctx->stream);

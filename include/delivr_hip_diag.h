@@ -21,6 +21,8 @@ extern "C" {
  *   "pool_rows_off" 1     the pooling pass by pooled voxels instead of by full lines
  *   "erode_xy_split" 1, "erode_z_two_sweeps" 1, "ccl_simple" 1, "resample_simple" 1, "resample_run16" 1
  *                         the earlier kernels of finalize / CCL / the resamplers (cross-checks in tests/test_gpu_parity.py)
+ *   "tiff_chunk" n        planes per pinned staging chunk of dlv_tiff_stack_to_device (0: ~256 MB): the hand-over between the two
+ *                         staging buffers on stacks of small planes (tests/test_gpu_pipeline.py)
  * DLV_EINVAL for an unknown name. */
 int dlv_diag_set(dlv_ctx* ctx, const char* name, int value);
 

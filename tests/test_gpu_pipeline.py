@@ -504,6 +504,19 @@ def test_tiff_stack_ingest_to_device(golden_dir):
                   "tiff_tiled16_deflate_pred.tif"]
         vol2 = load_stack_to_device(eng, [os.path.join(golden_dir, names2[(3 * i) % 5]) for i in range(11)], n_threads=3)
         np.testing.assert_array_equal(vol2.cpu().numpy(), np.broadcast_to(want2, (11,) + want2.shape))
+        # the two staging buffers change hands: chunks of 4 / 1 / 23 planes ("tiff_chunk"; by default ~256 MB, one chunk here), more
+        # threads than planes of a chunk (a thread that has taken a plane of chunk c + 2 waits for the copy of chunk c), a last chunk
+        # that is not full, planes that differ in encoding; then a file that is missing in the LAST chunk: the error, no hang
+        many = [os.path.join(golden_dir, names[(7 * i) % 3]) for i in range(61)]
+        for chunk, thr in ((4, 9), (1, 3), (23, 2), (5, 64)):
+            eng.diag_set("tiff_chunk", chunk)
+            got = load_stack_to_device(eng, many, n_threads=thr).cpu().numpy()
+            np.testing.assert_array_equal(got, np.broadcast_to(want, (61, 97, 131)), err_msg=f"chunk {chunk}, {thr} threads")
+        eng.diag_set("tiff_chunk", 4)
+        with pytest.raises(RuntimeError, match="no_such_plane"):
+            load_stack_to_device(eng, many[:58] + [os.path.join(golden_dir, "no_such_plane.tif")] + many[59:], n_threads=6)
+        np.testing.assert_array_equal(load_stack_to_device(eng, many[:9], n_threads=6).cpu().numpy(), np.broadcast_to(want, (9, 97, 131)))
+        eng.diag_set("tiff_chunk", 0)
     finally:
         eng.close()
 
