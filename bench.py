@@ -778,6 +778,11 @@ def main():
     roofline_isolated = None
     if prof and lanes_used > 1 and not args.no_isolated and world == 1:
         eng.set_lanes(1)
+        # (one unmeasured one-lane pass first: the chip has just spent a second on the checksum's light kernels, and a pass that
+        # starts on a rested chip runs above the sustained clock for its first seconds - 1276 us per launch of the hot kernel
+        # against the 1340 us rocprofv3 sees over whole one-lane passes of the same box, profiles/README.md r06final)
+        step()
+        fence()
         eng.prof_reset()
         eng.prof_enable(True)
         step()
