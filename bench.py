@@ -72,7 +72,27 @@ def _cpu_info():
                     cores.add((pid, v))
     except OSError:
         pass
-    return {"model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count()}
+    # the container's CPU bandwidth limit (cgroup v2 cpu.max "quota period", v1 cfs_quota_us / cfs_period_us): a box that shows 256
+    # logical CPUs may grant this process 16 cores' worth of time - threads beyond that only get throttled (the thread probe of
+    # the CPU baseline and the TIFF decode pool both stop scaling there)
+    quota = None
+    for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            with open(qf) as f:
+                txt = f.read().split()
+            if pf is None:
+                q, per = txt[0], txt[1]
+            else:
+                q = txt[0]
+                with open(pf) as f:
+                    per = f.read().split()[0]
+            if q not in ("max", "-1"):
+                quota = round(int(q) / int(per), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count(),
+            "cgroup_cpu_quota_cores": quota}
 
 
 def cpu_baseline(eng, sd, vol, shape, roi, n_active_full, vox_full, threads, crop_edge, precision, weights_name, acc_full, zblock):
