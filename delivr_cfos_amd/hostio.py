@@ -30,8 +30,10 @@ N_STAGE = 4
 # 32 / 64 / 128 threads - buffered writes of ONE file serialise on its inode lock, more threads only add hand-overs - and the
 # mapping 3.5 / 3.8 / 2.1 / 1.1 / 0.7 GB/s: page faults that allocate tmpfs pages scale negatively.  A single file takes 4-7 GB/s
 # from the kernel, whatever the host does; the writers exist to keep the copy engine and the coordinator from waiting.
+# (The boxes these figures come from grant the process 16 cores of CPU time - cgroup cpu.max - whatever they show: part of why more
+# threads were slower there.  $DLV_IO_WRITE_THREADS overrides the 8 on a host that has its cores to itself.)
 WRITE_MODE = "pwrite"
-WRITE_THREADS = 8
+WRITE_THREADS = max(1, int(os.environ.get("DLV_IO_WRITE_THREADS") or 8))
 # Files written into a FRESH file (create_npy: ftruncate, every byte reads as zero) skip the blocks that are zero in HBM: the file
 # stays sparse there and reads back the same bytes.  A brain fills ~40 % of its box - binaries.npy and the label volume are zero
 # outside it - so ~60 % of the 4.3 + 17 GB never cross PCIe or the kernel's one-file write path (the bottleneck of step 3).
