@@ -680,6 +680,7 @@ int dlv_diag_set(dlv_ctx* ctx, const char* name, int value) {
     else if (n == "no_upconv") ctx->fold_up = value ? 0 : 1;
     else if (n == "upconv_simple") ctx->upconv_simple = value ? 1 : 0;
     else if (n == "fuse_levels") ctx->fuse_levels = value;
+    else if (n == "fuse_layers") ctx->fuse_layers = value;
     else if (n == "zreg_mask") ctx->zreg_mask = value;
     else if (n == "deep_mask") ctx->deep_mask = value;
     else if (n == "generic_ncb") ctx->generic_ncb = value;

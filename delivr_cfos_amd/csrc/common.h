@@ -123,6 +123,11 @@ struct dlv_ctx {
     // environment (a stray DLV_* in a user's shell must not change kernels): dlv_diag_set (include/delivr_hip_diag.h) sets them
     // per context.  What the library does read from the environment: DLV_LANES, DLV_LAUNCH_LOG, DLV_RCCL_PATH / ROCM_PATH /
     // DLV_FORCE_RCCL (transport), nothing else.
+    // bit li: conv block li applies the InstanceNorm + Mish of its first input itself while it stages the planes (no normalisation
+    // pass over that tensor).  Default: block 17 (upcat_1.conv_1) only - the one site where it pays: -1.4...-1.7 % of a pass on every
+    // workload, masks identical; block 16 (the raw skip tensor into the addend conv) +2.2 %, the level-1 sites +0.3...+0.9 %
+    // (profiles/r06z_fuse_sites_ab.txt).  The level-wise switch of rounds 2-6 saw the two level-0 sites cancel.
+    int fuse_layers = 1 << 17;
     int fuse_levels = 0;     // bit l: raw tensors of level l are activated by the z-reg conv that stages them (no norm pass)
     int zreg_mask = 3;       // 1 = Cin 32, 2 = Cin 64 layers may take the register-resident-weights conv
     int deep_mask = 2;       // conv_deep.hip: bit 0 = the layers the LDS-weights z-march also takes, bit 1 = the others

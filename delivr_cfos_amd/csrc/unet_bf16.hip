@@ -1285,13 +1285,14 @@ struct Net16 {
                dlv_conv3_zreg_supports(L.cin, L.cout, c1, c2, d.W) && ((L.cin == 32 ? 1 : 2) & zreg_mask);
     }
     bool fuses_first_input(int li, int c1, int c2, Dims d) const {
-        // which levels' raw tensors are activated by the consuming conv while it stages them (bit l = level l).  Measured
-        // (profiles/README.md, round 2): the Mish costs the staging conv more VALU time than the separate pass costs HBM
-        // time at level 0, so the default fuses nothing into the convs; the transposed convs and the final 1x1x1 conv
-        // always activate on load.  dlv_diag_set "fuse_levels" overrides (A/B).
+        // which raw tensors are activated by the consuming conv while it stages them: per conv block (ctx->fuse_layers, default
+        // block 17 = upcat_1.conv_1: common.h) or per level (fuse_levels, bit l = level l; A/B).  The Mish costs the staging conv
+        // issue cycles (one wave per SIMD), the separate pass costs HBM time: it pays where the pass it removes is a whole
+        // read + write of a level-0 tensor and nothing else changes; the transposed convs and the final 1x1x1 conv always
+        // activate on load.
         const int fuse_levels = ctx->fuse_levels;
         static const int level_of[DLV_N_CONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
-        return ((fuse_levels >> level_of[li]) & 1) && c1 == 32 && zreg_runs(li, c1, c2, d);
+        return (((fuse_levels >> level_of[li]) & 1) || ((ctx->fuse_layers >> li) & 1)) && c1 == 32 && zreg_runs(li, c1, c2, d);
     }
     // InstanceNorm + Mish in place (the tensor becomes final); PW: the format the activated tensor is written in (P, except
     // where the mixed mode hands a bf16 level-1 tensor to the fp16 level 0)

@@ -13,6 +13,8 @@ extern "C" {
  *   "no_upconv" 1         upcat_1 as transposed conv + 64-channel conv instead of the folded form (upconv.hip)
  *   "upconv_simple" 1     the one-tile-per-workgroup upconv kernel for every shape
  *   "fuse_levels" mask    bit l: raw tensors of level l are activated by the z-reg conv that stages them (no normalisation pass)
+ *   "fuse_layers" mask    bit li: conv block li activates its first input itself (default 1 << 17: upcat_1.conv_1, the one site that
+ *                         pays; 0 = a normalisation pass in front of every conv)
  *   "zreg_mask" mask      1 = Cin 32, 2 = Cin 64 layers may take the register-resident-weights conv (default 3)
  *   "deep_mask" mask      conv_deep.hip: bit 0 = the layers the LDS-weights z-march also takes, bit 1 = the others (default 2)
  *   "generic_ncb" n       cout blocks per workgroup of the generic conv (0: its own choice)

@@ -352,7 +352,8 @@ def _pass_with_switches(prec, switches, lanes=None, big=False, odd=None):
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_library_switches_that_pick_other_kernels_give_the_same_pass(prec):
     """Every kernel-selection switch (dlv_diag_set; the library reads none from the environment) selects kernels, never results:
-    the activation fused into the z-reg conv's staging ("fuse_levels": levels 0 and 1, incl. the 16-row and the addend
+    the activation fused into the z-reg conv's staging (by conv block, "fuse_layers": the default fuses block 17 = upcat_1.conv_1,
+    0 = a normalisation pass in front of every conv; by level, "fuse_levels": levels 0 and 1, incl. the 16-row and the addend
     instantiations), edge-step code on every plane ("zreg_dbg"), the LDS-weights z-march instead of the z-reg conv
     ("zreg_mask"), cout blocks of the generic conv ("generic_ncb"), lanes, the pooling pass by pooled voxels instead of by
     full lines ("pool_rows_off"), upcat_1 unfolded ("no_upconv") or folded with the one-tile kernel ("upconv_simple"), the
@@ -366,8 +367,8 @@ def test_library_switches_that_pick_other_kernels_give_the_same_pass(prec):
     # same values up to the rounding of one 16-bit store (activation applied while staging: the activated tensor is never
     # rounded through HBM differently, but the InstanceNorm partial sums are taken over other tiles) / another kernel
     tol = 2e-3 if prec == "fp16" else 2e-2
-    for sw in ({"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"no_upconv": 1}, {"upconv_simple": 1}, {"deep_mask": 0},
-               {"no_upconv": 1, "fuse_levels": 3}):
+    for sw in ({"fuse_layers": 0}, {"fuse_layers": 3 << 16}, {"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"no_upconv": 1},
+               {"upconv_simple": 1}, {"deep_mask": 0}, {"no_upconv": 1, "fuse_levels": 3}, {"no_upconv": 1, "fuse_layers": 0}):
         a = _pass_with_switches(prec, sw)
         rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
         print(sw, "rel rms vs default:", rel)
@@ -388,7 +389,7 @@ def test_library_switches_on_windows_with_odd_levels(prec):
     for sw in ({"zreg_dbg": 1}, {"generic_ncb": 1}, {"pool_rows_off": 1}):
         np.testing.assert_array_equal(_pass_with_switches(prec, sw, odd=odd), base, err_msg=str(sw))
     tol = 2e-3 if prec == "fp16" else 2e-2
-    for sw in ({"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"deep_mask": 0}, {"no_zmarch": 1}):
+    for sw in ({"fuse_layers": 0}, {"fuse_levels": 1}, {"fuse_levels": 2}, {"fuse_levels": 3}, {"zreg_mask": 0}, {"deep_mask": 0}, {"no_zmarch": 1}):
         a = _pass_with_switches(prec, sw, odd=odd)
         rel = float(np.sqrt(np.mean((a - base) ** 2)) / std)
         print(sw, "rel rms vs default:", rel)
@@ -467,3 +468,6 @@ def test_pooling_pass_by_full_lines_is_bit_identical_at_128():
     voxels = _pass_with_switches("fp16", {"pool_rows_off": 1}, big=True)
     assert np.isfinite(rows).all() and rows.std() > 0
     np.testing.assert_array_equal(rows, voxels)
+    # ... and the 16-row activating instantiation of the z-reg conv (the default's upcat_1.conv_1 at these windows) against a
+    # normalisation pass + the plain one: the activated value is rounded to 16 bits once either way
+    np.testing.assert_array_equal(_pass_with_switches("fp16", {"fuse_layers": 0}, big=True), rows)
