@@ -109,6 +109,39 @@ def test_unet_seed_reproduces_and_logits(golden_dir):
     np.testing.assert_allclose(out, g["logits32"], rtol=1e-4, atol=1e-4)
 
 
+def test_upcat_pads_an_odd_level_at_the_far_end_with_the_edge_value():
+    """MONAI's UpCat (basic_unet.py, is_pad=True - the default the reference's BasicUNet(...) call leaves in place,
+    inference/inference.py:190-197) replicate-pads the up-sampled tensor by ONE voxel at the FAR end of every dimension in which
+    the skip tensor is odd; MaxPool3d(2) floors.  The oracle's UpCat against that statement written out with numpy (np.pad
+    mode="edge" on the right only), and the whole network on a window with odd levels: finite, right shape, and changed by a
+    change of the last plane of the input (the plane MaxPool3d drops at level 0 still feeds conv_0 and the skip connection)."""
+    import torch
+    from oracle import delivr_oracle as orc
+
+    net = orc.build_unet(seed=3)
+    up = net.upcat_4
+    x = torch.randn(1, 256, 1, 2, 3)
+    x_e = torch.randn(1, 128, 3, 5, 7)  # odd in every dimension: 2 * (1, 2, 3) = (2, 4, 6) is one short everywhere
+    with torch.no_grad():
+        got = up(x, x_e).numpy()
+        x0 = up.upsample(x).numpy()
+        assert x0.shape == (1, 128, 2, 4, 6)
+        padded = np.pad(x0, ((0, 0), (0, 0), (0, 1), (0, 1), (0, 1)), mode="edge")
+        want = up.convs(torch.cat([x_e, torch.from_numpy(padded)], dim=1)).numpy()
+    np.testing.assert_array_equal(got, want)
+    assert np.array_equal(padded[..., -1], padded[..., -2]) and np.array_equal(padded[:, :, -1], padded[:, :, -2])
+    # even skip tensor: no padding at all
+    x_e2 = torch.randn(1, 128, 2, 4, 6)
+    with torch.no_grad():
+        np.testing.assert_array_equal(up(x, x_e2).numpy(), up.convs(torch.cat([x_e2, up.upsample(x)], dim=1)).numpy())
+    vol = np.random.default_rng(0).integers(200, 4000, size=(1, 1, 35, 21, 50)).astype(np.float32)
+    out = orc.unet_forward(net, vol)
+    assert out.shape == vol.shape and np.isfinite(out).all()
+    vol2 = vol.copy()
+    vol2[0, 0, -1] += 500.0
+    assert np.abs(orc.unet_forward(net, vol2) - out).max() > 0
+
+
 def test_resamplers(golden_dir):
     g = _load(golden_dir, "scipy_resample.npz")
     np.testing.assert_array_equal(orc.block_mean_u16(g["bm_in"], tuple(g["bm_factors"])), g["bm_out"])
